@@ -1,0 +1,325 @@
+"""Seeded synthetic clip generator (harness).
+
+Produces, deterministically from a seed and without any RNG library state:
+  * source frames (noise blended with a gradient and a checker, full code range),
+  * a GoPro-style ``opencv_fisheye`` lens,
+  * a smooth quaternion track and, from it, the per-row rolling-shutter
+    matrices ``float32(inv(new_k * R_row))`` laid out as ``[rows][14]`` exactly
+    like ``FrameTransform.matrices`` (frame_transform.rs:13, :249-308),
+  * per-plane ``KernelParams`` filled the way ``get_frame_transform_at``
+    (stabilization/mod.rs:253-326) and the render loop (rendering/mod.rs:531-541) do.
+
+The matrices are *inputs* of the parity contract (the reference builds them
+with an f64 SVD pseudo-inverse that is not reproducible bit-for-bit), so they
+are generated once here in float64 and fed identically to oracle and kernel.
+"""
+import math
+
+import numpy as np
+
+from . import abi
+
+MASK64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x):
+    """Vectorised splitmix64 finaliser over a uint64 array (pure integer hash)."""
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & MASK64
+        x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & MASK64
+        x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & MASK64
+        x = x ^ (x >> np.uint64(31))
+    return x
+
+
+def plane_pattern(width, height, channels, dtype, seed, max_value=None):
+    """Deterministic test pattern: 50% hash noise + 30% diagonal gradient + 20% 16-px checker.
+
+    Returns an array of shape (height, width, channels) of ``dtype``.
+    Integer types span the full code range (or ``0..max_value``); float types span
+    ``[0, max_value)`` (default 1.0).
+    """
+    dt = np.dtype(dtype)
+    yy, xx = np.meshgrid(np.arange(height, dtype=np.uint64), np.arange(width, dtype=np.uint64), indexing="ij")
+    out = np.empty((height, width, channels), dtype=dt)
+    for ch in range(channels):
+        key = (np.uint64(seed) << np.uint64(32)) ^ (np.uint64(ch) << np.uint64(56)) ^ (yy * np.uint64(65537) + xx)
+        noise = (_splitmix64(key) >> np.uint64(40)).astype(np.float64) / float(1 << 24)          # [0,1)
+        grad = ((xx.astype(np.float64) / max(width - 1, 1)) + (yy.astype(np.float64) / max(height - 1, 1))) * 0.5
+        if ch % 2:
+            grad = 1.0 - grad
+        checker = (((xx >> np.uint64(4)) + (yy >> np.uint64(4))) & np.uint64(1)).astype(np.float64)
+        v = 0.5 * noise + 0.3 * grad + 0.2 * checker                                                 # [0,1)
+        if dt.kind == "u":
+            top = float(np.iinfo(dt).max if max_value is None else max_value)
+            out[:, :, ch] = np.minimum(np.floor(v * (top + 1.0)), top).astype(dt)
+        else:
+            out[:, :, ch] = (v * float(1.0 if max_value is None else max_value)).astype(dt)
+    return out
+
+
+def align(n, a):
+    return (n + a - 1) // a * a
+
+
+def make_plane_buffer(width, height, pixel_type, seed, max_value=None, stride_align=256, fill=0xA5):
+    """Host buffer (1-D uint8, len = stride*height) holding a pattern plane; returns (buf, stride)."""
+    _, dt, count, _ = abi.PIXEL_TYPES[pixel_type]
+    bpp = np.dtype(dt).itemsize * count
+    stride = align(width * bpp, stride_align)
+    buf = np.full(stride * height, fill, dtype=np.uint8)
+    pat = plane_pattern(width, height, count, dt, seed, max_value)
+    view = buf.reshape(height, stride)[:, : width * bpp]
+    view[:] = pat.reshape(height, width * count).view(np.uint8).reshape(height, width * bpp)
+    return buf, stride
+
+
+# --------------------------------------------------------------------- lens / motion
+def gopro_style_lens(width, height):
+    """'GoPro-style' synthetic lens (ours; no profile DB is vendored): opencv_fisheye."""
+    return {
+        "model": "opencv_fisheye",
+        "f": (0.47 * width, 0.47 * width),
+        "c": (width / 2.0, height / 2.0),
+        "k": [0.045, 0.02, -0.02, 0.006] + [0.0] * 8,
+        "r_limit": 0.0,
+    }
+
+
+def quat_mul(a, b):
+    aw, ax, ay, az = a
+    bw, bx, by, bz = b
+    return np.array([
+        aw * bw - ax * bx - ay * by - az * bz,
+        aw * bx + ax * bw + ay * bz - az * by,
+        aw * by - ax * bz + ay * bw + az * bx,
+        aw * bz + ax * by - ay * bx + az * bw,
+    ])
+
+
+def quat_from_euler_deg(yaw, pitch, roll):
+    """Rotation about y (yaw), x (pitch), z (roll), composed z*x*y, in degrees."""
+    def axis(ax, deg):
+        h = math.radians(deg) / 2.0
+        q = np.zeros(4)
+        q[0] = math.cos(h)
+        q[1 + ax] = math.sin(h)
+        return q
+    return quat_mul(axis(2, roll), quat_mul(axis(0, pitch), axis(1, yaw)))
+
+
+def quat_to_matrix(q):
+    w, x, y, z = q / np.linalg.norm(q)
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+def camera_quat_at(t_ms, seed):
+    """Smooth seeded orientation track: three sinusoids per axis, <= 8 deg total, 0.5-3 Hz."""
+    h = _splitmix64(np.arange(18, dtype=np.uint64) + (np.uint64(seed) << np.uint64(8)))
+    u = (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    ang = [0.0, 0.0, 0.0]
+    for axis in range(3):
+        for j in range(3):
+            freq = 0.5 + 2.5 * u[axis * 6 + j * 2]
+            phase = 2 * math.pi * u[axis * 6 + j * 2 + 1]
+            amp = (8.0 / 3.0) / (1.0 + j)
+            ang[axis] += amp * math.sin(2 * math.pi * freq * t_ms / 1000.0 + phase)
+    return quat_from_euler_deg(ang[0], ang[1], ang[2] * 0.5)
+
+
+def new_k(lens, fov, out_w, out_h):
+    """``get_new_k`` (frame_transform.rs:37-51) with input_horizontal_stretch = 1."""
+    return np.array([[lens["f"][0] / fov, 0.0, out_w / 2.0], [0.0, lens["f"][1] / fov, out_h / 2.0], [0.0, 0.0, 1.0]])
+
+
+def row_matrices(lens, fov, size, out_size, timestamp_ms, frame_readout_time_ms, seed, horizontal_rs=False,
+                 constant_quat=None, ibis=None):
+    """Per-row ``[f32;14]`` table: ``inv(new_k * R_row)`` + (sx, sy, ra, ox, oy).
+
+    Mirrors frame_transform.rs:247-308: rows = H (or W for horizontal RS) when the readout
+    time is non-zero, else 1; R_row = R(smoothed(ts) * org(ts)^-1 * org(ts_row)) with the
+    non-inverted-framebuffer sign flips of :265-267.
+    """
+    width, height = size
+    rows = (width if horizontal_rs else height) if abs(frame_readout_time_ms) > 0.0 else 1
+    nk = new_k(lens, fov, out_size[0], out_size[1])
+    out = np.zeros((rows, 14), dtype=np.float32)
+    start_ts = timestamp_ms - frame_readout_time_ms / 2.0
+    row_t = frame_readout_time_ms / (width if horizontal_rs else height)
+    if constant_quat is not None:
+        smoothed = np.asarray(constant_quat, dtype=np.float64)
+        org_c = np.array([1.0, 0.0, 0.0, 0.0])
+    else:
+        org_c = camera_quat_at(timestamp_ms, seed)
+        # "smoothed" orientation: a low-amplitude version of the same track
+        smoothed = camera_quat_at(timestamp_ms, seed + 7777)
+        smoothed = smoothed / np.linalg.norm(smoothed)
+        smoothed = np.array([smoothed[0], *(smoothed[1:] * 0.25)])
+        smoothed /= np.linalg.norm(smoothed)
+    inv_c = np.array([org_c[0], -org_c[1], -org_c[2], -org_c[3]])
+    for y in range(rows):
+        if constant_quat is not None:
+            q = smoothed
+        else:
+            q = quat_mul(smoothed, quat_mul(inv_c, camera_quat_at(start_ts + row_t * y, seed)))
+        r = quat_to_matrix(q)
+        r[0, 1] *= -1.0; r[0, 2] *= -1.0
+        r[1, 0] *= -1.0; r[2, 0] *= -1.0
+        i_r = np.linalg.inv(nk @ r)
+        out[y, :9] = i_r.reshape(9).astype(np.float32)
+        if ibis is not None:
+            out[y, 9:14] = np.asarray(ibis(y), dtype=np.float32)
+    return out
+
+
+# --------------------------------------------------------------------- KernelParams
+def base_kernel_params(lens, fov, matrix_count, **kw):
+    """What ``FrameTransform::at_timestamp`` fills (frame_transform.rs:322-340)."""
+    p = abi.KernelParams()
+    p.matrix_count = matrix_count
+    p.f[0], p.f[1] = lens["f"]
+    p.c[0], p.c[1] = lens["c"]
+    for i, v in enumerate(lens["k"][:12]):
+        p.k[i] = v
+    p.fov = fov
+    p.r_limit = lens.get("r_limit", 0.0)
+    p.lens_correction_amount = kw.get("lens_correction_amount", 1.0)
+    p.input_vertical_stretch = kw.get("input_vertical_stretch", 1.0)
+    p.input_horizontal_stretch = kw.get("input_horizontal_stretch", 1.0)
+    p.background_mode = kw.get("background_mode", 0)
+    p.background_margin = kw.get("background_margin", 0.0)
+    p.background_margin_feather = kw.get("background_margin_feather", 0.0)
+    t2 = kw.get("translation2d", (0.0, 0.0))
+    p.translation2d[0], p.translation2d[1] = t2
+    for i, v in enumerate(kw.get("digital_lens_params", [])):
+        p.digital_lens_params[i] = v
+    p.light_refraction_coefficient = kw.get("light_refraction_coefficient", 1.0)
+    return p
+
+
+EWA_BC = {10: (0.2620145, 0.3689927), 11: (0.3782157, 0.3108921), 12: (0.3333333, 0.3333333), 13: (0.0, 0.5)}
+
+
+def plane_kernel_params(base, pixel_type, size, out_size, in_desc, out_desc, interpolation=2, flags=0,
+                        background=(0.0, 0.0, 0.0, 0.0), max_val=None, plane_index=0):
+    """Complete a per-plane ``KernelParams`` as ``get_frame_transform_at::<T>``
+    (stabilization/mod.rs:253-326) followed by the render loop's overrides
+    (rendering/mod.rs:532-541).  ``in_desc``/``out_desc`` = (w, h, stride, rect|None, rotation|None)."""
+    pid, dt, count, dmax = abi.PIXEL_TYPES[pixel_type]
+    p = base.copy()
+    p.pixel_value_limit = dmax if dmax is not None else float(np.finfo(np.float32).max)
+    p.max_pixel_value = dmax if dmax is not None else 1.0
+    p.interpolation = interpolation
+    p.width, p.height = size
+    p.output_width, p.output_height = out_size
+    for i in range(4):
+        p.background[i] = background[i]
+    p.bytes_per_pixel = np.dtype(dt).itemsize * count
+    p.pix_element_count = count
+    p.canvas_scale = 1.0
+    f = flags
+    if in_desc[3] is not None or (in_desc[0], in_desc[1]) != tuple(size):
+        f |= abi.FLAG_HAS_SOURCE_RECT
+    if out_desc[3] is not None or (out_desc[0], out_desc[1]) != tuple(out_size):
+        f |= abi.FLAG_HAS_OUTPUT_RECT
+    p.flags = f
+    p.stride = in_desc[2]
+    p.output_stride = out_desc[2]
+    if interpolation > 8:
+        b, c = EWA_BC[interpolation]
+        f32 = np.float32
+        b, c = f32(b), f32(c)
+        p.ewa_coeffs_p[0] = (f32(6.0) - f32(2.0) * b) / f32(6.0)
+        p.ewa_coeffs_p[1] = 0.0
+        p.ewa_coeffs_p[2] = (f32(-18.0) + f32(12.0) * b + f32(6.0) * c) / f32(6.0)
+        p.ewa_coeffs_p[3] = (f32(12.0) - f32(9.0) * b - f32(6.0) * c) / f32(6.0)
+        p.ewa_coeffs_q[0] = (f32(8.0) * b + f32(24.0) * c) / f32(6.0)
+        p.ewa_coeffs_q[1] = (f32(-12.0) * b - f32(48.0) * c) / f32(6.0)
+        p.ewa_coeffs_q[2] = (f32(6.0) * b + f32(30.0) * c) / f32(6.0)
+        p.ewa_coeffs_q[3] = (f32(-1.0) * b - f32(6.0) * c) / f32(6.0)
+    ow, oh = float(out_size[0]), float(out_size[1])
+    p.safe_area_rect[0] = 0.0
+    p.safe_area_rect[1] = 0.0
+    p.safe_area_rect[2] = ow
+    p.safe_area_rect[3] = oh
+    if in_desc[4] is not None:
+        p.input_rotation = in_desc[4]
+    if out_desc[4] is not None:
+        p.output_rotation = out_desc[4]
+    sr = in_desc[3] if in_desc[3] is not None else (0, 0, in_desc[0], in_desc[1])
+    orr = out_desc[3] if out_desc[3] is not None else (0, 0, out_desc[0], out_desc[1])
+    for i in range(4):
+        p.source_rect[i] = sr[i]
+        p.output_rect[i] = orr[i]
+    if max_val is not None:
+        p.pixel_value_limit = max_val
+        p.max_pixel_value = max_val
+    p.plane_index = plane_index
+    return p
+
+
+# Appendix C of SURVEY.md (rendering/mod.rs:565-649): format -> planes
+# (pixel type, (w divisor, h divisor), yuv index for the background colour, max_val)
+FRAME_FORMATS = {
+    "NV12":        [("Luma8", (1, 1), [0], 255.0), ("UV8", (2, 2), [1, 2], 255.0)],
+    "P010":        [("Luma16", (1, 1), [0], 65535.0), ("UV16", (2, 2), [1, 2], 65535.0)],
+    "P210":        [("Luma16", (1, 1), [0], 65535.0), ("UV16", (2, 1), [1, 2], 65535.0)],
+    "YUV420P":     [("Luma8", (1, 1), [0], 255.0), ("Luma8", (2, 2), [1], 255.0), ("Luma8", (2, 2), [2], 255.0)],
+    "YUV420P10LE": [("Luma16", (1, 1), [0], 1023.0), ("Luma16", (2, 2), [1], 1023.0), ("Luma16", (2, 2), [2], 1023.0)],
+    "YUV422P10LE": [("Luma16", (1, 1), [0], 1023.0), ("Luma16", (2, 1), [1], 1023.0), ("Luma16", (2, 1), [2], 1023.0)],
+    "YUV422P16LE": [("Luma16", (1, 1), [0], 65535.0), ("Luma16", (2, 1), [1], 65535.0), ("Luma16", (2, 1), [2], 65535.0)],
+    "YUV444P16LE": [("Luma16", (1, 1), [0], 65535.0), ("Luma16", (1, 1), [1], 65535.0), ("Luma16", (1, 1), [2], 65535.0)],
+    "GBRAPF32LE":  [("R32f", (1, 1), [2], 255.0), ("R32f", (1, 1), [0], 255.0), ("R32f", (1, 1), [1], 255.0), ("R32f", (1, 1), [3], 255.0)],
+    "RGBA":        [("RGBA8", (1, 1), [], 255.0)],
+    "RGBA64":      [("RGBA16", (1, 1), [], 65535.0)],
+    "RGBAF32":     [("RGBAf", (1, 1), [], None)],
+}
+
+
+class SyntheticFrame:
+    """One frame of a synthetic clip: per-plane host buffers + per-plane KernelParams + matrices."""
+
+    def __init__(self, fmt, width, height, seed=0x9F10, fov=1.0, readout_ms=16.0, timestamp_ms=1000.0,
+                 interpolation=2, constant_quat=None, out_size=None, lens=None, horizontal_rs=False,
+                 stride_align=256, background_rgba=(0.0, 0.0, 0.0, 0.0), base_overrides=None, flags=0):
+        self.fmt, self.width, self.height = fmt, width, height
+        self.out_size = out_size or (width, height)
+        self.lens = lens or gopro_style_lens(width, height)
+        self.model = abi.MODELS[self.lens["model"]]
+        self.digital = abi.MODELS[self.lens.get("digital", "none")]
+        self.matrices = row_matrices(self.lens, fov, (width, height), self.out_size, timestamp_ms, readout_ms,
+                                     seed, horizontal_rs=horizontal_rs, constant_quat=constant_quat)
+        if horizontal_rs:
+            flags |= abi.FLAG_HORIZONTAL_RS
+        if self.digital:
+            flags |= abi.FLAG_HAS_DIGITAL_LENS
+        base = base_kernel_params(self.lens, fov, self.matrices.shape[0], **(base_overrides or {}))
+        self.planes = []
+        for idx, (ptype, (dw, dh), _yuvi, max_val) in enumerate(FRAME_FORMATS[fmt]):
+            pw, ph = width // dw, height // dh
+            ow, oh = self.out_size[0] // dw, self.out_size[1] // dh
+            src, stride = make_plane_buffer(pw, ph, ptype, seed + idx * 101, max_val, stride_align)
+            _, dt, count, _ = abi.PIXEL_TYPES[ptype]
+            ostride = align(ow * np.dtype(dt).itemsize * count, stride_align)
+            dst = np.full(ostride * oh, 0x5A, dtype=np.uint8)
+            kp = plane_kernel_params(base, ptype, (width, height), self.out_size,
+                                     (pw, ph, stride, None, None), (ow, oh, ostride, None, None),
+                                     interpolation=interpolation, flags=flags, background=background_rgba,
+                                     max_val=max_val, plane_index=idx)
+            self.planes.append({"pixel_type": ptype, "size": (pw, ph, stride), "out_size": (ow, oh, ostride),
+                                "src": src, "dst": dst, "params": kp})
+
+    def luma_pixels(self):
+        return self.out_size[0] * self.out_size[1]
+
+    def algorithmic_bytes(self):
+        """Sum over planes of w*h*bpp read once + written once."""
+        total = 0
+        for pl in self.planes:
+            bpp = pl["params"].bytes_per_pixel
+            total += pl["size"][0] * pl["size"][1] * bpp + pl["out_size"][0] * pl["out_size"][1] * bpp
+        return total

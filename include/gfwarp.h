@@ -1,0 +1,278 @@
+/* gfwarp.h — C ABI of libgfwarp, the MI355X (gfx950) warp backend.
+ *
+ * This is the drop-in boundary for gyroflow-core's per-pixel
+ * undistort -> rotate (rolling shutter) -> redistort -> sample path.  Every
+ * entry point states the reference interface it stands in for
+ * (paths relative to the gyroflow tree, v1.6.3):
+ *
+ *   backend object          src/core/gpu/opencl.rs:178   OclWrapper::new
+ *                           src/core/gpu/wgpu.rs:147     WgpuWrapper::new
+ *   per-plane call          src/core/gpu/opencl.rs:330   OclWrapper::undistort_image
+ *                           src/core/gpu/wgpu.rs:454     WgpuWrapper::undistort_image
+ *   CPU twin (authoritative arithmetic)
+ *                           src/core/stabilization/cpu_undistort.rs:233
+ *   uniform block           src/core/stabilization/mod.rs:101-150  KernelParams
+ *   buffers                 src/core/gpu/mod.rs:17-71    Buffers / BufferDescription / BufferSource
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  All functions are
+ * thread-safe with respect to *different* contexts; one context is
+ * single-thread-affine exactly like the reference's thread-local backend
+ * caches (stabilization/mod.rs:59-66).
+ */
+#ifndef GFWARP_H
+#define GFWARP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFW_ABI_VERSION 1
+
+/* ---- KernelParams: byte-exact mirror of stabilization/mod.rs:101-150 ------
+ * #[repr(C, packed(4))], 92 four-byte words = 368 bytes. */
+typedef struct gfw_kernel_params {
+    int32_t width;               /*   0 */
+    int32_t height;              /*   4 */
+    int32_t stride;              /*   8  bytes */
+    int32_t output_width;        /*  12 */
+    int32_t output_height;       /*  16 */
+    int32_t output_stride;       /*  20  bytes */
+    int32_t matrix_count;        /*  24  1 = no rolling-shutter correction */
+    int32_t interpolation;       /*  28  2,4,8 = LUT taps; 10..13 = EWA */
+    int32_t background_mode;     /*  32  0 solid,1 repeat,2 mirror,3 margin+feather */
+    int32_t flags;               /*  36  GFW_FLAG_* */
+    int32_t bytes_per_pixel;     /*  40 */
+    int32_t pix_element_count;   /*  44 */
+    float   background[4];       /*  48 */
+    float   f[2];                /*  64 */
+    float   c[2];                /*  72 */
+    float   k[12];               /*  80 */
+    float   fov;                 /* 128 */
+    float   r_limit;             /* 132 */
+    float   lens_correction_amount;    /* 136 */
+    float   input_vertical_stretch;    /* 140 */
+    float   input_horizontal_stretch;  /* 144 */
+    float   background_margin;         /* 148 */
+    float   background_margin_feather; /* 152 */
+    float   canvas_scale;              /* 156 */
+    float   input_rotation;            /* 160  degrees */
+    float   output_rotation;           /* 164  degrees */
+    float   translation2d[2];          /* 168 */
+    float   translation3d[4];          /* 176 */
+    int32_t source_rect[4];            /* 192  x,y,w,h */
+    int32_t output_rect[4];            /* 208  x,y,w,h */
+    float   digital_lens_params[16];   /* 224 */
+    float   safe_area_rect[4];         /* 288 */
+    float   max_pixel_value;           /* 304 */
+    int32_t distortion_model;          /* 308  GFW_MODEL_* (not trusted: see gfw_create) */
+    int32_t digital_lens;              /* 312 */
+    float   pixel_value_limit;         /* 316 */
+    float   light_refraction_coefficient; /* 320 */
+    int32_t plane_index;               /* 324 */
+    float   reserved1;                 /* 328 */
+    float   reserved2;                 /* 332 */
+    float   ewa_coeffs_p[4];           /* 336 */
+    float   ewa_coeffs_q[4];           /* 352 */
+} gfw_kernel_params;                   /* 368 */
+
+/* KernelParamsFlags, stabilization/mod.rs:83-99 */
+enum {
+    GFW_FLAG_FIX_COLOR_RANGE      = 1 << 0,
+    GFW_FLAG_HAS_DIGITAL_LENS     = 1 << 1,
+    GFW_FLAG_FILL_WITH_BACKGROUND = 1 << 2,
+    GFW_FLAG_DRAWING_ENABLED      = 1 << 3,
+    GFW_FLAG_HORIZONTAL_RS        = 1 << 4,
+    GFW_FLAG_HAS_SOURCE_RECT      = 1 << 5,
+    GFW_FLAG_HAS_OUTPUT_RECT      = 1 << 6,
+    GFW_FLAG_FRAMEBUFFER_INVERTED = 1 << 7,
+    GFW_FLAG_HAS_IBIS_DATA        = 1 << 8,
+    GFW_FLAG_HAS_MESH_DATA        = 1 << 9,
+    GFW_FLAG_HAS_FPD_DATA         = 1 << 10,
+    GFW_FLAG_ANY_UNDERWATER       = 1 << 11
+};
+
+/* Interpolation, stabilization/mod.rs:25-34 */
+enum {
+    GFW_INTERP_BILINEAR       = 2,
+    GFW_INTERP_BICUBIC        = 4,
+    GFW_INTERP_LANCZOS4       = 8,
+    GFW_INTERP_ROBIDOUX_SHARP = 10,
+    GFW_INTERP_ROBIDOUX       = 11,
+    GFW_INTERP_MITCHELL       = 12,
+    GFW_INTERP_CATMULL_ROM    = 13
+};
+
+/* Distortion model ids: src/core/gpu/stabilize_spirv/src/distortion_models/mod.rs:62-81
+ * (declaration order of impl_models!).  GoPro6Superview has no id there
+ * (it exists only in stabilization/distortion_models/mod.rs:107); 14 is ours. */
+enum {
+    GFW_MODEL_NONE               = 0,
+    GFW_MODEL_OPENCV_FISHEYE     = 1,
+    GFW_MODEL_OPENCV_STANDARD    = 2,
+    GFW_MODEL_POLY3              = 3,
+    GFW_MODEL_POLY5              = 4,
+    GFW_MODEL_PTLENS             = 5,
+    GFW_MODEL_INSTA360           = 6,
+    GFW_MODEL_SONY               = 7,
+    GFW_MODEL_GENERIC_POLYNOMIAL = 8,
+    GFW_MODEL_GOPRO              = 9,
+    GFW_MODEL_GOPRO_SUPERVIEW    = 10,
+    GFW_MODEL_GOPRO_HYPERVIEW    = 11,
+    GFW_MODEL_GOPRO_WARP         = 12,
+    GFW_MODEL_DIGITAL_STRETCH    = 13,
+    GFW_MODEL_GOPRO6_SUPERVIEW   = 14
+};
+
+/* PixelType implementors, stabilization/pixel_formats.rs:48-60 (declaration order) */
+enum {
+    GFW_PIX_LUMA8   = 0,
+    GFW_PIX_LUMA16  = 1,
+    GFW_PIX_RGB8    = 2,
+    GFW_PIX_RGBA8   = 3,
+    GFW_PIX_BGRA8   = 4,
+    GFW_PIX_RGB16   = 5,
+    GFW_PIX_RGBA16  = 6,
+    GFW_PIX_AYUV16  = 7,
+    GFW_PIX_RGBAF   = 8,
+    GFW_PIX_RGBAF16 = 9,
+    GFW_PIX_R32F    = 10,
+    GFW_PIX_UV8     = 11,
+    GFW_PIX_UV16    = 12,
+    GFW_PIX_COUNT   = 13
+};
+
+/* BufferSource, gpu/mod.rs:29-71.  HOST = BufferSource::Cpu{buffer};
+ * HIP_DEVICE = the analogue of CUDABuffer{buffer} (a device pointer that
+ * already lives in this GPU's HBM). */
+enum {
+    GFW_BUF_NONE       = 0,
+    GFW_BUF_HOST       = 1,
+    GFW_BUF_HIP_DEVICE = 2
+};
+
+/* BufferDescription, gpu/mod.rs:17-24 */
+typedef struct gfw_buffer_desc {
+    int32_t width, height, stride;   /* size: (w, h, stride in bytes) */
+    int32_t has_rect;                /* Option<(x,y,w,h)> */
+    int32_t rect[4];
+    int32_t has_rotation;            /* Option<f32>, degrees */
+    float   rotation;
+    int32_t kind;                    /* GFW_BUF_* */
+    int32_t texture_copy;            /* kept for layout parity; unused */
+    void   *data;
+    size_t  len;                     /* bytes available at data */
+} gfw_buffer_desc;
+
+/* Buffers, gpu/mod.rs:25-28 */
+typedef struct gfw_buffers {
+    gfw_buffer_desc input;
+    gfw_buffer_desc output;
+} gfw_buffers;
+
+/* Error codes: GyroflowCoreError (src/core/lib.rs:2099-2141) + backend-level
+ * conditions that the reference logs-and-skips (opencl.rs:336-358). */
+enum {
+    GFW_OK                        =  0,
+    GFW_ERR_SIZE_TOO_SMALL        = -1,   /* SizeTooSmall          mod.rs:613 */
+    GFW_ERR_SIZE_MISMATCH         = -2,   /* SizeMismatch          mod.rs:636-637 */
+    GFW_ERR_INVALID_STRIDE        = -3,   /* InvalidStride         mod.rs:639-640 */
+    GFW_ERR_NO_STABILIZATION_DATA = -4,   /* NoStabilizationData   mod.rs:721 */
+    GFW_ERR_INPUT_BUFFER_EMPTY    = -5,   /* InputBufferEmpty      lib.rs:890 */
+    GFW_ERR_OUTPUT_BUFFER_EMPTY   = -6,   /* OutputBufferEmpty     lib.rs:891 */
+    GFW_ERR_UNSUPPORTED_BUFFER    = -7,   /* is_buffer_supported == false */
+    GFW_ERR_BUFFER_SIZE_MISMATCH  = -8,   /* "Buffer size mismatch" opencl.rs:336-358 */
+    GFW_ERR_INVALID_ARGUMENT      = -9,
+    GFW_ERR_NO_DEVICE             = -10,  /* no gfx950 device / HIP runtime error */
+    GFW_ERR_HIP                   = -11,
+    GFW_ERR_UNKNOWN               = -100  /* Unknown */
+};
+
+typedef struct gfw_ctx gfw_ctx;
+
+/* ---- device management --------------------------------------------------
+ * OclWrapper::list_devices opencl.rs:60, ::set_device :93,
+ * ::initialize_context :118, ::get_info (wgpu.rs:123). */
+int  gfw_abi_version(void);
+/* Writes '\n'-separated device names ("[HIP] <name>") into buf; returns the
+ * device count, or a negative GFW_ERR_* */
+int  gfw_list_devices(char *buf, size_t cap);
+int  gfw_set_device(int index);
+int  gfw_get_info(char *buf, size_t cap);
+/* is_buffer_supported(): opencl.rs:451 / wgpu.rs:562 */
+int  gfw_is_buffer_supported(const gfw_buffers *buffers);
+
+/* ---- backend object -----------------------------------------------------
+ * OclWrapper::new(params, ocl_names, distortion_model, digital_lens,
+ *                 buffers, drawing_len)              opencl.rs:178
+ * The model ids are explicit arguments because FrameTransform leaves
+ * KernelParams.distortion_model/digital_lens at their defaults
+ * (frame_transform.rs:322-340).  digital_lens = GFW_MODEL_NONE for "None".
+ * Owns: the stream, device staging for HOST buffers (sized from `buffers`),
+ * matrices (14 * (flags&16 ? width : height) floats), params, mesh
+ * (MAX_BUFFER_SIZE = 839 floats, gyro_source/splines.rs:88-89).
+ * Returns NULL on failure; see gfw_last_error(). */
+gfw_ctx *gfw_create(const gfw_kernel_params *params, int pixel_type,
+                    int distortion_model, int digital_lens,
+                    const gfw_buffers *buffers, size_t drawing_len);
+void     gfw_destroy(gfw_ctx *ctx);
+
+/* OclWrapper::undistort_image(&self, buffers, itm: &FrameTransform, drawing)
+ *                                                             opencl.rs:330
+ * `matrices` = FrameTransform.matrices flattened ([f32;14] per row,
+ * frame_transform.rs:13); host pointer unless GFW_MATRICES_ON_DEVICE is set
+ * with gfw_set_option.  Synchronous for HOST buffers (output complete on
+ * return, like opencl.rs:413); for HIP_DEVICE buffers the work is enqueued on
+ * the context stream and the call returns after enqueue unless the context
+ * is in synchronous mode (default: synchronous).
+ * Returns GFW_OK or a negative code; never aborts. */
+int gfw_undistort_image(gfw_ctx *ctx, const gfw_buffers *buffers,
+                        const gfw_kernel_params *params,
+                        const float *matrices, int matrix_count,
+                        const uint8_t *drawing, size_t drawing_len,
+                        const float *mesh, size_t mesh_len);
+
+/* Additive: all planes of one frame in one launch, sharing the per-row
+ * matrices and the coordinate evaluation between planes (the reference runs
+ * one process_pixels per plane: src/rendering/mod.rs:655-658).  planes[i] /
+ * params[i] / pixel_types[i] describe plane i exactly as the i-th
+ * gfw_undistort_image call would.  Results are bit-identical to calling
+ * gfw_undistort_image once per plane. */
+int gfw_undistort_frame(gfw_ctx *ctx, int nplanes,
+                        const gfw_buffers *planes,
+                        const gfw_kernel_params *params,
+                        const int *pixel_types,
+                        const float *matrices, int matrix_count,
+                        const float *mesh, size_t mesh_len);
+
+/* ---- options / stream ---------------------------------------------------*/
+enum {
+    GFW_OPT_SYNCHRONOUS        = 1,  /* 1 (default): return after stream sync */
+    GFW_OPT_MATRICES_ON_DEVICE = 2,  /* 1: `matrices` is a device pointer */
+    GFW_OPT_KERNEL_VARIANT     = 3   /* debug/benchmark: force a kernel variant */
+};
+int   gfw_set_option(gfw_ctx *ctx, int option, int64_t value);
+/* hipStream_t the context enqueues on (as void*); caller may substitute its
+ * own stream (e.g. the decoder's) — mirrors passing the cl_command_queue in
+ * BufferSource::OpenCL{queue} (gpu/mod.rs:37-40). */
+void *gfw_get_stream(gfw_ctx *ctx);
+int   gfw_set_stream(gfw_ctx *ctx, void *hip_stream);
+int   gfw_synchronize(gfw_ctx *ctx);
+/* Name of the kernel path the last call took ("plane_generic", "yuv_fused", ...):
+ * the analogue of ProcessedInfo.backend (stabilization/mod.rs:194-200). */
+const char *gfw_last_backend(gfw_ctx *ctx);
+
+/* Thread-local, human-readable description of the last failure. */
+const char *gfw_last_error(void);
+
+/* Static tables the reference exposes through PixelType (pixel_formats.rs):
+ * bytes per pixel, element count, default_max_value (0 => None). */
+int   gfw_pixel_type_info(int pixel_type, int *bytes_per_pixel,
+                          int *element_count, float *default_max_value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFWARP_H */

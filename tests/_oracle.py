@@ -1,0 +1,85 @@
+"""ctypes binding of the parity oracle (oracle/libgfw_oracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from gyroflow_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libgfw_oracle.so")
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(ORACLE_DIR, "gfw_oracle.c")
+        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+        L = C.CDLL(ORACLE_SO)
+        vp = C.c_void_p
+        L.gfw_oracle_undistort_image.argtypes = [C.POINTER(abi.Buffers), C.POINTER(abi.KernelParams), C.c_int, C.c_int,
+                                                 C.c_int, vp, vp, C.c_size_t, C.c_int]
+        L.gfw_oracle_undistort_image.restype = C.c_int
+        L.gfw_oracle_undistort_coord.argtypes = [C.POINTER(abi.KernelParams), C.c_int, C.c_int, vp, vp, C.c_size_t,
+                                                 C.c_float, C.c_float, vp]
+        L.gfw_oracle_distort_point.argtypes = [C.c_int, C.POINTER(abi.KernelParams), C.c_float, C.c_float, C.c_float, vp]
+        L.gfw_oracle_undistort_point.argtypes = [C.c_int, C.POINTER(abi.KernelParams), C.c_float, C.c_float, vp]
+        L.gfw_oracle_undistort_point.restype = C.c_int
+        L.gfw_oracle_libm.argtypes = [C.c_int, vp, vp, C.c_size_t]
+        L.gfw_oracle_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def host_buffers(src, in_size, dst, out_size, in_rect=None, out_rect=None, in_rot=None, out_rot=None):
+    """Build a Buffers struct over two numpy uint8 arrays (BufferSource::Cpu)."""
+    b = abi.Buffers()
+    for d, arr, size, rect, rot in ((b.input, src, in_size, in_rect, in_rot), (b.output, dst, out_size, out_rect, out_rot)):
+        d.width, d.height, d.stride = size
+        d.has_rect = 1 if rect is not None else 0
+        if rect is not None:
+            for i in range(4):
+                d.rect[i] = rect[i]
+        d.has_rotation = 1 if rot is not None else 0
+        d.rotation = rot or 0.0
+        d.kind = abi.BUF_HOST
+        d.data = arr.ctypes.data
+        d.len = arr.nbytes
+    return b
+
+
+def undistort_image(src, in_size, dst, out_size, params, pixel_type, model, digital, matrices, mesh=None, nthreads=0):
+    """Run the oracle's undistort_image_cpu restatement in place on ``dst``; returns its status."""
+    b = host_buffers(src, in_size, dst, out_size)
+    m = np.ascontiguousarray(matrices, dtype=np.float32)
+    mesh_ptr, mesh_len = None, 0
+    if mesh is not None and len(mesh):
+        mesh = np.ascontiguousarray(mesh, dtype=np.float32)
+        mesh_ptr, mesh_len = mesh.ctypes.data, mesh.size
+    pid = abi.PIXEL_TYPES[pixel_type][0]
+    return lib().gfw_oracle_undistort_image(C.byref(b), C.byref(params), pid, model, digital, m.ctypes.data,
+                                            mesh_ptr, mesh_len, nthreads)
+
+
+def undistort_coord(params, model, digital, matrices, x, y, mesh=None):
+    out = np.zeros(3, dtype=np.float32)
+    m = np.ascontiguousarray(matrices, dtype=np.float32)
+    lib().gfw_oracle_undistort_coord(C.byref(params), model, digital, m.ctypes.data, None, 0, x, y, out.ctypes.data)
+    return bool(out[0]), float(out[1]), float(out[2])
+
+
+def run_frame(frame, nthreads=0):
+    """Oracle over every plane of a SyntheticFrame; returns list of output arrays (copies)."""
+    outs = []
+    for pl in frame.planes:
+        dst = pl["dst"].copy()
+        st = undistort_image(pl["src"], pl["size"], dst, pl["out_size"], pl["params"], pl["pixel_type"],
+                             frame.model, frame.digital, frame.matrices, nthreads=nthreads)
+        assert st == 1, "oracle returned %d" % st
+        outs.append(dst)
+    return outs
