@@ -98,7 +98,7 @@ ERRORS = {
     -9: "InvalidArgument", -10: "NoDevice", -11: "HipError", -100: "Unknown",
 }
 
-OPT_SYNCHRONOUS, OPT_MATRICES_ON_DEVICE, OPT_KERNEL_VARIANT = 1, 2, 3
+OPT_SYNCHRONOUS, OPT_MATRICES_ON_DEVICE, OPT_KERNEL_VARIANT, OPT_PROFILE = 1, 2, 3, 4
 
 _lib = None
 
@@ -123,6 +123,7 @@ def bind(lib):
     lib.gfw_set_stream.argtypes = [vp, vp]; lib.gfw_set_stream.restype = i32
     lib.gfw_synchronize.argtypes = [vp]; lib.gfw_synchronize.restype = i32
     lib.gfw_last_backend.argtypes = [vp]; lib.gfw_last_backend.restype = C.c_char_p
+    lib.gfw_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]; lib.gfw_get_profile.restype = i32
     lib.gfw_last_error.restype = C.c_char_p
     lib.gfw_pixel_type_info.argtypes = [i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_float)]
     lib.gfw_pixel_type_info.restype = i32
@@ -131,7 +132,7 @@ def bind(lib):
 
 EXPORTS = ["gfw_abi_version", "gfw_list_devices", "gfw_set_device", "gfw_get_info", "gfw_is_buffer_supported",
            "gfw_create", "gfw_destroy", "gfw_undistort_image", "gfw_undistort_frame", "gfw_set_option",
-           "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_last_backend", "gfw_last_error",
+           "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_last_backend", "gfw_get_profile", "gfw_last_error",
            "gfw_pixel_type_info"]
 
 

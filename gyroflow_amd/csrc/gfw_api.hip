@@ -1,0 +1,404 @@
+// gfw_api.hip — the extern "C" boundary of libgfwarp (include/gfwarp.h).
+//
+// Mirrors the reference's backend-object contract (OclWrapper: src/core/gpu/opencl.rs:178-448,
+// WgpuWrapper: src/core/gpu/wgpu.rs:147-559): `create` owns all device allocations, `undistort_image`
+// validates like the reference does (mismatches are reported, never abort), uploads params + matrices,
+// launches, and (for HOST buffers) copies back before returning.  No CPU fallback lives here: if the HIP
+// runtime or a gfx950 device is missing every entry point fails with GFW_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/gfwarp.h"
+#include "gfw_launch.h"
+
+static_assert(sizeof(gfw_kernel_params) == 368, "KernelParams must be 368 bytes (stabilization/mod.rs:101-150)");
+static_assert(offsetof(gfw_kernel_params, background) == 48, "layout");
+static_assert(offsetof(gfw_kernel_params, k) == 80, "layout");
+static_assert(offsetof(gfw_kernel_params, translation2d) == 168, "layout");
+static_assert(offsetof(gfw_kernel_params, source_rect) == 192, "layout");
+static_assert(offsetof(gfw_kernel_params, digital_lens_params) == 224, "layout");
+static_assert(offsetof(gfw_kernel_params, max_pixel_value) == 304, "layout");
+static_assert(offsetof(gfw_kernel_params, plane_index) == 324, "layout");
+static_assert(offsetof(gfw_kernel_params, ewa_coeffs_p) == 336, "layout");
+
+#define GFW_MESH_MAX 839   /* MAX_BUFFER_SIZE, gyro_source/splines.rs:88-89 */
+
+static thread_local std::string g_last_error;
+static void set_error(const char *fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_last_error = buf;
+}
+#define HIP_TRY(expr, code)                                                                   \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) {                                      \
+        set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return (code); } } while (0)
+
+static const int   PIX_BPP[GFW_PIX_COUNT]   = {1, 2, 3, 4, 4, 6, 8, 8, 16, 8, 4, 2, 4};
+static const int   PIX_N[GFW_PIX_COUNT]     = {1, 1, 3, 4, 4, 3, 4, 4, 4, 4, 1, 2, 2};
+static const float PIX_MAX[GFW_PIX_COUNT]   = {255.f, 65535.f, 255.f, 255.f, 255.f, 65535.f, 65535.f, 65535.f, 0.f, 0.f, 0.f, 255.f, 65535.f};
+
+struct DevBuf {
+    void *ptr = nullptr; size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; cap = 0;
+        hipError_t e = hipMalloc(&ptr, n);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+};
+
+struct gfw_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    bool synchronous = true;
+    bool matrices_on_device = false;
+    int kernel_variant = 0;
+    int pixel_type = 0, model = 0, digital = 0;
+    int max_matrix_rows = 0;
+    size_t src_len = 0, dst_len = 0;              // sizes declared at create (opencl.rs:287-293)
+    std::vector<DevBuf> stage_src, stage_dst;      // per-plane staging for HOST buffers
+    DevBuf d_matrices, d_matrices_raw, d_mesh;
+    float *h_matrices = nullptr; size_t h_matrices_cap = 0;   // pinned repack staging
+    const char *last_backend = "";
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;   // recorded, not yet harvested
+    size_t ev_used = 0;
+    double prof_ms = 0.0; int64_t prof_launches = 0;
+};
+
+static void prof_begin(gfw_ctx *c) {
+    if (!c->profile) return;
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        c->ev_pool.emplace_back(a, b);
+    }
+    (void)hipEventRecord(c->ev_pool[c->ev_used].first, c->stream);
+}
+static void prof_end(gfw_ctx *c) {
+    if (!c->profile) return;
+    (void)hipEventRecord(c->ev_pool[c->ev_used].second, c->stream);
+    c->ev_used++;
+}
+static void prof_harvest(gfw_ctx *c) {
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second) == hipSuccess) { c->prof_ms += ms; c->prof_launches++; }
+    }
+    c->ev_used = 0;
+}
+
+static int g_device_count = -1;
+static int device_count() {
+    if (g_device_count < 0) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+        g_device_count = n;
+    }
+    return g_device_count;
+}
+
+extern "C" {
+
+int gfw_abi_version(void) { return GFW_ABI_VERSION; }
+
+int gfw_list_devices(char *buf, size_t cap) {
+    const int n = device_count();
+    std::string out;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, i) != hipSuccess) continue;
+        out += "[HIP] "; out += pr.name; out += " ("; out += pr.gcnArchName; out += ")\n";
+    }
+    if (buf && cap) { strncpy(buf, out.c_str(), cap - 1); buf[cap - 1] = 0; }
+    if (n == 0) { set_error("no HIP device visible"); return GFW_ERR_NO_DEVICE; }
+    return n;
+}
+
+static thread_local int g_current_device = 0;
+int gfw_set_device(int index) {
+    if (index < 0 || index >= device_count()) { set_error("device index %d out of range (%d devices)", index, device_count()); return GFW_ERR_NO_DEVICE; }
+    HIP_TRY(hipSetDevice(index), GFW_ERR_HIP);
+    g_current_device = index;
+    return GFW_OK;
+}
+
+int gfw_get_info(char *buf, size_t cap) {
+    if (device_count() == 0) { set_error("no HIP device visible"); return GFW_ERR_NO_DEVICE; }
+    hipDeviceProp_t pr;
+    HIP_TRY(hipGetDeviceProperties(&pr, g_current_device), GFW_ERR_HIP);
+    int rt = 0; (void)hipRuntimeGetVersion(&rt);
+    char tmp[512];
+    snprintf(tmp, sizeof(tmp), "%s %s, %d CUs, %.1f GiB, clock %d MHz, HIP runtime %d", pr.name, pr.gcnArchName,
+             pr.multiProcessorCount, (double)pr.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), pr.clockRate / 1000, rt);
+    if (buf && cap) { strncpy(buf, tmp, cap - 1); buf[cap - 1] = 0; }
+    return GFW_OK;
+}
+
+int gfw_is_buffer_supported(const gfw_buffers *b) {
+    if (!b) return 0;
+    const int ki = b->input.kind, ko = b->output.kind;
+    const bool in_ok = ki == GFW_BUF_HOST || ki == GFW_BUF_HIP_DEVICE;
+    const bool out_ok = ko == GFW_BUF_HOST || ko == GFW_BUF_HIP_DEVICE;
+    return (in_ok && out_ok) ? 1 : 0;
+}
+
+int gfw_pixel_type_info(int t, int *bpp, int *count, float *maxv) {
+    if (t < 0 || t >= GFW_PIX_COUNT) return GFW_ERR_INVALID_ARGUMENT;
+    if (bpp) *bpp = PIX_BPP[t];
+    if (count) *count = PIX_N[t];
+    if (maxv) *maxv = PIX_MAX[t];
+    return GFW_OK;
+}
+
+const char *gfw_last_error(void) { return g_last_error.c_str(); }
+
+gfw_ctx *gfw_create(const gfw_kernel_params *params, int pixel_type, int distortion_model, int digital_lens,
+                    const gfw_buffers *buffers, size_t drawing_len) {
+    (void)drawing_len;   // the CPU kernel never draws overlays (cpu_undistort.rs:234-251 is commented out)
+    if (!params || !buffers) { set_error("null params/buffers"); return nullptr; }
+    if (pixel_type < 0 || pixel_type >= GFW_PIX_COUNT) { set_error("unknown pixel type %d", pixel_type); return nullptr; }
+    if (distortion_model <= GFW_MODEL_NONE || distortion_model > GFW_MODEL_GOPRO6_SUPERVIEW) { set_error("unknown distortion model %d", distortion_model); return nullptr; }
+    if (digital_lens < GFW_MODEL_NONE || digital_lens > GFW_MODEL_GOPRO6_SUPERVIEW) { set_error("unknown digital lens %d", digital_lens); return nullptr; }
+    if (params->height < 4 || params->output_height < 4 || params->stride < 1) {      // opencl.rs:179
+        set_error("size too small: height %d, output_height %d, stride %d", params->height, params->output_height, params->stride); return nullptr; }
+    if (!gfw_is_buffer_supported(buffers)) { set_error("unsupported buffer kinds %d/%d", buffers->input.kind, buffers->output.kind); return nullptr; }
+    if (params->bytes_per_pixel != PIX_BPP[pixel_type]) { set_error("bytes_per_pixel %d does not match pixel type %d", params->bytes_per_pixel, pixel_type); return nullptr; }
+    if (device_count() == 0) { set_error("no HIP device visible (libgfwarp has no CPU fallback)"); return nullptr; }
+    if (hipSetDevice(g_current_device) != hipSuccess) { set_error("hipSetDevice(%d) failed", g_current_device); return nullptr; }
+
+    gfw_ctx *c = new gfw_ctx();
+    c->device = g_current_device;
+    c->pixel_type = pixel_type; c->model = distortion_model; c->digital = digital_lens;
+    c->src_len = buffers->input.len; c->dst_len = buffers->output.len;
+    c->max_matrix_rows = ((params->flags & GFW_FLAG_HORIZONTAL_RS) ? params->width : params->height);   // opencl.rs:287
+    if (c->max_matrix_rows < 1) c->max_matrix_rows = 1;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && c->d_matrices.ensure((size_t)c->max_matrix_rows * GFW_MAT_STRIDE * sizeof(float)) == hipSuccess;
+    ok = ok && c->d_mesh.ensure(GFW_MESH_MAX * sizeof(float)) == hipSuccess;
+    if (ok) {
+        c->h_matrices_cap = (size_t)c->max_matrix_rows * GFW_MAT_STRIDE * sizeof(float);
+        ok = hipHostMalloc((void **)&c->h_matrices, c->h_matrices_cap) == hipSuccess;
+    }
+    c->stage_src.resize(1); c->stage_dst.resize(1);
+    if (ok && buffers->input.kind == GFW_BUF_HOST) ok = c->stage_src[0].ensure(c->src_len) == hipSuccess;
+    if (ok && buffers->output.kind == GFW_BUF_HOST) ok = c->stage_dst[0].ensure(c->dst_len) == hipSuccess;
+    if (!ok) { set_error("device allocation failed: %s", hipGetErrorString(hipGetLastError())); gfw_destroy(c); return nullptr; }
+    return c;
+}
+
+void gfw_destroy(gfw_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &b : c->stage_src) b.release();
+    for (auto &b : c->stage_dst) b.release();
+    c->d_matrices.release(); c->d_matrices_raw.release(); c->d_mesh.release();
+    if (c->h_matrices) (void)hipHostFree(c->h_matrices);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int gfw_set_option(gfw_ctx *c, int option, int64_t value) {
+    if (!c) return GFW_ERR_INVALID_ARGUMENT;
+    switch (option) {
+    case GFW_OPT_SYNCHRONOUS: c->synchronous = value != 0; return GFW_OK;
+    case GFW_OPT_MATRICES_ON_DEVICE: c->matrices_on_device = value != 0; return GFW_OK;
+    case GFW_OPT_KERNEL_VARIANT: c->kernel_variant = (int)value; return GFW_OK;
+    case GFW_OPT_PROFILE: c->profile = value != 0; return GFW_OK;
+    default: set_error("unknown option %d", option); return GFW_ERR_INVALID_ARGUMENT;
+    }
+}
+void *gfw_get_stream(gfw_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int gfw_set_stream(gfw_ctx *c, void *s) {
+    if (!c) return GFW_ERR_INVALID_ARGUMENT;
+    if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    c->stream = (hipStream_t)s; c->own_stream = false;
+    return GFW_OK;
+}
+int gfw_synchronize(gfw_ctx *c) {
+    if (!c) return GFW_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
+    return GFW_OK;
+}
+const char *gfw_last_backend(gfw_ctx *c) { return c ? c->last_backend : ""; }
+int gfw_get_profile(gfw_ctx *c, double *kernel_ms, int64_t *launches, int reset) {
+    if (!c) return GFW_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
+    prof_harvest(c);
+    if (kernel_ms) *kernel_ms = c->prof_ms;
+    if (launches) *launches = c->prof_launches;
+    if (reset) { c->prof_ms = 0.0; c->prof_launches = 0; }
+    return GFW_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// per-call validation shared by the plane and frame entry points
+static int validate_plane(const gfw_buffers *b, const gfw_kernel_params *p, int pixel_type) {
+    if (!b || !p) { set_error("null buffers/params"); return GFW_ERR_INVALID_ARGUMENT; }
+    if (!b->input.data || b->input.len == 0)  { set_error("input buffer empty");  return GFW_ERR_INPUT_BUFFER_EMPTY; }   // lib.rs:890
+    if (!b->output.data || b->output.len == 0) { set_error("output buffer empty"); return GFW_ERR_OUTPUT_BUFFER_EMPTY; } // lib.rs:891
+    if (!gfw_is_buffer_supported(b)) { set_error("unsupported buffer kind"); return GFW_ERR_UNSUPPORTED_BUFFER; }
+    if (b->input.height < 4 || b->output.height < 4) { set_error("SizeTooSmall: %d / %d rows", b->input.height, b->output.height); return GFW_ERR_SIZE_TOO_SMALL; }  // mod.rs:613
+    if (b->input.width  > p->stride)        { set_error("InvalidStride(%d, %d)", p->stride, b->input.width);  return GFW_ERR_INVALID_STRIDE; }         // mod.rs:639
+    if (b->output.width > p->output_stride) { set_error("InvalidStride(%d, %d)", p->output_stride, b->output.width); return GFW_ERR_INVALID_STRIDE; }  // mod.rs:640
+    if (p->bytes_per_pixel != PIX_BPP[pixel_type]) { set_error("bytes_per_pixel %d != size_of::<T>() %d", p->bytes_per_pixel, PIX_BPP[pixel_type]); return GFW_ERR_INVALID_ARGUMENT; }  // cpu_undistort.rs:541
+    if (b->output.stride <= 0 || p->stride <= 0) { set_error("non-positive stride"); return GFW_ERR_INVALID_STRIDE; }
+    if (p->matrix_count < 1) { set_error("matrix_count %d", p->matrix_count); return GFW_ERR_NO_STABILIZATION_DATA; }
+    const int it = p->interpolation;
+    if (!(it == 2 || it == 4 || it == 8 || (it >= 10 && it <= 13))) { set_error("unknown interpolation %d", it); return GFW_ERR_INVALID_ARGUMENT; }
+    // The CPU reference indexes `input[...]` for every tap inside source_rect; out-of-range would panic there.
+    const int64_t sx = p->source_rect[0], sy = p->source_rect[1], sw = p->source_rect[2], sh = p->source_rect[3];
+    if (sx < 0 || sy < 0 || sw < 0 || sh < 0) { set_error("negative source_rect"); return GFW_ERR_INVALID_ARGUMENT; }
+    if (sw > 0 && sh > 0) {
+        const int64_t last = (sy + sh - 1) * (int64_t)p->stride + (sx + sw) * (int64_t)p->bytes_per_pixel;
+        if (last > (int64_t)b->input.len) { set_error("source_rect (%lld,%lld,%lld,%lld) exceeds the input buffer (%zu bytes, stride %d)", (long long)sx, (long long)sy, (long long)sw, (long long)sh, b->input.len, p->stride); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
+    }
+    return GFW_OK;
+}
+
+static int upload_matrices(gfw_ctx *c, const float *matrices, int matrix_count, const float **d_out) {
+    if (!matrices) { set_error("null matrices"); return GFW_ERR_NO_STABILIZATION_DATA; }
+    if (matrix_count > c->max_matrix_rows) {
+        // opencl.rs:336 logs "Buffer size mismatch matrices!" and skips the frame
+        set_error("Buffer size mismatch matrices! %d vs %d", c->max_matrix_rows, matrix_count); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
+    float *d = (float *)c->d_matrices.ptr;
+    if (c->matrices_on_device) {
+        HIP_TRY(gfw_launch_repack(matrices, d, matrix_count, c->stream), GFW_ERR_HIP);
+    } else {
+        // host repack into pinned memory; cos/sin of the IBIS roll angle come from the host libm so
+        // they are the very values the reference's CPU path uses (cpu_undistort.rs:159-160)
+        float *h = c->h_matrices;
+        for (int r = 0; r < matrix_count; ++r) {
+            const float *m = matrices + (size_t)r * 14;
+            float *o = h + (size_t)r * GFW_MAT_STRIDE;
+            memcpy(o, m, 14 * sizeof(float));
+            if (m[9] != 0.0f || m[10] != 0.0f || m[11] != 0.0f || m[12] != 0.0f || m[13] != 0.0f) { o[14] = cosf(-m[11]); o[15] = sinf(-m[11]); }
+            else { o[14] = 1.0f; o[15] = 0.0f; }
+        }
+        HIP_TRY(hipMemcpyAsync(d, h, (size_t)matrix_count * GFW_MAT_STRIDE * sizeof(float), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
+    }
+    *d_out = d;
+    return GFW_OK;
+}
+
+static void fill_common(gfw_ctx *c, const gfw_kernel_params *p, const float *d_mat, const float *d_mesh, int mesh_len, GfwCommon &C) {
+    memset(&C, 0, sizeof(C));
+    C.matrices = d_mat; C.mesh = d_mesh; C.mesh_len = mesh_len;
+    C.model = c->model; C.digital = c->digital;
+    C.frame_w = (float)p->width; C.frame_h = (float)p->height;
+    C.rot_cos = 1.0f; C.rot_sin = 0.0f;
+    if (p->input_rotation != 0.0f) {
+        // rotate_point (cpu_undistort.rs:262-265, :486-489) evaluated with host libm, as the reference does
+        const float rotation = p->input_rotation * (3.14159265358979323846f / 180.0f);
+        C.rot_cos = cosf(rotation); C.rot_sin = sinf(rotation);
+        const float s0 = (float)p->width, s1 = (float)p->height;
+        const float fx = C.rot_cos * (s0 - 0.0f) - C.rot_sin * (s1 - 0.0f) + 0.0f;
+        const float fy = C.rot_sin * (s0 - 0.0f) + C.rot_cos * (s1 - 0.0f) + 0.0f;
+        C.frame_w = roundf(fabsf(fx)); C.frame_h = roundf(fabsf(fy));
+    }
+    C.gopro_tt = tanf(1.5533f);   // gopro.rs:45,58: TMAX.tan()
+}
+
+static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params, const int *pixel_types,
+                      const float *matrices, int matrix_count, const float *mesh, size_t mesh_len) {
+    if (!c) { set_error("null context"); return GFW_ERR_INVALID_ARGUMENT; }
+    if (nplanes < 1 || nplanes > 8) { set_error("nplanes %d", nplanes); return GFW_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
+    for (int i = 0; i < nplanes; ++i) {
+        const int rc = validate_plane(&planes[i], &params[i], pixel_types[i]);
+        if (rc != GFW_OK) return rc;
+        if (params[i].matrix_count != matrix_count) { set_error("plane %d: matrix_count %d != %d", i, params[i].matrix_count, matrix_count); return GFW_ERR_INVALID_ARGUMENT; }
+    }
+    if (mesh_len > GFW_MESH_MAX) { set_error("Buffer size mismatch buf_mesh_data! %d vs %zu", GFW_MESH_MAX, mesh_len); return GFW_ERR_BUFFER_SIZE_MISMATCH; }  // opencl.rs:352
+    const float *d_mat = nullptr;
+    int rc = upload_matrices(c, matrices, matrix_count, &d_mat);
+    if (rc != GFW_OK) return rc;
+    const float *d_mesh = nullptr;
+    if (mesh && mesh_len) {
+        HIP_TRY(hipMemcpyAsync(c->d_mesh.ptr, mesh, mesh_len * sizeof(float), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
+        d_mesh = (const float *)c->d_mesh.ptr;
+    }
+    if ((int)c->stage_src.size() < nplanes) { c->stage_src.resize(nplanes); c->stage_dst.resize(nplanes); }
+
+    std::vector<GfwPlane> launches(nplanes);
+    for (int i = 0; i < nplanes; ++i) {
+        const gfw_buffers &b = planes[i];
+        GfwPlane &A = launches[i];
+        memset(&A, 0, sizeof(A));
+        A.p = params[i];
+        A.pix = pixel_types[i];
+        if (b.input.kind == GFW_BUF_HOST) {
+            HIP_TRY(c->stage_src[i].ensure(b.input.len), GFW_ERR_HIP);
+            HIP_TRY(hipMemcpyAsync(c->stage_src[i].ptr, b.input.data, b.input.len, hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);  // opencl.rs:359
+            A.src = (const uint8_t *)c->stage_src[i].ptr;
+        } else A.src = (const uint8_t *)b.input.data;
+        if (b.output.kind == GFW_BUF_HOST) {
+            HIP_TRY(c->stage_dst[i].ensure(b.output.len), GFW_ERR_HIP);
+            // bytes the kernel never writes (stride padding, pixels outside output_rect) must keep the caller's
+            // content, as they do on the CPU path — bring the current output over first.
+            HIP_TRY(hipMemcpyAsync(c->stage_dst[i].ptr, b.output.data, b.output.len, hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
+            A.dst = (uint8_t *)c->stage_dst[i].ptr;
+        } else A.dst = (uint8_t *)b.output.data;
+        A.dst_len = (int64_t)b.output.len;
+        A.dst_stride = b.output.stride;
+        A.out_rows = (int32_t)((b.output.len + (size_t)b.output.stride - 1) / (size_t)b.output.stride);
+        A.out_cols = b.output.stride / A.p.bytes_per_pixel;
+    }
+
+    GfwCommon C;
+    prof_begin(c);
+    for (int i = 0; i < nplanes; ++i) {
+        fill_common(c, &params[i], d_mat, d_mesh, (int)mesh_len, C);
+        HIP_TRY(gfw_launch_plane(launches[i], C, c->stream), GFW_ERR_HIP);
+    }
+    prof_end(c);
+    if (c->ev_used > 4096) { (void)hipStreamSynchronize(c->stream); prof_harvest(c); }
+    c->last_backend = "plane_generic";
+
+    bool any_host_out = false;
+    for (int i = 0; i < nplanes; ++i) {
+        if (planes[i].output.kind == GFW_BUF_HOST) {
+            HIP_TRY(hipMemcpyAsync(planes[i].output.data, c->stage_dst[i].ptr, planes[i].output.len, hipMemcpyDeviceToHost, c->stream), GFW_ERR_HIP);  // opencl.rs:413
+            any_host_out = true;
+        }
+    }
+    if (c->synchronous || any_host_out) HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
+    return GFW_OK;
+}
+
+extern "C" {
+
+int gfw_undistort_image(gfw_ctx *c, const gfw_buffers *buffers, const gfw_kernel_params *params,
+                        const float *matrices, int matrix_count, const uint8_t *drawing, size_t drawing_len,
+                        const float *mesh, size_t mesh_len) {
+    (void)drawing; (void)drawing_len;
+    if (!c) { set_error("null context"); return GFW_ERR_INVALID_ARGUMENT; }
+    if (buffers && buffers->input.kind == GFW_BUF_HOST && buffers->input.len != c->src_len) {
+        set_error("Buffer size mismatch input! %zu vs %zu", c->src_len, buffers->input.len); return GFW_ERR_BUFFER_SIZE_MISMATCH; }   // opencl.rs:358
+    const int pt = c->pixel_type;
+    return run_planes(c, 1, buffers, params, &pt, matrices, matrix_count, mesh, mesh_len);
+}
+
+int gfw_undistort_frame(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params,
+                        const int *pixel_types, const float *matrices, int matrix_count, const float *mesh, size_t mesh_len) {
+    if (!planes || !params || !pixel_types) { set_error("null plane arrays"); return GFW_ERR_INVALID_ARGUMENT; }
+    for (int i = 0; i < nplanes; ++i)
+        if (pixel_types[i] < 0 || pixel_types[i] >= GFW_PIX_COUNT) { set_error("plane %d: unknown pixel type %d", i, pixel_types[i]); return GFW_ERR_INVALID_ARGUMENT; }
+    return run_planes(c, nplanes, planes, params, pixel_types, matrices, matrix_count, mesh, mesh_len);
+}
+
+}  // extern "C"

@@ -1,0 +1,7 @@
+// gfw_launch.h — host-visible launch entry points of gfw_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gfw_warp.h"
+
+hipError_t gfw_launch_plane(const GfwPlane &A, const GfwCommon &C, hipStream_t s);
+hipError_t gfw_launch_repack(const float *in, float *out, int rows, hipStream_t s);

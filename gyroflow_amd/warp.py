@@ -1,0 +1,154 @@
+"""Thin ctypes driver over the C ABI (include/gfwarp.h).
+
+``Backend`` plays the role of the reference's ``OclWrapper`` / ``WgpuWrapper`` objects
+(src/core/gpu/opencl.rs:178,330): construct once per (size, pixel type, lens model) key, then call
+``undistort_image`` per plane or ``undistort_frame`` per frame.  All pixel work happens in
+libgfwarp.so on the GPU; this module only marshals pointers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+class GfwError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (abi.ERRORS.get(code, "?"), code, msg))
+        self.code = code
+        self.name = abi.ERRORS.get(code, "?")
+
+
+def _desc(d, size, kind, ptr, nbytes, rect=None, rotation=None):
+    d.width, d.height, d.stride = size
+    d.has_rect = 1 if rect is not None else 0
+    if rect is not None:
+        for i in range(4):
+            d.rect[i] = rect[i]
+    d.has_rotation = 1 if rotation is not None else 0
+    d.rotation = rotation or 0.0
+    d.kind = kind
+    d.data = ptr
+    d.len = nbytes
+
+
+def host_buffers(src, in_size, dst, out_size, in_rect=None, out_rect=None, in_rot=None, out_rot=None):
+    """``Buffers`` over two numpy uint8 arrays (BufferSource::Cpu)."""
+    b = abi.Buffers()
+    _desc(b.input, in_size, abi.BUF_HOST, src.ctypes.data, src.nbytes, in_rect, in_rot)
+    _desc(b.output, out_size, abi.BUF_HOST, dst.ctypes.data, dst.nbytes, out_rect, out_rot)
+    return b
+
+
+def device_buffers(src_ptr, src_len, in_size, dst_ptr, dst_len, out_size, in_rect=None, out_rect=None):
+    """``Buffers`` over raw HIP device pointers (the CUDABuffer analogue)."""
+    b = abi.Buffers()
+    _desc(b.input, in_size, abi.BUF_HIP_DEVICE, src_ptr, src_len, in_rect)
+    _desc(b.output, out_size, abi.BUF_HIP_DEVICE, dst_ptr, dst_len, out_rect)
+    return b
+
+
+_last_backend = ""
+
+
+def last_backend():
+    return _last_backend
+
+
+class Backend:
+    def __init__(self, params, pixel_type, model, digital, buffers, drawing_len=0):
+        self.lib = abi.load_library()
+        pid = abi.PIXEL_TYPES[pixel_type][0] if isinstance(pixel_type, str) else pixel_type
+        self.ctx = self.lib.gfw_create(C.byref(params), pid, model, digital, C.byref(buffers), drawing_len)
+        if not self.ctx:
+            raise GfwError(-100, self.lib.gfw_last_error().decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.gfw_destroy(self.ctx)
+            self.ctx = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        global _last_backend
+        if rc != 0:
+            raise GfwError(rc, self.lib.gfw_last_error().decode())
+        _last_backend = self.lib.gfw_last_backend(self.ctx).decode()
+
+    def set_option(self, opt, value):
+        self._check(self.lib.gfw_set_option(self.ctx, opt, value))
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.gfw_set_stream(self.ctx, stream_ptr))
+
+    def get_profile(self, reset=True):
+        """(kernel milliseconds, launches) accumulated since the last reset (needs OPT_PROFILE)."""
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        self._check(self.lib.gfw_get_profile(self.ctx, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
+    def synchronize(self):
+        self._check(self.lib.gfw_synchronize(self.ctx))
+
+    def undistort_image(self, buffers, params, matrices, mesh=None, matrix_count=None):
+        """One plane (OclWrapper::undistort_image).  ``matrices``: numpy [rows][14] f32, or a device pointer int."""
+        if isinstance(matrices, np.ndarray):
+            m = np.ascontiguousarray(matrices, dtype=np.float32)
+            mp, mc = m.ctypes.data, m.shape[0]
+        else:
+            mp, mc = matrices, matrix_count
+        meshp, meshn = None, 0
+        if mesh is not None and len(mesh):
+            mesh = np.ascontiguousarray(mesh, dtype=np.float32)
+            meshp, meshn = mesh.ctypes.data, mesh.size
+        self._check(self.lib.gfw_undistort_image(self.ctx, C.byref(buffers), C.byref(params), mp, mc, None, 0, meshp, meshn))
+
+    def undistort_frame(self, planes, params, pixel_types, matrices, mesh=None, matrix_count=None):
+        """All planes of a frame in one call (additive entry point)."""
+        n = len(planes)
+        barr = (abi.Buffers * n)(*planes)
+        parr = (abi.KernelParams * n)(*params)
+        tarr = (C.c_int * n)(*[abi.PIXEL_TYPES[t][0] if isinstance(t, str) else t for t in pixel_types])
+        if isinstance(matrices, np.ndarray):
+            m = np.ascontiguousarray(matrices, dtype=np.float32)
+            mp, mc = m.ctypes.data, m.shape[0]
+        else:
+            mp, mc = matrices, matrix_count
+        meshp, meshn = None, 0
+        if mesh is not None and len(mesh):
+            mesh = np.ascontiguousarray(mesh, dtype=np.float32)
+            meshp, meshn = mesh.ctypes.data, mesh.size
+        self._check(self.lib.gfw_undistort_frame(self.ctx, n, barr, parr, tarr, mp, mc, meshp, meshn))
+
+
+def run_plane(src, in_size, dst, out_size, params, pixel_type, model, digital, matrices, mesh=None, **rects):
+    """Convenience: create a backend, warp one HOST plane in place into ``dst``."""
+    b = host_buffers(src, in_size, dst, out_size, **rects)
+    be = Backend(params, pixel_type, model, digital, b)
+    try:
+        be.undistort_image(b, params, matrices, mesh)
+    finally:
+        be.close()
+
+
+def run_frame(frame, fused=True):
+    """Warp every plane of a ``synthetic.SyntheticFrame`` from HOST buffers; returns output copies."""
+    outs = [pl["dst"].copy() for pl in frame.planes]
+    bufs = [host_buffers(pl["src"], pl["size"], o, pl["out_size"]) for pl, o in zip(frame.planes, outs)]
+    params = [pl["params"] for pl in frame.planes]
+    types = [pl["pixel_type"] for pl in frame.planes]
+    be = Backend(params[0], types[0], frame.model, frame.digital, bufs[0])
+    try:
+        if fused:
+            be.undistort_frame(bufs, params, types, frame.matrices)
+        else:
+            for b, p, t in zip(bufs, params, types):
+                be2 = Backend(p, t, frame.model, frame.digital, b)
+                try:
+                    be2.undistort_image(b, p, frame.matrices)
+                finally:
+                    be2.close()
+    finally:
+        be.close()
+    return outs

@@ -251,7 +251,8 @@ int gfw_undistort_frame(gfw_ctx *ctx, int nplanes,
 enum {
     GFW_OPT_SYNCHRONOUS        = 1,  /* 1 (default): return after stream sync */
     GFW_OPT_MATRICES_ON_DEVICE = 2,  /* 1: `matrices` is a device pointer */
-    GFW_OPT_KERNEL_VARIANT     = 3   /* debug/benchmark: force a kernel variant */
+    GFW_OPT_KERNEL_VARIANT     = 3,  /* debug/benchmark: force a kernel variant */
+    GFW_OPT_PROFILE            = 4   /* 1: bracket every warp-kernel launch with hipEvents on the context stream */
 };
 int   gfw_set_option(gfw_ctx *ctx, int option, int64_t value);
 /* hipStream_t the context enqueues on (as void*); caller may substitute its
@@ -263,6 +264,10 @@ int   gfw_synchronize(gfw_ctx *ctx);
 /* Name of the kernel path the last call took ("plane_generic", "yuv_fused", ...):
  * the analogue of ProcessedInfo.backend (stabilization/mod.rs:194-200). */
 const char *gfw_last_backend(gfw_ctx *ctx);
+
+/* With GFW_OPT_PROFILE on: accumulated warp-kernel time (ms, hipEventElapsedTime on the context stream)
+ * and launch count since the last reset; synchronises the stream.  reset != 0 clears the accumulators. */
+int   gfw_get_profile(gfw_ctx *ctx, double *kernel_ms, int64_t *launches, int reset);
 
 /* Thread-local, human-readable description of the last failure. */
 const char *gfw_last_error(void);
