@@ -16,6 +16,9 @@
 
 #include "../../include/gfwarp.h"
 #include "gfw_launch.h"
+#include "gfw_frame.h"
+#include <map>
+#include <mutex>
 
 static_assert(sizeof(gfw_kernel_params) == 368, "KernelParams must be 368 bytes (stabilization/mod.rs:101-150)");
 static_assert(offsetof(gfw_kernel_params, background) == 48, "layout");
@@ -313,6 +316,152 @@ static void fill_common(gfw_ctx *c, const gfw_kernel_params *p, const float *d_m
     C.gopro_tt = tanf(1.5533f);   // gopro.rs:45,58: TMAX.tan()
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// divide-by-constant validation for gfw_map_const (gfw_fastmath.h): exhaustive over all 2^23 significands,
+// scale-invariant, cached per divisor.
+static bool map_const_valid(float den) {
+    static std::mutex mu;
+    static std::map<uint32_t, bool> cache;
+    uint32_t key; memcpy(&key, &den, 4);
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
+    bool ok = den >= 1.0f && den <= 1048576.0f;
+    if (ok) {
+        const float rcp = 1.0f / den;
+        for (uint32_t m = 0; m < (1u << 23) && ok; ++m) {
+            const uint32_t bits = 0x3f800000u | m;
+            float a; memcpy(&a, &bits, 4);
+            const float q0 = a * rcp;
+            const float r0 = fmaf(-den, q0, a);
+            const float q = fmaf(r0, rcp, q0);
+            ok = (q == a / den);
+        }
+    }
+    std::lock_guard<std::mutex> g(mu);
+    cache[key] = ok;
+    return ok;
+}
+// x * n is exact in f32 for every integer 0 <= x < n_max  <=>  (n_max-1) * odd_part(n) < 2^24
+static bool int_products_exact(int n_max, int n) {
+    if (n <= 0 || n_max <= 0) return false;
+    int odd = n; while ((odd & 1) == 0) odd >>= 1;
+    return (int64_t)(n_max - 1) * odd < (1 << 24);
+}
+
+// Decide whether the frame qualifies for the fused YUV kernel and, if so, build its argument block.
+// Anything not proven here runs through the generic per-plane kernel (same results, slower).
+static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params, const int *pixel_types,
+                           const std::vector<GfwPlane> &launches, const float *h_matrices, int matrix_count, size_t mesh_len,
+                           GfwYuvArgs &Y, int &bytes_per_sample, int &dw, int &dh, bool &interleaved) {
+    if (c->kernel_variant == 1) return false;                       // forced generic (tests / A-B benchmarking)
+    if (nplanes < 1 || nplanes > 4 || mesh_len != 0) return false;
+    const gfw_kernel_params &p0 = params[0];
+    const int t0 = pixel_types[0];
+    if (t0 != GFW_PIX_LUMA8 && t0 != GFW_PIX_LUMA16) return false;
+    bytes_per_sample = (t0 == GFW_PIX_LUMA8) ? 1 : 2;
+    interleaved = false;
+    if (nplanes >= 2) {
+        const int t1 = pixel_types[1];
+        if (t1 == (bytes_per_sample == 1 ? GFW_PIX_UV8 : GFW_PIX_UV16)) { if (nplanes != 2) return false; interleaved = true; }
+        else { for (int i = 1; i < nplanes; ++i) if (pixel_types[i] != t0) return false; }
+    }
+    if (c->digital != GFW_MODEL_NONE && (p0.flags & GFW_FLAG_HAS_DIGITAL_LENS)) return false;
+    if (c->model < GFW_MODEL_OPENCV_FISHEYE || c->model > GFW_MODEL_GOPRO) return false;
+    // plane-invariant parameters must really be invariant, and inside the fused kernel's feature set
+    for (int i = 0; i < nplanes; ++i) {
+        const gfw_kernel_params &p = params[i];
+        if (p.interpolation != 2 || p.background_mode != 0 || p.input_rotation != 0.0f) return false;
+        if (p.lens_correction_amount < 1.0f || !(p.lens_correction_amount == p.lens_correction_amount)) return false;
+        if (p.light_refraction_coefficient != 1.0f && p.light_refraction_coefficient > 0.0f) return false;
+        if (!(p.light_refraction_coefficient == p.light_refraction_coefficient)) return false;
+        if (p.flags & (GFW_FLAG_FIX_COLOR_RANGE | GFW_FLAG_FILL_WITH_BACKGROUND)) return false;
+        if (p.translation3d[0] != 0.0f || p.translation3d[1] != 0.0f || p.translation3d[2] != 0.0f) return false;
+        if (p.width != p0.width || p.height != p0.height || p.output_width != p0.output_width || p.output_height != p0.output_height) return false;
+        if (p.matrix_count != p0.matrix_count || ((p.flags ^ p0.flags) & GFW_FLAG_HORIZONTAL_RS)) return false;
+        if (memcmp(p.f, p0.f, sizeof(p.f)) || memcmp(p.c, p0.c, sizeof(p.c)) || memcmp(p.k, p0.k, sizeof(p.k))) return false;
+        if (memcmp(p.translation2d, p0.translation2d, sizeof(p.translation2d)) || p.r_limit != p0.r_limit || p.fov != p0.fov) return false;
+        if (p.input_horizontal_stretch != p0.input_horizontal_stretch || p.input_vertical_stretch != p0.input_vertical_stretch) return false;
+        // full-plane rects: source_rect = (0,0,pw,ph), output_rect = (0,0,opw,oph), buffers sized accordingly
+        const gfw_buffers &b = planes[i];
+        if (p.source_rect[0] || p.source_rect[1] || p.source_rect[2] != b.input.width || p.source_rect[3] != b.input.height) return false;
+        if (p.output_rect[0] || p.output_rect[1] || p.output_rect[2] != b.output.width || p.output_rect[3] != b.output.height) return false;
+        if (p.stride <= 0 || b.output.stride <= 0) return false;
+        if ((int64_t)b.input.height * p.stride > (int64_t)b.input.len) return false;
+        if ((int64_t)b.output.height * b.output.stride > (int64_t)b.output.len) return false;
+        if ((int64_t)b.output.width * p.bytes_per_pixel > b.output.stride) return false;
+        // rows of the buffer beyond the plane would be visited (and skipped) by the reference; require none carry pixels
+        if ((bytes_per_sample == 2) && ((p.stride | b.output.stride) & 1)) return false;
+    }
+    for (int i = 0; i < 12; ++i) { const float k = p0.k[i]; if (!(k == k) || fabsf(k) > 1024.0f) return false; }
+    if (!(p0.f[0] == p0.f[0]) || !(p0.f[1] == p0.f[1]) || !(p0.c[0] == p0.c[0]) || !(p0.c[1] == p0.c[1])) return false;
+    if (!(p0.translation2d[0] == p0.translation2d[0]) || !(p0.translation2d[1] == p0.translation2d[1])) return false;
+    // luma plane is full resolution on both sides
+    if (planes[0].input.width != p0.width || planes[0].input.height != p0.height) return false;
+    if (planes[0].output.width != p0.output_width || planes[0].output.height != p0.output_height) return false;
+    dw = 1; dh = 1;
+    if (nplanes >= 2) {
+        const int cw = planes[1].output.width, ch = planes[1].output.height;
+        if (cw <= 0 || ch <= 0 || p0.output_width % cw || p0.output_height % ch) return false;
+        dw = p0.output_width / cw; dh = p0.output_height / ch;
+        if (!((dw == 1 && dh == 1) || (dw == 2 && dh == 1) || (dw == 2 && dh == 2))) return false;
+        for (int i = 1; i < nplanes; ++i) {
+            if (planes[i].output.width != cw || planes[i].output.height != ch) return false;
+            if (planes[i].input.width * dw != p0.width || planes[i].input.height * dh != p0.height) return false;
+        }
+        // chroma site -> luma position identity: xc*ow exact and (xc*ow)/(ow/dw) = dw*xc   (util.rs:144-147)
+        if (!int_products_exact(cw, p0.output_width) || !int_products_exact(ch, p0.output_height)) return false;
+    }
+    // luma output pixel -> output space identity: x*ow/ow = x
+    if (!int_products_exact(p0.output_width, p0.output_width) || !int_products_exact(p0.output_height, p0.output_height)) return false;
+    if (p0.output_width >= (1 << 23) || p0.output_height >= (1 << 23)) return false;
+    // IBIS/OIS terms (matrices[9..13]) must be absent: host matrices are scanned, device matrices rely on the flag
+    if (h_matrices) {
+        for (int r = 0; r < matrix_count; ++r) { const float *m = h_matrices + (size_t)r * 14;
+            if (m[9] != 0.0f || m[10] != 0.0f || m[11] != 0.0f || m[12] != 0.0f || m[13] != 0.0f) return false; }
+    } else if (p0.flags & GFW_FLAG_HAS_IBIS_DATA) return false;
+    // source_rect map constants: u * pw / W  (cpu_undistort.rs:511-514 with frame_size = (width, height))
+    const float Wf = (float)p0.width, Hf = (float)p0.height;
+    if (!map_const_valid(Wf) || !map_const_valid(Hf)) return false;
+
+    memset(&Y, 0, sizeof(Y));
+    for (int i = 0; i < nplanes; ++i) {
+        GfwYuvPlane &P = Y.pl[i];
+        P.src = launches[i].src; P.dst = launches[i].dst;
+        P.src_stride = params[i].stride; P.dst_stride = planes[i].output.stride;
+        P.w = planes[i].input.width; P.h = planes[i].input.height;
+        P.bg[0] = params[i].background[0] * params[i].max_pixel_value;
+        P.bg[1] = params[i].background[1] * params[i].max_pixel_value;
+        P.limit = params[i].pixel_value_limit;
+    }
+    Y.nplanes = nplanes;
+    Y.width = p0.width; Y.height = p0.height;
+    Y.out_w = p0.output_width; Y.out_h = p0.output_height;
+    Y.cw = (p0.output_width + dw - 1) / dw; Y.ch = (p0.output_height + dh - 1) / dh;
+    Y.tiles_x = (Y.cw + 63) / 64; Y.tiles_y = (Y.ch + 3) / 4;
+    Y.matrix_count = matrix_count;
+    Y.hrs = (p0.flags & GFW_FLAG_HORIZONTAL_RS) ? 1 : 0;
+    Y.model = c->model;
+    Y.k_all_zero = (p0.k[0] == 0.0f && p0.k[1] == 0.0f && p0.k[2] == 0.0f && p0.k[3] == 0.0f) ? 1 : 0;
+    Y.hstretch = p0.input_horizontal_stretch; Y.vstretch = p0.input_vertical_stretch;
+    Y.hstretch_div = (p0.input_horizontal_stretch > 0.001f && p0.input_horizontal_stretch != 1.0f) ? 1 : 0;   // x/1 == x
+    Y.vstretch_div = (p0.input_vertical_stretch > 0.001f && p0.input_vertical_stretch != 1.0f) ? 1 : 0;
+    memcpy(Y.f, p0.f, sizeof(Y.f)); memcpy(Y.c, p0.c, sizeof(Y.c)); memcpy(Y.k, p0.k, sizeof(Y.k));
+    Y.t2[0] = p0.translation2d[0]; Y.t2[1] = p0.translation2d[1];
+    Y.r_limit_sq = p0.r_limit * p0.r_limit;
+    Y.map_lx = GfwMapConst{(float)planes[0].input.width, Wf, 1.0f / Wf};
+    Y.map_ly = GfwMapConst{(float)planes[0].input.height, Hf, 1.0f / Hf};
+    if (nplanes >= 2) {
+        Y.map_cx = GfwMapConst{(float)planes[1].input.width, Wf, 1.0f / Wf};
+        Y.map_cy = GfwMapConst{(float)planes[1].input.height, Hf, 1.0f / Hf};
+    }
+    Y.kp = p0;
+    return true;
+}
+
 static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params, const int *pixel_types,
                       const float *matrices, int matrix_count, const float *mesh, size_t mesh_len) {
     if (!c) { set_error("null context"); return GFW_ERR_INVALID_ARGUMENT; }
@@ -360,14 +509,25 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
     }
 
     GfwCommon C;
+    GfwYuvArgs Y;
+    int bps = 0, dw = 1, dh = 1; bool interleaved = false;
+    const bool fused = build_yuv_args(c, nplanes, planes, params, pixel_types, launches, c->matrices_on_device ? nullptr : matrices,
+                                      matrix_count, mesh_len, Y, bps, dw, dh, interleaved);
     prof_begin(c);
-    for (int i = 0; i < nplanes; ++i) {
-        fill_common(c, &params[i], d_mat, d_mesh, (int)mesh_len, C);
-        HIP_TRY(gfw_launch_plane(launches[i], C, c->stream), GFW_ERR_HIP);
+    if (fused) {
+        fill_common(c, &params[0], d_mat, nullptr, 0, Y.common);
+        Y.matrices = d_mat;
+        HIP_TRY(gfw_launch_yuv(Y, bps, dw, dh, interleaved, c->stream), GFW_ERR_HIP);
+        c->last_backend = "yuv_fused";
+    } else {
+        for (int i = 0; i < nplanes; ++i) {
+            fill_common(c, &params[i], d_mat, d_mesh, (int)mesh_len, C);
+            HIP_TRY(gfw_launch_plane(launches[i], C, c->stream), GFW_ERR_HIP);
+        }
+        c->last_backend = "plane_generic";
     }
     prof_end(c);
     if (c->ev_used > 4096) { (void)hipStreamSynchronize(c->stream); prof_harvest(c); }
-    c->last_backend = "plane_generic";
 
     bool any_host_out = false;
     for (int i = 0; i < nplanes; ++i) {

@@ -132,23 +132,30 @@ def run_plane(src, in_size, dst, out_size, params, pixel_type, model, digital, m
         be.close()
 
 
-def run_frame(frame, fused=True):
-    """Warp every plane of a ``synthetic.SyntheticFrame`` from HOST buffers; returns output copies."""
+def run_frame(frame, fused=True, per_plane=False):
+    """Warp every plane of a ``synthetic.SyntheticFrame`` from HOST buffers; returns output copies.
+
+    fused=False forces the generic per-plane kernel (GFW_OPT_KERNEL_VARIANT = 1); per_plane=True issues one
+    ``gfw_undistort_image`` per plane, the way the reference's render loop does."""
     outs = [pl["dst"].copy() for pl in frame.planes]
     bufs = [host_buffers(pl["src"], pl["size"], o, pl["out_size"]) for pl, o in zip(frame.planes, outs)]
     params = [pl["params"] for pl in frame.planes]
     types = [pl["pixel_type"] for pl in frame.planes]
+    if per_plane:
+        for b, p, t in zip(bufs, params, types):
+            be = Backend(p, t, frame.model, frame.digital, b)
+            try:
+                if not fused:
+                    be.set_option(abi.OPT_KERNEL_VARIANT, 1)
+                be.undistort_image(b, p, frame.matrices)
+            finally:
+                be.close()
+        return outs
     be = Backend(params[0], types[0], frame.model, frame.digital, bufs[0])
     try:
-        if fused:
-            be.undistort_frame(bufs, params, types, frame.matrices)
-        else:
-            for b, p, t in zip(bufs, params, types):
-                be2 = Backend(p, t, frame.model, frame.digital, b)
-                try:
-                    be2.undistort_image(b, p, frame.matrices)
-                finally:
-                    be2.close()
+        if not fused:
+            be.set_option(abi.OPT_KERNEL_VARIANT, 1)
+        be.undistort_frame(bufs, params, types, frame.matrices)
     finally:
         be.close()
     return outs

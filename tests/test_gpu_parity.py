@@ -37,11 +37,20 @@ def assert_plane_equal(ref, got, pixel_type, where=""):
             raise AssertionError("%s: %d bytes differ (first at %d: ref %d got %d)" % (where, bad.size, bad[0], ref[bad[0]], got[bad[0]]))
 
 
-def check_frame(fr, fused=True):
+def check_frame(fr, expect_backend=None):
+    """Oracle vs (a) the frame entry point (fused kernel when eligible) and (b) the generic per-plane kernel."""
     ref = O.run_frame(fr)
-    got = warp.run_frame(fr, fused=fused)
+    got = warp.run_frame(fr, fused=True)
+    backend = warp.last_backend()
     for i, (a, b) in enumerate(zip(ref, got)):
-        assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "plane %d" % i)
+        assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "%s plane %d" % (backend, i))
+    if expect_backend is not None:
+        assert backend == expect_backend
+    if backend != "plane_generic":
+        got2 = warp.run_frame(fr, fused=False)
+        assert warp.last_backend() == "plane_generic"
+        for i, (a, b) in enumerate(zip(ref, got2)):
+            assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "plane_generic plane %d" % i)
     return ref, got
 
 
@@ -60,9 +69,32 @@ def test_interpolations(interp, ptype_fmt):
 def test_per_plane_calls_equal_frame_call():
     fr = S.SyntheticFrame("YUV422P16LE", 256, 160, seed=3)
     a = warp.run_frame(fr, fused=True)
-    b = warp.run_frame(fr, fused=False)
-    for x, y in zip(a, b):
-        assert np.array_equal(x, y)
+    assert warp.last_backend() == "yuv_fused"
+    b = warp.run_frame(fr, fused=False, per_plane=True)
+    c = warp.run_frame(fr, fused=True, per_plane=True)
+    for x, y, z in zip(a, b, c):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+
+
+@pytest.mark.parametrize("fmt", ["NV12", "P010", "P210", "YUV420P", "YUV422P16LE", "YUV444P16LE", "YUV420P10LE"])
+def test_fused_kernel_is_used_for_yuv(fmt):
+    check_frame(S.SyntheticFrame(fmt, 320, 192, seed=13), expect_backend="yuv_fused")
+
+
+def test_fused_kernel_out_of_frame_and_edges():
+    # zoomed-out view: large background regions + taps straddling every source edge
+    check_frame(S.SyntheticFrame("YUV422P16LE", 320, 192, seed=17, fov=3.0, background_rgba=(0.25, 0.5, 0.75, 1.0)), expect_backend="yuv_fused")
+    check_frame(S.SyntheticFrame("NV12", 320, 192, seed=17, fov=3.0, background_rgba=(0.25, 0.5, 0.75, 1.0)), expect_backend="yuv_fused")
+
+
+def test_fused_kernel_odd_sizes():
+    check_frame(S.SyntheticFrame("YUV422P16LE", 322, 190, seed=19), expect_backend="yuv_fused")
+    check_frame(S.SyntheticFrame("YUV420P", 130, 66, seed=19), expect_backend="yuv_fused")
+
+
+def test_fused_kernel_no_rolling_shutter_and_horizontal():
+    check_frame(S.SyntheticFrame("YUV422P16LE", 256, 160, seed=23, readout_ms=0.0), expect_backend="yuv_fused")
+    check_frame(S.SyntheticFrame("YUV422P16LE", 256, 160, seed=23, horizontal_rs=True), expect_backend="yuv_fused")
 
 
 def test_c1_1080p_nv12_constant_quaternion():
