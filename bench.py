@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from gyroflow_amd import abi, synthetic as S, warp
+from gyroflow_amd import abi, shard, synthetic as S, warp
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FMT, WIDTH, HEIGHT = "YUV422P16LE", 3840, 2160
@@ -47,18 +47,12 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = shard.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libgfwarp has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    dist = shard.init("nccl", rank, world, dev)
 
     lib = abi.load_library()
     if lib.gfw_set_device(local_rank) != 0:
@@ -95,15 +89,13 @@ def main():
     torch.cuda.synchronize(dev)
     be.set_option(abi.OPT_PROFILE, 1)
     be.get_profile(reset=True)
-    if dist is not None:
-        dist.barrier()
+    shard.barrier(dist)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
     torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
+    shard.barrier(dist)
     t1 = time.perf_counter()
     elapsed = t1 - t0
     kernel_ms, launches = be.get_profile(reset=True)
@@ -114,13 +106,8 @@ def main():
     last = (args.steps - 1) & 1
     for p in range(nplanes):
         crc = zlib.crc32(d_dst[last][p].cpu().numpy().tobytes(), crc)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        csum = torch.tensor([crc], dtype=torch.int64, device=dev)
-        dist.all_reduce(csum, op=dist.ReduceOp.SUM)
-        crc = int(csum.item())
+    elapsed = shard.reduce_max(dist, elapsed, dev)
+    crc = shard.reduce_checksum(dist, crc, dev)
 
     luma_px = frames[0].luma_pixels()
     alg_bytes = frames[0].algorithmic_bytes()
@@ -153,7 +140,7 @@ def main():
         while True:
             ref = O.run_frame(frames[n_cpu % N_DISTINCT])
             n_cpu += 1
-            if time.perf_counter() - c0 > 10.0 or n_cpu >= 16:
+            if time.perf_counter() - c0 > 12.0 or n_cpu >= 256:
                 break
         cpu_s = time.perf_counter() - c0
         out["cpu_baseline"] = {"value": round(luma_px * n_cpu / cpu_s / 1e6, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
@@ -167,8 +154,7 @@ def main():
     be.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    shard.finish(dist)
 
 
 if __name__ == "__main__":

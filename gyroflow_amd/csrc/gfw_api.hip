@@ -562,3 +562,34 @@ int gfw_undistort_frame(gfw_ctx *c, int nplanes, const gfw_buffers *planes, cons
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ test hooks
+extern "C" {
+int gfw_debug_math(int op, const float *a, const float *b, float *out, size_t n) {
+    if (!a || !out || n == 0) { set_error("null/empty arrays"); return GFW_ERR_INVALID_ARGUMENT; }
+    if (device_count() == 0) { set_error("no HIP device visible"); return GFW_ERR_NO_DEVICE; }
+    HIP_TRY(hipSetDevice(g_current_device), GFW_ERR_HIP);
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(&da, n * sizeof(float)), GFW_ERR_HIP);
+    HIP_TRY(hipMalloc(&dout, n * sizeof(float)), GFW_ERR_HIP);
+    if (b) HIP_TRY(hipMalloc(&db, n * sizeof(float)), GFW_ERR_HIP);
+    HIP_TRY(hipMemcpy(da, a, n * sizeof(float), hipMemcpyHostToDevice), GFW_ERR_HIP);
+    if (b) HIP_TRY(hipMemcpy(db, b, n * sizeof(float), hipMemcpyHostToDevice), GFW_ERR_HIP);
+    HIP_TRY(gfw_launch_debug_math(op, da, db, dout, n, nullptr), GFW_ERR_HIP);
+    HIP_TRY(hipMemcpy(out, dout, n * sizeof(float), hipMemcpyDeviceToHost), GFW_ERR_HIP);
+    (void)hipFree(da); (void)hipFree(dout); if (db) (void)hipFree(db);
+    return GFW_OK;
+}
+long long gfw_debug_selftest(int test, unsigned long long n, unsigned long long seed) {
+    if (device_count() == 0) { set_error("no HIP device visible"); return GFW_ERR_NO_DEVICE; }
+    HIP_TRY(hipSetDevice(g_current_device), GFW_ERR_HIP);
+    if (test == 2 && n == 0) n = 1ull << 31;
+    unsigned long long *dbad = nullptr, bad = 0;
+    HIP_TRY(hipMalloc(&dbad, sizeof(bad)), GFW_ERR_HIP);
+    HIP_TRY(hipMemset(dbad, 0, sizeof(bad)), GFW_ERR_HIP);
+    HIP_TRY(gfw_launch_debug_selftest(test, n, seed, dbad, nullptr), GFW_ERR_HIP);
+    HIP_TRY(hipMemcpy(&bad, dbad, sizeof(bad), hipMemcpyDeviceToHost), GFW_ERR_HIP);
+    (void)hipFree(dbad);
+    return (long long)bad;
+}
+}

@@ -1,6 +1,7 @@
 // gfw_kernels.hip — kernel dispatch by PixelType + the small utility kernels of libgfwarp.
 #include <hip/hip_runtime.h>
 #include "gfw_launch.h"
+#include "gfw_fastmath.h"
 
 #define GFW_DECL(n) hipError_t gfw_launch_plane_pix##n(const GfwPlane &A, const GfwCommon &C, hipStream_t s);
 GFW_DECL(0) GFW_DECL(1) GFW_DECL(2) GFW_DECL(3) GFW_DECL(4) GFW_DECL(5) GFW_DECL(6)
@@ -26,5 +27,64 @@ __global__ void gfw_repack_matrices_kernel(const float *in, float *out, int rows
 hipError_t gfw_launch_repack(const float *in, float *out, int rows, hipStream_t s) {
     const int n = rows * GFW_MAT_STRIDE;
     hipLaunchKernelGGL(gfw_repack_matrices_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, rows);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------- test hooks (gfw_debug_*)
+__global__ void gfw_debug_math_kernel(int op, const float *a, const float *b, float *out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], y = b ? b[i] : 1.0f;
+    float r = 0.0f;
+    switch (op) {
+    case 0: r = gfw_atanf(x); break;
+    case 1: r = gfw_tanf(x); break;
+    case 2: r = gfw_atanf_pos(x); break;
+    case 3: r = gfw_div_lean(x, y); break;
+    case 4: r = x / y; break;
+    case 5: r = gfw_sqrt_lean(x); break;
+    case 6: r = sqrtf(x); break;
+    case 7: r = (float)gfw_f2i(x); break;
+    case 8: r = (float)gfw_f2u_sat(x, 65535.0f); break;
+    case 9: r = gfw_round(x); break;
+    case 10: r = (float)gfw_f2u_sat(x, 255.0f); break;
+    }
+    out[i] = r;
+}
+hipError_t gfw_launch_debug_math(int op, const float *a, const float *b, float *out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(gfw_debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, op, a, b, out, n);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ uint64_t gfw_mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31);
+}
+__global__ void gfw_debug_selftest_kernel(int test, unsigned long long n, unsigned long long seed, unsigned long long *bad) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long local = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t h = gfw_mix64(i ^ seed);
+        if (test == 0) {
+            // a: sign, exponent in [2^-19.., 2^19], any mantissa (or exactly 0 once in 64); b: positive, exponent in [2^-20, 2^20]
+            const uint32_t ea = 108u + (uint32_t)((h >> 23) % 39u), eb = 107u + (uint32_t)((h >> 55) % 41u);
+            float a = gfw_u2f(((uint32_t)(h >> 63) << 31) | (ea << 23) | (uint32_t)(h & 0x7fffffu));
+            const float b = gfw_u2f((eb << 23) | (uint32_t)((h >> 29) & 0x7fffffu));
+            if (((h >> 47) & 63u) == 0) a = 0.0f;
+            const float q = gfw_div_lean(a, b), r = a / b;
+            if (gfw_f2u(q) != gfw_f2u(r) && !(q == 0.0f && r == 0.0f)) local++;
+        } else if (test == 1) {
+            const uint32_t e = 47u + (uint32_t)((h >> 23) % 160u);                    // 2^-80 .. 2^79
+            const float x = (((h >> 40) & 255u) == 0) ? 0.0f : gfw_u2f((e << 23) | (uint32_t)(h & 0x7fffffu));
+            if (gfw_f2u(gfw_sqrt_lean(x)) != gfw_f2u(sqrtf(x))) local++;
+        } else if (test == 2) {
+            const float x = gfw_u2f((uint32_t)i & 0x7fffffffu);                       // every non-negative float (incl. inf/NaN)
+            const float p = gfw_atanf_pos(x), q = gfw_atanf(x);
+            if (gfw_f2u(p) != gfw_f2u(q) && !(p != p && q != q)) local++;
+        }
+    }
+    if (local) atomicAdd(bad, local);
+}
+hipError_t gfw_launch_debug_selftest(int test, unsigned long long n, unsigned long long seed, unsigned long long *bad, hipStream_t s) {
+    hipLaunchKernelGGL(gfw_debug_selftest_kernel, dim3(256 * 8), dim3(256), 0, s, test, n, seed, bad);
     return hipGetLastError();
 }

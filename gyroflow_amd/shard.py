@@ -1,0 +1,59 @@
+"""Frame sharding across ranks (one process per GPU) — the control path of the multi-GPU run.
+
+Frames of a clip are independent once clip-level state is fixed (frame_transform.rs:165), so the data path has no
+collective: rank r owns a contiguous-by-stride set of frame indices and its own resident buffers.  The only
+communication is a barrier either side of the timed region, a MAX reduction of the elapsed time and a reduction of
+per-rank output checksums (checksum of checksums).  Backend "nccl" is RCCL over xGMI on ROCm; tests run it on "gloo".
+"""
+import os
+
+import torch
+
+
+def env_rank():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def frames_for_rank(rank, world, total_frames):
+    """Round-robin frame ownership: rank r handles frames r, r+world, ...."""
+    return range(rank, total_frames, world)
+
+
+def init(backend, rank, world, device=None):
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    kw = {}
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = device
+    dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return dist
+
+
+def barrier(dist):
+    if dist is not None:
+        dist.barrier()
+
+
+def reduce_max(dist, value, device="cpu"):
+    if dist is None:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def reduce_checksum(dist, crc, device="cpu"):
+    """Order-independent combination of the per-rank CRC32s: sum modulo 2^63."""
+    if dist is None:
+        return int(crc)
+    t = torch.tensor([int(crc)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def finish(dist):
+    if dist is not None:
+        dist.destroy_process_group()

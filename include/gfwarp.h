@@ -272,6 +272,16 @@ int   gfw_get_profile(gfw_ctx *ctx, double *kernel_ms, int64_t *launches, int re
 /* Thread-local, human-readable description of the last failure. */
 const char *gfw_last_error(void);
 
+/* ---- test hooks (used by tests/test_gpu_math.py; not part of the operator surface) ---------------
+ * gfw_debug_math: out[i] = f(a[i], b[i]) evaluated ON THE DEVICE with the kernels' own routines; host arrays.
+ *   op 0 gfw_atanf  1 gfw_tanf  2 gfw_atanf_pos  3 lean a/b  4 generic a/b  5 lean sqrt  6 generic sqrt
+ *      7 (float)(i32)`as i32`  8 (float)`as u16`  9 round-half-away  10 (float)`as u8`
+ * gfw_debug_selftest: compares a lean routine with its generic twin on `n` device-generated operands
+ *   (test 0: divide, operands in the proven range; 1: sqrt; 2: atanf_pos vs atanf over ALL non-negative floats
+ *   when n == 0) and returns the number of mismatching results (0 expected), or a negative GFW_ERR_*. */
+int   gfw_debug_math(int op, const float *a, const float *b, float *out, size_t n);
+long long gfw_debug_selftest(int test, unsigned long long n, unsigned long long seed);
+
 /* Static tables the reference exposes through PixelType (pixel_formats.rs):
  * bytes per pixel, element count, default_max_value (0 => None). */
 int   gfw_pixel_type_info(int pixel_type, int *bytes_per_pixel,

@@ -5,7 +5,7 @@
  *
  *   src/core/stabilization/cpu_undistort.rs:133-228   Stabilization::rotate_and_distort
  *   src/core/stabilization/cpu_undistort.rs:233-633   Stabilization::undistort_image_cpu::<I,T>
- *   src/core/stabilization/distortion_models/*.rs     distort_point / undistort_point (14 models)
+  *   src/core/stabilization/distortion_models/<model>.rs    distort_point / undistort_point (14 models)
  *   src/core/stabilization/pixel_formats.rs           PixelType::to_float / from_float
  *   src/core/util.rs:144-147                          map_coord
  *   src/core/gyro_source/splines.rs:88-177, sony.rs:557-563   interpolate_mesh

@@ -1,0 +1,93 @@
+"""The C-ABI library loads on a CPU-only box, exports every symbol of include/gfwarp.h, and fails loudly (no CPU
+fallback) when there is no GPU.  No compute calls are made here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gyroflow_amd import abi, synthetic as S, warp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "gfwarp.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gfw_[a-z_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = abi.load_library()
+    names = header_functions()
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(abi.EXPORTS) == names
+
+
+def test_struct_layouts():
+    assert C.sizeof(abi.KernelParams) == 368
+    kp = abi.KernelParams
+    assert kp.background.offset == 48 and kp.k.offset == 80 and kp.translation2d.offset == 168
+    assert kp.source_rect.offset == 192 and kp.digital_lens_params.offset == 224 and kp.max_pixel_value.offset == 304
+    assert kp.plane_index.offset == 324 and kp.ewa_coeffs_p.offset == 336
+    assert abi.load_library().gfw_abi_version() == 1
+
+
+def test_pixel_type_table_matches_reference_pixel_formats():
+    lib = abi.load_library()
+    for name, (pid, dt, count, dmax) in abi.PIXEL_TYPES.items():
+        bpp, n, mx = C.c_int(), C.c_int(), C.c_float()
+        assert lib.gfw_pixel_type_info(pid, C.byref(bpp), C.byref(n), C.byref(mx)) == 0
+        assert bpp.value == np.dtype(dt).itemsize * count and n.value == count
+        assert mx.value == (dmax or 0.0)
+    assert lib.gfw_pixel_type_info(99, None, None, None) < 0
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_have_gpu(), reason="checks the no-device behaviour")
+def test_no_device_means_loud_failure_not_cpu_fallback():
+    lib = abi.load_library()
+    buf = C.create_string_buffer(256)
+    assert lib.gfw_list_devices(buf, 256) == -10                      # GFW_ERR_NO_DEVICE
+    assert lib.gfw_set_device(0) == -10
+    fr = S.SyntheticFrame("NV12", 64, 32, seed=1)
+    pl = fr.planes[0]
+    dst = pl["dst"].copy()
+    b = warp.host_buffers(pl["src"], pl["size"], dst, pl["out_size"])
+    with pytest.raises(warp.GfwError) as e:
+        warp.Backend(pl["params"], pl["pixel_type"], fr.model, fr.digital, b)
+    assert "no HIP device" in str(e.value)
+    assert np.all(dst == pl["dst"])                                    # nothing was computed
+
+
+def test_create_rejects_bad_arguments_before_touching_the_device():
+    lib = abi.load_library()
+    fr = S.SyntheticFrame("NV12", 64, 32, seed=1)
+    pl = fr.planes[0]
+    b = warp.host_buffers(pl["src"], pl["size"], pl["dst"].copy(), pl["out_size"])
+    assert not lib.gfw_create(C.byref(pl["params"]), 99, 1, 0, C.byref(b), 0)
+    assert b"pixel type" in lib.gfw_last_error()
+    assert not lib.gfw_create(C.byref(pl["params"]), 0, 0, 0, C.byref(b), 0)       # model None is not a lens
+    assert not lib.gfw_create(C.byref(pl["params"]), 1, 1, 0, C.byref(b), 0)       # bytes_per_pixel mismatch (Luma16 vs 1)
+    small = pl["params"].copy()
+    small.height = 3
+    assert not lib.gfw_create(C.byref(small), 0, 1, 0, C.byref(b), 0)              # opencl.rs:179
+    assert lib.gfw_is_buffer_supported(C.byref(b)) == 1
+    b.input.kind = abi.BUF_NONE
+    assert lib.gfw_is_buffer_supported(C.byref(b)) == 0
+
+
+def test_missing_library_raises(tmp_path):
+    with pytest.raises(RuntimeError) as e:
+        abi.load_library(str(tmp_path / "nope.so"))
+    assert "no CPU fallback" in str(e.value)

@@ -1,0 +1,40 @@
+"""gfw_math.h (the fixed-op-sequence atanf/tanf every kernel uses) vs this box's libm, exhaustively.
+
+The header is compiled for the host with gcc -ffp-contract=off and compared with glibc's atanf/tanf on ALL 2^32
+float bit patterns (OpenMP; ~25 s on 8 cores).  The reference (Rust std on linux-gnu) calls exactly these libm
+routines (opencv_fisheye.rs:56,79; gopro.rs:52,67), so equality here is what makes the oracle's `libm` arithmetic and
+the device's arithmetic the same function.
+"""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SRC = r"""
+#include <math.h>
+#include <stdio.h>
+#include <stdint.h>
+#include "%s/gyroflow_amd/csrc/gfw_math.h"
+int main(void) {
+    long bad_atan = 0, bad_tan = 0;
+    #pragma omp parallel for reduction(+:bad_atan,bad_tan) schedule(static)
+    for (long i = 0; i < (1L << 32); ++i) {
+        const uint32_t u = (uint32_t)i; const float x = gfw_u2f(u);
+        const float a = atanf(x), b = gfw_atanf(x);
+        if (gfw_f2u(a) != gfw_f2u(b) && !(a != a && b != b)) bad_atan++;
+        const float c = tanf(x), d = gfw_tanf(x);
+        if (gfw_f2u(c) != gfw_f2u(d) && !(c != c && d != d)) bad_tan++;
+    }
+    printf("%%ld %%ld\n", bad_atan, bad_tan);
+    return 0;
+}
+"""
+
+
+def test_atanf_tanf_bit_identical_to_libm_on_all_inputs(tmp_path):
+    c = tmp_path / "m.c"
+    c.write_text(SRC % ROOT)
+    exe = tmp_path / "m"
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fno-fast-math", str(c), "-o", str(exe), "-lm"])
+    out = subprocess.check_output([str(exe)], timeout=900).decode().split()
+    assert out == ["0", "0"], "mismatches vs libm: atanf %s, tanf %s" % tuple(out)
