@@ -73,6 +73,9 @@ struct gfw_ctx {
     DevBuf d_matrices, d_matrices_raw, d_mesh;
     float *h_matrices = nullptr; size_t h_matrices_cap = 0;   // pinned repack staging
     const char *last_backend = "";
+    // certified first pass of the fused kernel: s(rho) table cache
+    DevBuf d_p1_table, d_audit;
+    float p1_k[4] = {0, 0, 0, 0}; float p1_rho_max = 0.0f; double p1_etab = 0.0; double p1_smax = 1.0; bool p1_valid = false;
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;   // recorded, not yet harvested
     size_t ev_used = 0;
@@ -207,7 +210,7 @@ void gfw_destroy(gfw_ctx *c) {
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &b : c->stage_src) b.release();
     for (auto &b : c->stage_dst) b.release();
-    c->d_matrices.release(); c->d_matrices_raw.release(); c->d_mesh.release();
+    c->d_matrices.release(); c->d_matrices_raw.release(); c->d_mesh.release(); c->d_p1_table.release(); c->d_audit.release();
     if (c->h_matrices) (void)hipHostFree(c->h_matrices);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -236,6 +239,17 @@ int gfw_synchronize(gfw_ctx *c) {
     return GFW_OK;
 }
 const char *gfw_last_backend(gfw_ctx *c) { return c ? c->last_backend : ""; }
+int gfw_get_audit(gfw_ctx *c, unsigned long long *counters4, int reset) {
+    if (!c || !counters4) return GFW_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
+    const bool fresh = c->d_audit.cap == 0;
+    HIP_TRY(c->d_audit.ensure(4 * sizeof(unsigned long long)), GFW_ERR_HIP);
+    if (fresh) HIP_TRY(hipMemsetAsync(c->d_audit.ptr, 0, 4 * sizeof(unsigned long long), c->stream), GFW_ERR_HIP);
+    HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
+    HIP_TRY(hipMemcpy(counters4, c->d_audit.ptr, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost), GFW_ERR_HIP);
+    if (reset) HIP_TRY(hipMemset(c->d_audit.ptr, 0, 4 * sizeof(unsigned long long)), GFW_ERR_HIP);
+    return GFW_OK;
+}
 int gfw_get_profile(gfw_ctx *c, double *kernel_ms, int64_t *launches, int reset) {
     if (!c) return GFW_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
@@ -352,11 +366,92 @@ static bool int_products_exact(int n_max, int n) {
     return (int64_t)(n_max - 1) * odd < (1 << 24);
 }
 
+// s(rho) = theta_d(atan(r)) / r with r = sqrt(rho) (opencv_fisheye.rs:72-95), tabulated for the certified first pass.
+static double p1_s_of_rho(double rho, const float *k) {
+    const double r = sqrt(rho);
+    if (r == 0.0) return 1.0;
+    const double t = atan(r), t2 = t * t;
+    return t * (1.0 + t2 * ((double)k[0] + t2 * ((double)k[1] + t2 * ((double)k[2] + t2 * (double)k[3])))) / r;
+}
+static int p1_prepare_table(gfw_ctx *c, const gfw_kernel_params &p, float rho_max) {
+    if (c->p1_valid && memcmp(c->p1_k, p.k, sizeof(c->p1_k)) == 0 && rho_max <= c->p1_rho_max && rho_max >= 0.5f * c->p1_rho_max) return GFW_OK;
+    const int N = GFW_P1_TABLE_N;
+    std::vector<float2> tab(N + 1);
+    const double h = (double)rho_max / N;
+    double etab = 0.0, smax = 0.0;
+    double s_prev = p1_s_of_rho(0.0, p.k);
+    for (int i = 0; i < N; ++i) {
+        const double s_next = p1_s_of_rho((i + 1) * h, p.k);
+        tab[i] = float2{(float)s_prev, (float)(s_next - s_prev)};
+        // interpolation error at the quarter points of the interval, against the float entries actually stored
+        for (int q = 1; q < 4; ++q) {
+            const double fr = q / 4.0;
+            const double lerp = (double)tab[i].x + fr * (double)tab[i].y;
+            etab = fmax(etab, fabs(lerp - p1_s_of_rho((i + fr) * h, p.k)));
+        }
+        smax = fmax(smax, fmax(fabs(s_prev), fabs(s_next)));
+        s_prev = s_next;
+    }
+    tab[N] = float2{(float)s_prev, 0.0f};
+    if (!(etab == etab) || !(smax == smax)) { c->p1_valid = false; return GFW_OK; }
+    HIP_TRY(c->d_p1_table.ensure((N + 1) * sizeof(float2)), GFW_ERR_HIP);
+    HIP_TRY(hipMemcpyAsync(c->d_p1_table.ptr, tab.data(), (N + 1) * sizeof(float2), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
+    HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);      // `tab` is a stack-lifetime source
+    memcpy(c->p1_k, p.k, sizeof(c->p1_k));
+    c->p1_rho_max = rho_max; c->p1_etab = etab; c->p1_smax = smax; c->p1_valid = true;
+    return GFW_OK;
+}
+// Fill the first-pass fields of the fused kernel's arguments; returns true when the certified pass may be used.
+static bool p1_setup(gfw_ctx *c, const gfw_kernel_params &p0, const float *h_matrices, int matrix_count, GfwYuvArgs &Y) {
+    Y.p1_table = nullptr; Y.audit = nullptr;
+    if (c->kernel_variant == 2) return false;                   // forced exact first pass (tests / A-B benchmarking)
+    if (c->model != GFW_MODEL_OPENCV_FISHEYE || matrix_count <= 1 || Y.hstretch_div || Y.vstretch_div) return false;
+    const bool hrs = (p0.flags & GFW_FLAG_HORIZONTAL_RS) != 0;
+    // rho range over the output frame under the mid-row matrix (corners + edge midpoints), in double
+    double rho_max = 0.0;
+    if (h_matrices) {
+        const float *m = h_matrices + (size_t)(matrix_count >> 1) * 14;
+        const double xs[3] = {0.0, p0.output_width * 0.5, (double)p0.output_width}, ys[3] = {0.0, p0.output_height * 0.5, (double)p0.output_height};
+        for (double y : ys) for (double x : xs) {
+            const double ox = x + p0.translation2d[0], oy = y + p0.translation2d[1];
+            const double X = ox * m[0] + oy * m[1] + m[2], Yy = ox * m[3] + oy * m[4] + m[5], W = ox * m[6] + oy * m[7] + m[8];
+            if (!(W > 0.05)) { rho_max = 1e9; continue; }
+            rho_max = fmax(rho_max, (X * X + Yy * Yy) / (W * W));
+        }
+        rho_max = rho_max * 1.25 + 0.01;
+    } else {
+        rho_max = 16.0;                                         // device-resident matrices: no host view of the geometry
+    }
+    if (!(rho_max == rho_max)) return false;
+    if (rho_max > 64.0) rho_max = 64.0;
+    if (!(c->p1_valid && memcmp(c->p1_k, p0.k, sizeof(c->p1_k)) == 0 && rho_max <= c->p1_rho_max && rho_max >= 0.5 * c->p1_rho_max))
+        rho_max = fmin(rho_max * 1.15, 64.0);                   // head-room so that frame-to-frame motion does not rebuild the table
+    if (p1_prepare_table(c, p0, (float)rho_max) != GFW_OK || !c->p1_valid) return false;
+    const double f = fabs((double)(hrs ? p0.f[0] : p0.f[1])), cc = fabs((double)(hrs ? p0.c[0] : p0.c[1]));
+    const double rmax = sqrt((double)c->p1_rho_max);
+    const double vmag = f * rmax * c->p1_smax + cc;
+    // bound on |approx - exact|: ~12 roundings of relative size 2^-24 on each path, taken 4x,
+    // plus the table's interpolation error carried through f*b, taken 2x, plus an absolute floor.
+    const double eps = 4.0 * 1.2e-6 * vmag + 2.0 * f * rmax * c->p1_etab + 1.0 / 4096.0;
+    if (!(eps < 0.2)) return false;                             // certificate would reject most pixels: use the exact pass
+    Y.p1_table = (const float2 *)c->d_p1_table.ptr;
+    Y.p1_rho_max = c->p1_rho_max; Y.p1_rho_scale = (float)(GFW_P1_TABLE_N / (double)c->p1_rho_max);
+    Y.p1_eps = (float)eps;
+    Y.p1_f = hrs ? p0.f[0] : p0.f[1]; Y.p1_c = hrs ? p0.c[0] : p0.c[1];
+    if (c->kernel_variant == 3) {                               // audit mode: count certificates and check each one
+        const bool fresh = c->d_audit.cap == 0;
+        if (c->d_audit.ensure(4 * sizeof(unsigned long long)) != hipSuccess) return false;
+        if (fresh) (void)hipMemsetAsync(c->d_audit.ptr, 0, 4 * sizeof(unsigned long long), c->stream);
+        Y.audit = (unsigned long long *)c->d_audit.ptr;
+    }
+    return true;
+}
+
 // Decide whether the frame qualifies for the fused YUV kernel and, if so, build its argument block.
 // Anything not proven here runs through the generic per-plane kernel (same results, slower).
 static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params, const int *pixel_types,
                            const std::vector<GfwPlane> &launches, const float *h_matrices, int matrix_count, size_t mesh_len,
-                           GfwYuvArgs &Y, int &bytes_per_sample, int &dw, int &dh, bool &interleaved) {
+                           GfwYuvArgs &Y, int &bytes_per_sample, int &dw, int &dh, bool &interleaved, bool &fast1) {
     if (c->kernel_variant == 1) return false;                       // forced generic (tests / A-B benchmarking)
     if (nplanes < 1 || nplanes > 4 || mesh_len != 0) return false;
     const gfw_kernel_params &p0 = params[0];
@@ -441,7 +536,6 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     Y.width = p0.width; Y.height = p0.height;
     Y.out_w = p0.output_width; Y.out_h = p0.output_height;
     Y.cw = (p0.output_width + dw - 1) / dw; Y.ch = (p0.output_height + dh - 1) / dh;
-    Y.tiles_x = (Y.cw + 63) / 64; Y.tiles_y = (Y.ch + 3) / 4;
     Y.matrix_count = matrix_count;
     Y.hrs = (p0.flags & GFW_FLAG_HORIZONTAL_RS) ? 1 : 0;
     Y.model = c->model;
@@ -459,6 +553,9 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
         Y.map_cy = GfwMapConst{(float)planes[1].input.height, Hf, 1.0f / Hf};
     }
     Y.kp = p0;
+    fast1 = p1_setup(c, p0, h_matrices, matrix_count, Y);
+    const int rb = gfw_yuv_rows_per_lane(fast1);
+    Y.tiles_x = (Y.cw + 63) / 64; Y.tiles_y = (Y.ch + 4 * rb - 1) / (4 * rb);
     return true;
 }
 
@@ -510,15 +607,15 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
 
     GfwCommon C;
     GfwYuvArgs Y;
-    int bps = 0, dw = 1, dh = 1; bool interleaved = false;
+    int bps = 0, dw = 1, dh = 1; bool interleaved = false, fast1 = false;
     const bool fused = build_yuv_args(c, nplanes, planes, params, pixel_types, launches, c->matrices_on_device ? nullptr : matrices,
-                                      matrix_count, mesh_len, Y, bps, dw, dh, interleaved);
+                                      matrix_count, mesh_len, Y, bps, dw, dh, interleaved, fast1);
     prof_begin(c);
     if (fused) {
         fill_common(c, &params[0], d_mat, nullptr, 0, Y.common);
         Y.matrices = d_mat;
-        HIP_TRY(gfw_launch_yuv(Y, bps, dw, dh, interleaved, c->stream), GFW_ERR_HIP);
-        c->last_backend = "yuv_fused";
+        HIP_TRY(gfw_launch_yuv(Y, bps, dw, dh, interleaved, fast1, c->stream), GFW_ERR_HIP);
+        c->last_backend = fast1 ? "yuv_fused_p1" : "yuv_fused";
     } else {
         for (int i = 0; i < nplanes; ++i) {
             fill_common(c, &params[i], d_mat, d_mesh, (int)mesh_len, C);

@@ -14,6 +14,10 @@ struct GfwYuvPlane {
     int32_t pad_;
 };
 
+#define GFW_P1_TABLE_N 1024      // intervals of the first-pass s(rho) table
+#define GFW_YUV_RB_FAST 4         // luma block rows per lane with the certified first pass (tile = 64 x 16 lanes-rows)
+#define GFW_YUV_RB_EXACT 1
+
 struct GfwYuvArgs {
     GfwYuvPlane pl[4];
     const float *matrices;            // [matrix_count][GFW_MAT_STRIDE]
@@ -32,8 +36,15 @@ struct GfwYuvArgs {
     float t2[2];
     float r_limit_sq;
     GfwMapConst map_lx, map_ly, map_cx, map_cy;
+    // certified first pass (gfw_frame.hip): table of (s_i, s_{i+1}-s_i) over rho in [0, rho_max], certificate half-width
+    const float2 *p1_table;
+    float p1_rho_max, p1_rho_scale;   // scale = N / rho_max
+    float p1_eps;                     // E: bound on |approx - exact| of the projected row/column coordinate, pixels
+    float p1_f, p1_c;                 // f[1], c[1] (f[0], c[0] for horizontal rolling shutter)
+    unsigned long long *audit;        // nullptr, or 4 counters: certified, certified-but-wrong, queued, queue-overflow
     gfw_kernel_params kp;             // plane-0 params, for the non-specialised lens models
     GfwCommon common;
 };
 
-hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int bytes_per_sample, int dw, int dh, bool interleaved, hipStream_t s);
+int gfw_yuv_rows_per_lane(bool fast1);
+hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int bytes_per_sample, int dw, int dh, bool interleaved, bool fast1, hipStream_t s);

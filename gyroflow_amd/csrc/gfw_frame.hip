@@ -158,51 +158,168 @@ store:
     for (int c = 0; c < N; ++c) dst[c] = (T)gfw_f2u_sat(out[c], sizeof(T) == 1 ? 255.0f : 65535.0f);
 }
 
-template <int MODEL, typename T, int DW, int DH, bool INTERLEAVED_UV>
+// ---- first pass (rolling-shutter row pick) -----------------------------------------------------------------
+// The mid-row projection of undistort_coord (cpu_undistort.rs:470-479) is used for ONE thing: the integer
+// sy = clamp(round(p.y)).  FAST1 evaluates p.y with fused arithmetic and a per-lens table of
+// s(rho) = theta_d(atan(sqrt(rho)))/sqrt(rho) (linear interpolation, rho = (X/W)^2 + (Y/W)^2) and accepts the
+// rounded value only when no half-integer lies within +-E of it, E bounding |approx - exact| (derivation in
+// DESIGN.md section 2; tests/test_gpu_pass1.py measures the real gap).  Everything else — a few percent of the
+// pixels — goes through the exact projection: queued in LDS and processed densely by the whole workgroup, so
+// the exact path costs one wave-pass per tile instead of one per wave.
+#define GFW_QCAP 256
+struct Pass1 { float X, Y, W; };
+
+template <int MODEL, bool FAST1>
+__device__ __forceinline__ int pass1_default_row(float ox, float oy, const GfwYuvArgs &A) {
+    const int lim = A.hrs ? A.width : A.height;
+    const int sy = gfw_f2i(roundf(A.hrs ? ox : oy));
+    return max(min(sy, lim), 0);
+}
+// exact: cpu_undistort.rs:470-479
+template <int MODEL>
+__device__ __forceinline__ int pass1_exact(float ox, float oy, const GfwYuvArgs &A) {
+    int sy = pass1_default_row<MODEL, false>(ox, oy, A);
+    const GfwPt pt = rd<MODEL>(ox, oy, A.matrix_count >> 1, A);
+    if (pt.ok) { const int lim = A.hrs ? A.width : A.height; sy = gfw_f2i(roundf(A.hrs ? pt.x : pt.y)); sy = max(min(sy, lim), 0); }
+    return sy;
+}
+// approximate + certificate; returns false when the exact path must decide
+__device__ __forceinline__ bool pass1_fast(float ox, float oy, const GfwYuvArgs &A, const float *mid, const float2 *tab, int &sy) {
+    // X, Y, W with fused multiply-adds (|error| ~ 1e-7 relative to the term magnitudes)
+    const float X = __builtin_fmaf(ox, mid[0], __builtin_fmaf(oy, mid[1], mid[2]));
+    const float Y = __builtin_fmaf(ox, mid[3], __builtin_fmaf(oy, mid[4], mid[5]));
+    const float W = __builtin_fmaf(ox, mid[6], __builtin_fmaf(oy, mid[7], mid[8]));
+    if (!(W > 0.0009765625f)) return false;                        // W not safely positive: exact path decides validity
+    const float rw = gfw_hw_rcp(W);
+    const float a = X * rw, b = Y * rw;
+    const float rho = __builtin_fmaf(a, a, b * b);
+    if (!(rho < A.p1_rho_max)) return false;                       // outside the table (or NaN)
+    if (A.r_limit_sq > 0.0f) {                                     // :139 — decide only when clear of the boundary
+        const float lhs = __builtin_fmaf(X, X, Y * Y), rhs = A.r_limit_sq * W;
+        if (!(lhs < rhs * 0.9999f)) return false;
+    }
+    const float tpos = rho * A.p1_rho_scale;
+    const float ti = floorf(tpos);
+    const float2 e = tab[(int)ti];
+    const float s = __builtin_fmaf(tpos - ti, e.y, e.x);
+    const float v = __builtin_fmaf((A.hrs ? a : b) * s, A.p1_f, A.p1_c);
+    const float g = v - 0.5f;
+    const float dist = fabsf(g - rintf(g));                        // distance of v to the nearest half-integer
+    const float lim = (float)(A.hrs ? A.width : A.height);
+    const bool inside = v > -0.25f && v < lim + 0.25f;             // outside, the clamp decides and ties cannot matter
+    if (inside && !(dist > A.p1_eps)) return false;
+    sy = max(min(gfw_f2i(rintf(v)), (int)lim), 0);
+    return true;
+}
+
+template <int MODEL, typename T, int DW, int DH, bool INTERLEAVED_UV, int RB, bool FAST1>
 __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
-    // tile = 64 threads x 4 rows of threads; each thread owns DW x DH luma pixels
+    // tile = 64 x 4 lanes, each lane owns RB vertically stacked DW x DH luma blocks (+ their chroma sites)
+    __shared__ float2 s_tab[FAST1 ? GFW_P1_TABLE_N + 1 : 1];
+    __shared__ float q_x[FAST1 ? GFW_QCAP : 1], q_y[FAST1 ? GFW_QCAP : 1];
+    __shared__ int q_sy[FAST1 ? GFW_QCAP : 1];
+    __shared__ unsigned q_n;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const bool two_pass = A.matrix_count > 1;
+    if (FAST1 && two_pass) {
+        for (int i = tid; i <= GFW_P1_TABLE_N; i += 256) s_tab[i] = A.p1_table[i];
+        if (tid == 0) q_n = 0;
+        __syncthreads();
+    }
     const int tiles_x = A.tiles_x;
     const int b = blockIdx.x;
     const int n = tiles_x * A.tiles_y;
     const int per = (n + 7) >> 3;
     const int t = (b & 7) * per + (b >> 3);          // XCD-banded tile order (workgroup b runs on XCD b % 8)
-    if (t >= n) return;
-    const int ty = t / tiles_x, tx = t - ty * tiles_x;
-    const int cx = tx * 64 + threadIdx.x, cy = ty * 4 + threadIdx.y;      // chroma-site / thread coordinates
-    if (cx >= A.cw || cy >= A.ch) return;
+    const bool tile_ok = t < n;
+    const int ty = tile_ok ? t / tiles_x : 0, tx = tile_ok ? t - ty * tiles_x : 0;
+    const int cx = tx * 64 + threadIdx.x;
+    const int cy0 = (ty * 4 + threadIdx.y) * RB;     // first chroma-site row of this lane
+    const bool lane_ok = tile_ok && cx < A.cw;
 
-    float u0 = 0.0f, v0 = 0.0f; bool ok0 = false;
-    #pragma unroll
-    for (int j = 0; j < DH; ++j) {
+    // ---- phase 1: rolling-shutter row of every luma pixel of this lane --------------------------------
+    int rows[RB][DH][DW];
+    if (two_pass) {
+        const float *mid = A.matrices + (size_t)(A.matrix_count >> 1) * GFW_MAT_STRIDE;   // wave-uniform -> scalar loads
         #pragma unroll
-        for (int i = 0; i < DW; ++i) {
-            const int lx = cx * DW + i, ly = cy * DH + j;
-            if (lx >= A.out_w || ly >= A.out_h) continue;
-            const GfwPt p = coord<MODEL>((float)lx, (float)ly, A);
-            if (i == 0 && j == 0) { u0 = p.x; v0 = p.y; ok0 = p.ok; }
-            // luma: source_rect map (cpu_undistort.rs:511-514) then taps
-            const float lu = gfw_map_const(p.x, A.map_lx), lv = gfw_map_const(p.y, A.map_ly);
-            sample_store<T, 1>(lu, lv, A.pl[0], lx, ly, p.ok);
+        for (int r = 0; r < RB; ++r) {
+            #pragma unroll
+            for (int j = 0; j < DH; ++j) {
+                #pragma unroll
+                for (int i = 0; i < DW; ++i) {
+                    const int lx = cx * DW + i, ly = (cy0 + r) * DH + j;
+                    int sy = 0;
+                    if (lane_ok && lx < A.out_w && ly < A.out_h) {
+                        const float ox = (float)lx + A.t2[0], oy = (float)ly + A.t2[1];
+                        if (FAST1) {
+                            if (!pass1_fast(ox, oy, A, mid, s_tab, sy)) {
+                                const unsigned slot = atomicAdd(&q_n, 1u);
+                                if (slot < GFW_QCAP) { q_x[slot] = ox; q_y[slot] = oy; sy = -1 - (int)slot; }
+                                else sy = pass1_exact<MODEL>(ox, oy, A);          // queue full: decide inline
+                                if (A.audit) atomicAdd(&A.audit[slot < GFW_QCAP ? 2 : 3], 1ull);
+                            } else if (A.audit) {                                 // audit mode: every certificate is checked
+                                atomicAdd(&A.audit[0], 1ull);
+                                if (pass1_exact<MODEL>(ox, oy, A) != sy) atomicAdd(&A.audit[1], 1ull);
+                            }
+                        } else {
+                            sy = pass1_exact<MODEL>(ox, oy, A);
+                        }
+                    }
+                    rows[r][j][i] = sy;
+                }
+            }
+        }
+        if (FAST1) {
+            // ---- phase 2: the workgroup resolves the queued pixels exactly, densely packed ---------------
+            __syncthreads();
+            const unsigned qn = min(q_n, (unsigned)GFW_QCAP);
+            for (unsigned e = tid; e < qn; e += 256) q_sy[e] = pass1_exact<MODEL>(q_x[e], q_y[e], A);
+            __syncthreads();
         }
     }
-    if (A.nplanes > 1) {
-        const float cu = gfw_map_const(u0, A.map_cx), cv = gfw_map_const(v0, A.map_cy);
-        if (INTERLEAVED_UV) {
-            sample_store<T, 2>(cu, cv, A.pl[1], cx, cy, ok0);
-        } else {
-            sample_store<T, 1>(cu, cv, A.pl[1], cx, cy, ok0);
-            if (A.nplanes > 2) sample_store<T, 1>(cu, cv, A.pl[2], cx, cy, ok0);
-            if (A.nplanes > 3) sample_store<T, 1>(cu, cv, A.pl[3], cx, cy, ok0);
+    if (!lane_ok) return;
+
+    // ---- phase 3: exact projection with the row's own matrix, then taps -------------------------------
+    #pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int cy = cy0 + r;
+        if (cy >= A.ch) break;
+        float u0 = 0.0f, v0 = 0.0f; bool ok0 = false;
+        #pragma unroll
+        for (int j = 0; j < DH; ++j) {
+            #pragma unroll
+            for (int i = 0; i < DW; ++i) {
+                const int lx = cx * DW + i, ly = cy * DH + j;
+                if (lx >= A.out_w || ly >= A.out_h) continue;
+                const float ox = (float)lx + A.t2[0], oy = (float)ly + A.t2[1];
+                int sy;
+                if (two_pass) { sy = rows[r][j][i]; if (FAST1 && sy < 0) sy = q_sy[-1 - sy]; }
+                else sy = pass1_default_row<MODEL, false>(ox, oy, A);
+                const GfwPt p = rd<MODEL>(ox, oy, min(sy, A.matrix_count - 1), A);
+                if (i == 0 && j == 0) { u0 = p.x; v0 = p.y; ok0 = p.ok; }
+                const float lu = gfw_map_const(p.x, A.map_lx), lv = gfw_map_const(p.y, A.map_ly);   // cpu_undistort.rs:511-514
+                sample_store<T, 1>(lu, lv, A.pl[0], lx, ly, p.ok);
+            }
+        }
+        if (A.nplanes > 1) {
+            const float cu = gfw_map_const(u0, A.map_cx), cv = gfw_map_const(v0, A.map_cy);
+            if (INTERLEAVED_UV) {
+                sample_store<T, 2>(cu, cv, A.pl[1], cx, cy, ok0);
+            } else {
+                sample_store<T, 1>(cu, cv, A.pl[1], cx, cy, ok0);
+                if (A.nplanes > 2) sample_store<T, 1>(cu, cv, A.pl[2], cx, cy, ok0);
+                if (A.nplanes > 3) sample_store<T, 1>(cu, cv, A.pl[3], cx, cy, ok0);
+            }
         }
     }
 }
 
-template <int MODEL, typename T>
+template <int MODEL, typename T, int RB, bool FAST1>
 hipError_t launch_mt(const GfwYuvArgs &A, int dw, int dh, bool interleaved, hipStream_t s) {
     const int grid = (((A.tiles_x * A.tiles_y) + 7) >> 3) << 3;
     if (grid <= 0) return hipSuccess;
     dim3 block(64, 4);
-#define GFW_YUV_LAUNCH(DW, DH, IL) hipLaunchKernelGGL((gfw_yuv_kernel<MODEL, T, DW, DH, IL>), dim3(grid), block, 0, s, A)
+#define GFW_YUV_LAUNCH(DW, DH, IL) hipLaunchKernelGGL((gfw_yuv_kernel<MODEL, T, DW, DH, IL, RB, FAST1>), dim3(grid), block, 0, s, A)
     if (dw == 2 && dh == 1 && !interleaved) GFW_YUV_LAUNCH(2, 1, false);
     else if (dw == 2 && dh == 1 && interleaved) GFW_YUV_LAUNCH(2, 1, true);
     else if (dw == 2 && dh == 2 && !interleaved) GFW_YUV_LAUNCH(2, 2, false);
@@ -216,11 +333,16 @@ hipError_t launch_mt(const GfwYuvArgs &A, int dw, int dh, bool interleaved, hipS
 
 }  // namespace
 
-hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int bytes_per_sample, int dw, int dh, bool interleaved, hipStream_t s) {
+int gfw_yuv_rows_per_lane(bool fast1) { return fast1 ? GFW_YUV_RB_FAST : GFW_YUV_RB_EXACT; }
+
+hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int bytes_per_sample, int dw, int dh, bool interleaved, bool fast1, hipStream_t s) {
     if (A.model == GFW_MODEL_OPENCV_FISHEYE) {
-        return bytes_per_sample == 1 ? launch_mt<GFW_MODEL_OPENCV_FISHEYE, uint8_t>(A, dw, dh, interleaved, s)
-                                     : launch_mt<GFW_MODEL_OPENCV_FISHEYE, uint16_t>(A, dw, dh, interleaved, s);
+        if (fast1)
+            return bytes_per_sample == 1 ? launch_mt<GFW_MODEL_OPENCV_FISHEYE, uint8_t, GFW_YUV_RB_FAST, true>(A, dw, dh, interleaved, s)
+                                         : launch_mt<GFW_MODEL_OPENCV_FISHEYE, uint16_t, GFW_YUV_RB_FAST, true>(A, dw, dh, interleaved, s);
+        return bytes_per_sample == 1 ? launch_mt<GFW_MODEL_OPENCV_FISHEYE, uint8_t, GFW_YUV_RB_EXACT, false>(A, dw, dh, interleaved, s)
+                                     : launch_mt<GFW_MODEL_OPENCV_FISHEYE, uint16_t, GFW_YUV_RB_EXACT, false>(A, dw, dh, interleaved, s);
     }
-    return bytes_per_sample == 1 ? launch_mt<-1, uint8_t>(A, dw, dh, interleaved, s)
-                                 : launch_mt<-1, uint16_t>(A, dw, dh, interleaved, s);
+    return bytes_per_sample == 1 ? launch_mt<-1, uint8_t, GFW_YUV_RB_EXACT, false>(A, dw, dh, interleaved, s)
+                                 : launch_mt<-1, uint16_t, GFW_YUV_RB_EXACT, false>(A, dw, dh, interleaved, s);
 }

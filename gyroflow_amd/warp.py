@@ -88,6 +88,12 @@ class Backend:
         self._check(self.lib.gfw_get_profile(self.ctx, C.byref(ms), C.byref(n), 1 if reset else 0))
         return ms.value, n.value
 
+    def get_audit(self, reset=False):
+        """First-pass audit counters: (certified, certified_but_wrong, queued, queue_overflow)."""
+        arr = (C.c_ulonglong * 4)()
+        self._check(self.lib.gfw_get_audit(self.ctx, C.byref(arr), 1 if reset else 0))
+        return tuple(int(v) for v in arr)
+
     def synchronize(self):
         self._check(self.lib.gfw_synchronize(self.ctx))
 
@@ -132,7 +138,7 @@ def run_plane(src, in_size, dst, out_size, params, pixel_type, model, digital, m
         be.close()
 
 
-def run_frame(frame, fused=True, per_plane=False):
+def run_frame(frame, fused=True, per_plane=False, variant=None):
     """Warp every plane of a ``synthetic.SyntheticFrame`` from HOST buffers; returns output copies.
 
     fused=False forces the generic per-plane kernel (GFW_OPT_KERNEL_VARIANT = 1); per_plane=True issues one
@@ -155,6 +161,8 @@ def run_frame(frame, fused=True, per_plane=False):
     try:
         if not fused:
             be.set_option(abi.OPT_KERNEL_VARIANT, 1)
+        elif variant is not None:
+            be.set_option(abi.OPT_KERNEL_VARIANT, variant)
         be.undistort_frame(bufs, params, types, frame.matrices)
     finally:
         be.close()

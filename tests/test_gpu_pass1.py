@@ -1,0 +1,67 @@
+"""Audit of the fused kernel's certified first pass (gfw_frame.hip): in audit mode the kernel recomputes the exact
+rolling-shutter row for EVERY pixel whose approximate row was accepted and counts disagreements — there must be none —
+and reports how many pixels were queued to the exact path."""
+import numpy as np
+import pytest
+
+from gyroflow_amd import abi, synthetic as S, warp
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def audit(fr):
+    outs = [pl["dst"].copy() for pl in fr.planes]
+    bufs = [warp.host_buffers(pl["src"], pl["size"], o, pl["out_size"]) for pl, o in zip(fr.planes, outs)]
+    params = [pl["params"] for pl in fr.planes]
+    types = [pl["pixel_type"] for pl in fr.planes]
+    be = warp.Backend(params[0], types[0], fr.model, fr.digital, bufs[0])
+    try:
+        be.set_option(abi.OPT_KERNEL_VARIANT, 3)
+        be.get_audit(reset=True)
+        be.undistort_frame(bufs, params, types, fr.matrices)
+        assert warp.last_backend() == "yuv_fused_p1"
+        return be.get_audit(), outs
+    finally:
+        be.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("size", [(640, 360), (1920, 1080)])
+def test_certificates_never_disagree_with_the_exact_row(seed, size):
+    fr = S.SyntheticFrame("YUV422P16LE", size[0], size[1], seed=seed, timestamp_ms=500.0 + 77.7 * seed, readout_ms=8.0 + 4.0 * seed)
+    (certified, wrong, queued, overflow), outs = audit(fr)
+    total = size[0] * size[1]
+    assert certified + queued + overflow == total
+    assert wrong == 0
+    assert queued + overflow < 0.15 * total, "certificate rejects too many pixels: %d of %d" % (queued + overflow, total)
+    ref = O.run_frame(fr)
+    for a, b in zip(ref, outs):
+        assert np.array_equal(a, b)
+
+
+def test_audit_4k_c2_and_wide_lens():
+    fr = S.SyntheticFrame("YUV422P16LE", 3840, 2160, seed=0x9F10)
+    (certified, wrong, queued, overflow), _ = audit(fr)
+    assert wrong == 0 and certified > 0.85 * 3840 * 2160
+    lens = S.gopro_style_lens(1280, 720)
+    lens["f"] = (0.33 * 1280, 0.33 * 1280)                      # much wider field of view: rho up to ~3.5
+    lens["k"] = [0.12, -0.04, 0.01, -0.002] + [0.0] * 8
+    fr = S.SyntheticFrame("NV12", 1280, 720, seed=8, lens=lens, fov=1.3)
+    (certified, wrong, queued, overflow), outs = audit(fr)
+    assert wrong == 0
+    ref = O.run_frame(fr)
+    for a, b in zip(ref, outs):
+        assert np.array_equal(a, b)
+
+
+def test_horizontal_rs_and_zoomed_out_audit():
+    fr = S.SyntheticFrame("YUV422P16LE", 640, 360, seed=4, horizontal_rs=True)
+    (certified, wrong, queued, overflow), _ = audit(fr)
+    assert wrong == 0 and certified > 0
+    fr = S.SyntheticFrame("YUV422P16LE", 640, 360, seed=17, fov=3.0)
+    (certified, wrong, queued, overflow), outs = audit(fr)
+    assert wrong == 0
+    ref = O.run_frame(fr)
+    for a, b in zip(ref, outs):
+        assert np.array_equal(a, b)
