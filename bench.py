@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--fmt", default=FMT)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--rows", type=int, default=0)
+    ap.add_argument("--grid", type=int, default=0)
     args = ap.parse_args()
 
     rank, local_rank, world = shard.env_rank()
@@ -79,6 +81,10 @@ def main():
     be.set_option(abi.OPT_SYNCHRONOUS, 0)
     if args.variant:
         be.set_option(abi.OPT_KERNEL_VARIANT, args.variant)
+    if args.rows:
+        be.set_option(abi.OPT_TUNE_ROWS, args.rows)
+    if args.grid:
+        be.set_option(abi.OPT_TUNE_GRID, args.grid)
 
     def step(k):
         i = k % N_DISTINCT

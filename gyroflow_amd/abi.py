@@ -98,7 +98,7 @@ ERRORS = {
     -9: "InvalidArgument", -10: "NoDevice", -11: "HipError", -100: "Unknown",
 }
 
-OPT_SYNCHRONOUS, OPT_MATRICES_ON_DEVICE, OPT_KERNEL_VARIANT, OPT_PROFILE = 1, 2, 3, 4
+OPT_SYNCHRONOUS, OPT_MATRICES_ON_DEVICE, OPT_KERNEL_VARIANT, OPT_PROFILE, OPT_TUNE_ROWS, OPT_TUNE_GRID = 1, 2, 3, 4, 5, 6
 
 _lib = None
 
@@ -124,7 +124,7 @@ def bind(lib):
     lib.gfw_synchronize.argtypes = [vp]; lib.gfw_synchronize.restype = i32
     lib.gfw_last_backend.argtypes = [vp]; lib.gfw_last_backend.restype = C.c_char_p
     lib.gfw_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]; lib.gfw_get_profile.restype = i32
-    lib.gfw_get_audit.argtypes = [vp, C.POINTER(C.c_ulonglong * 4), i32]; lib.gfw_get_audit.restype = i32
+    lib.gfw_get_audit.argtypes = [vp, C.POINTER(C.c_ulonglong * 8), i32]; lib.gfw_get_audit.restype = i32
     lib.gfw_debug_math.argtypes = [i32, vp, vp, vp, sz]; lib.gfw_debug_math.restype = i32
     lib.gfw_debug_selftest.argtypes = [i32, C.c_ulonglong, C.c_ulonglong]; lib.gfw_debug_selftest.restype = C.c_longlong
     lib.gfw_last_error.restype = C.c_char_p

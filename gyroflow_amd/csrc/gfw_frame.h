@@ -31,6 +31,8 @@ struct GfwYuvArgs {
     int32_t model;
     int32_t k_all_zero;               // k[0..3] all zero (opencv_fisheye.rs:75)
     int32_t hstretch_div, vstretch_div;
+    int32_t grid_limit;               // persistent workgroups to launch (0 = default)
+    int32_t ablate;                   // benchmark-only ablation bits (0 in production): 1 no first pass, 2 no luma taps, 4 no chroma, 8 no projection
     float hstretch, vstretch;
     float f[2], c[2], k[12];
     float t2[2];
@@ -41,10 +43,10 @@ struct GfwYuvArgs {
     float p1_rho_max, p1_rho_scale;   // scale = N / rho_max
     float p1_eps;                     // E: bound on |approx - exact| of the projected row/column coordinate, pixels
     float p1_f, p1_c;                 // f[1], c[1] (f[0], c[0] for horizontal rolling shutter)
-    unsigned long long *audit;        // nullptr, or 4 counters: certified, certified-but-wrong, queued, queue-overflow
+    unsigned long long *audit;        // nullptr, or 8 words: certified, certified-but-wrong, queued, queue-overflow, max |approx-exact| (f32 bits)
     gfw_kernel_params kp;             // plane-0 params, for the non-specialised lens models
     GfwCommon common;
 };
 
-int gfw_yuv_rows_per_lane(bool fast1);
-hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int bytes_per_sample, int dw, int dh, bool interleaved, bool fast1, hipStream_t s);
+int gfw_yuv_rows_per_lane(bool fast1, int tune_rb);
+hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int bytes_per_sample, int dw, int dh, bool interleaved, bool fast1, int rb, hipStream_t s);

@@ -4,10 +4,10 @@
 // coordinate of every chroma site from scratch although — with its own arithmetic — the chroma site (xc, yc)
 // of a plane subsampled by (DW, DH) evaluates `undistort_coord` at exactly the luma position (DW*xc, DH*yc):
 //   map_coord(xc, 0, ow/DW, 0, ow) = xc*ow/(ow/DW) = DW*xc       (exact in f32 when xc*ow is exact; checked on host)
-// So one thread owns a DW x DH block of luma pixels plus the chroma site that shares the block's top-left
-// coordinate: undistort_coord runs once per luma pixel and never for chroma (2x fewer evaluations for 4:2:2,
-// 1.5x for 4:2:0, 3x for 4:4:4), the U and V planes share one set of tap weights, and the per-plane
-// source_rect map (cpu_undistort.rs:511-514) is applied per plane with a validated divide-by-constant.
+// So one lane owns DW x DH luma pixels plus the chroma site that shares the block's top-left coordinate:
+// undistort_coord runs once per luma pixel and never for chroma (2x fewer evaluations for 4:2:2, 1.5x for
+// 4:2:0, 3x for 4:4:4), U and V share bins, weights and offsets, and the per-plane source_rect map
+// (cpu_undistort.rs:511-514) is a validated divide-by-constant.
 //
 // Arithmetic is the reference's operation sequence (cpu_undistort.rs:133-228, :421-517, :371-418,
 // opencv_fisheye.rs:72-95) with the range scaffolding of divide/sqrt removed (gfw_fastmath.h); operands outside
@@ -15,15 +15,37 @@
 // bit-identical to running gfw_plane_kernel once per plane; tests/test_gpu_parity.py checks both against the
 // oracle.
 //
+// Shape of the kernel (all of it driven by measurements in profiles/):
+//   * VALU-issue bound, so instruction count and code size are what matter: every code path exists once (row
+//     loop not unrolled), slow paths are side branches, uniform float parameters are pinned in VGPRs so that the
+//     SGPR file is left to pointers and control flow (the first version re-loaded kernel arguments and the mid
+//     matrix inside the pixel loop — s_load + s_waitcnt per pixel);
+//   * persistent workgroups: the grid is sized to the machine and each workgroup walks a band of tiles, so the
+//     ~5 us start-up of a wave (kernel-argument loads) is paid once, not once per tile;
+//   * XCD-banded tile order (workgroup b runs on XCD b % 8): an XCD's L2 sees a contiguous band of source lines.
+//
 // Eligibility (decided on the host, gfw_api.hip): bilinear, background_mode 0, no input rotation,
 // lens_correction_amount >= 1, no refraction / mesh / digital lens / IBIS terms / colour-range fix,
-// translation3d == 0, stretches in {<=0.001, 1}, full-plane rects, Luma8/Luma16 (+UV8/UV16) planes.
+// translation3d == 0, stretches in {<=0.001, 1}, full-plane rects, Luma8/Luma16 (+UV8/UV16) planes, chroma planes
+// of identical geometry.
 #include <hip/hip_runtime.h>
 #include "gfw_warp.h"
 #include "gfw_fastmath.h"
 #include "gfw_frame.h"
 
 namespace {
+
+// A wave-uniform float pinned in a VGPR (keeps SGPRs for pointers / exec masks; VALU reads either at no cost).
+#ifndef GFW_PIN_UNIFORMS
+#define GFW_PIN_UNIFORMS 0
+#endif
+__device__ __forceinline__ float vu(float s) {
+#if GFW_PIN_UNIFORMS
+    float v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v;
+#else
+    return s;
+#endif
+}
 
 struct IeeeOps {
     static __device__ __forceinline__ void div2(float a1, float a2, float b, float &q1, float &q2) { q1 = a1 / b; q2 = a2 / b; }
@@ -41,121 +63,175 @@ struct LeanOps {
         if (__builtin_expect(x < 8.271806125530277e-25f && x != 0.0f, 0)) return sqrtf(x);    // below 2^-80: generic path
         return gfw_sqrt_lean(x);
     }
-    static __device__ __forceinline__ float atan_pos(float x) { return gfw_atanf_pos(x); }
+    // glibc atanf, wave-specialised: when every active lane is below 0.4375 the reduction (and its division)
+    // disappears; otherwise the select-based single-division form (gfw_fastmath.h).
+    static __device__ __forceinline__ float atan_pos(float x) {
+        if (__all(x < 0.4375f)) {
+            const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+                        aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+                        aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+            const float z = x * x, w = z * z;
+            const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+            const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+            return x - x * (s1 + s2);
+        }
+        return gfw_atanf_pos(x);
+    }
 };
+
+// Lens + per-plane uniforms, VGPR-resident for the pixel loops.
+struct Lens {
+    float f0, f1, c0, c1, k0, k1, k2, k3, t2x, t2y, rl2;
+};
+struct Maps {                       // source_rect maps: u * mul / den  (den, rcp shared by luma and chroma)
+    float mul_lx, mul_ly, mul_cx, mul_cy, den_x, rcp_x, den_y, rcp_y;
+};
+__device__ __forceinline__ float map_c(float x, float mul, float den, float rcp) {
+    const float a = x * mul;
+    const float q0 = a * rcp;
+    const float r0 = __builtin_fmaf(-den, q0, a);
+    return __builtin_fmaf(r0, rcp, q0);
+}
 
 // opencv_fisheye.rs:72-95 on (X/W, Y/W); then *f, +c (cpu_undistort.rs:155,167)
 template <class Ops>
-__device__ __forceinline__ void fisheye_project(float X, float Y, float W, const GfwYuvArgs &A, float &u, float &v) {
+__device__ __forceinline__ void fisheye_project(float X, float Y, float W, const Lens &L, bool k_all_zero, float &u, float &v) {
     float a, b;
     Ops::div2(X, Y, W, a, b);
-    if (!A.k_all_zero) {
+    if (!k_all_zero) {
         const float r = Ops::sqrt(a * a + b * b);
         const float t = Ops::atan_pos(r);
         const float t2 = t * t, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
-        const float td = t * (1.0f + A.k[0] * t2 + A.k[1] * t4 + A.k[2] * t6 + A.k[3] * t8);
+        const float td = t * (1.0f + L.k0 * t2 + L.k1 * t4 + L.k2 * t6 + L.k3 * t8);
         const float s = (r == 0.0f) ? 1.0f : Ops::div(td, r);
         a = a * s; b = b * s;
     }
-    u = a * A.f[0] + A.c[0];
-    v = b * A.f[1] + A.c[1];
+    u = a * L.f0 + L.c0;
+    v = b * L.f1 + L.c1;
 }
 
-// rotate_and_distort restricted to the eligible configuration (no IBIS/mesh/digital/refraction, t3d == 0).
+// rotate_and_distort (cpu_undistort.rs:133-228) restricted to the eligible configuration
+// (no IBIS/mesh/digital/refraction, translation3d == 0).  ma/mb/m8 = the 9 matrix entries of the chosen row.
 template <int MODEL>
-__device__ __forceinline__ GfwPt rd(float px, float py, int idx, const GfwYuvArgs &A) {
-    const float *m = A.matrices + (size_t)idx * GFW_MAT_STRIDE;
-    const float4 ma = *reinterpret_cast<const float4 *>(m);
-    const float4 mb = *reinterpret_cast<const float4 *>(m + 4);
-    const float m8 = m[8];
+__device__ __forceinline__ GfwPt rd(float px, float py, const float4 ma, const float4 mb, const float m8, const Lens &L, const GfwYuvArgs &A) {
     const float X = (px * ma.x) + (py * ma.y) + ma.z;
     const float Y = (px * ma.w) + (py * mb.x) + mb.y;
     const float W = (px * mb.z) + (py * mb.w) + m8;
     GfwPt o{0.0f, 0.0f, false};
     if (!(W > 0.0f)) return o;
-    if (A.r_limit_sq > 0.0f && (X * X + Y * Y) > A.r_limit_sq * W) return o;
+    if (L.rl2 > 0.0f && (X * X + Y * Y) > L.rl2 * W) return o;
     o.ok = true;
     if (MODEL == GFW_MODEL_OPENCV_FISHEYE) {
         // proven operand range of the lean divide: |X|,|Y| <= 2^19, W in [2^-20, 2^20]  (=> |a|,|b| <= 2^39)
         const float mag = fmaxf(fmaxf(fabsf(X), fabsf(Y)), W);
         const bool lean = (mag <= 524288.0f) && (W >= 9.5367431640625e-07f);
-        if (__builtin_expect(lean, 1)) fisheye_project<LeanOps>(X, Y, W, A, o.x, o.y);
-        else fisheye_project<IeeeOps>(X, Y, W, A, o.x, o.y);
+        if (__builtin_expect(lean, 1)) fisheye_project<LeanOps>(X, Y, W, L, A.k_all_zero != 0, o.x, o.y);
+        else fisheye_project<IeeeOps>(X, Y, W, L, A.k_all_zero != 0, o.x, o.y);      // generic IEEE expansions
     } else {
         float du, dv;
         gfw_lens::distort<MODEL>(A.model, X, Y, W, A.kp, A.common, du, dv);
-        o.x = du * A.f[0] + A.c[0];
-        o.y = dv * A.f[1] + A.c[1];
+        o.x = du * L.f0 + L.c0;
+        o.y = dv * L.f1 + L.c1;
     }
-    if (A.hstretch_div) o.x /= A.hstretch;          // cpu_undistort.rs:222-223 (1.0 and <= 0.001 are skipped on the host)
-    if (A.vstretch_div) o.y /= A.vstretch;
+    // input_{horizontal,vertical}_stretch (cpu_undistort.rs:222-223): only <= 0.001 (skipped) or 1.0 (x/1 == x) reach
+    // this kernel; any other value is routed to the per-plane kernel by the host.
     return o;
 }
-
-// undistort_coord (cpu_undistort.rs:421-483) for the eligible configuration; (px, py) are full-res output pixels.
 template <int MODEL>
-__device__ __forceinline__ GfwPt coord(float px, float py, const GfwYuvArgs &A) {
-    const float ox = px + A.t2[0], oy = py + A.t2[1];
-    const int lim = A.hrs ? A.width : A.height;
-    int sy = gfw_f2i(roundf(A.hrs ? ox : oy));
-    sy = max(min(sy, lim), 0);
-    if (A.matrix_count > 1) {
-        const GfwPt pt = rd<MODEL>(ox, oy, A.matrix_count >> 1, A);
-        if (pt.ok) { sy = gfw_f2i(roundf(A.hrs ? pt.x : pt.y)); sy = max(min(sy, lim), 0); }
-    }
-    return rd<MODEL>(ox, oy, min(sy, A.matrix_count - 1), A);
+__device__ __forceinline__ GfwPt rd_row(float px, float py, int idx, const Lens &L, const GfwYuvArgs &A) {
+    const float *m = A.matrices + (size_t)idx * GFW_MAT_STRIDE;
+    return rd<MODEL>(px, py, *reinterpret_cast<const float4 *>(m), *reinterpret_cast<const float4 *>(m + 4), m[8], L, A);
 }
 
-// Bilinear taps of an N-channel u8/u16 plane (cpu_undistort.rs:371-418 with I = 2).
+// f32::round (half away from zero) then `as i32`: rndne is exact except on ties, which take the side branch.
+__device__ __forceinline__ int round_i32(float x) {
+    float r = rintf(x);
+    if (__builtin_expect(fabsf(x - r) == 0.5f, 0)) r = truncf(x) + copysignf(1.0f, x);
+    return gfw_f2i(r);
+}
+
+// ---- bilinear taps (cpu_undistort.rs:371-418 with I = 2) ---------------------------------------------------
+struct Bins { int sx, sy; float cx0, cx1, cy0, cy1; };
+__device__ __forceinline__ Bins make_bins(float u, float v) {
+    const int sx0 = round_i32(u * 32.0f), sy0 = round_i32(v * 32.0f);
+    Bins b;
+    b.sx = sx0 >> 5; b.sy = sy0 >> 5;
+    b.cx1 = (float)(sx0 & 31) * 0.03125f; b.cx0 = 1.0f - b.cx1;     // {1-k/32, k/32}: the LUT row (cpu_undistort.rs:14-19)
+    b.cy1 = (float)(sy0 & 31) * 0.03125f; b.cy0 = 1.0f - b.cy1;
+    return b;
+}
+// Taps that straddle the source rect: out-of-rect taps read `bg`, out-of-rect rows contribute bg*cy
+// (cpu_undistort.rs:392-409), in the reference's exact operation order.
 template <typename T, int N>
-__device__ __forceinline__ void sample_store(float u, float v, const GfwYuvPlane &P, int ox, int oy, bool ok) {
+__device__ __forceinline__ void taps_edge(const uint8_t *src, int stride, const Bins &b, int w, int h, const float *bg, float limit, float *out) {
+    const bool x0in = b.sx >= 0 && b.sx < w, x1in = b.sx + 1 >= 0 && b.sx + 1 < w;
+    const bool y0in = b.sy >= 0 && b.sy < h, y1in = b.sy + 1 >= 0 && b.sy + 1 < h;
+    const T *row0 = reinterpret_cast<const T *>(src + (int64_t)b.sy * stride) + (int64_t)b.sx * N;
+    const T *row1 = reinterpret_cast<const T *>(reinterpret_cast<const uint8_t *>(row0) + stride);
+    #pragma unroll
+    for (int c = 0; c < N; ++c) {
+        const float p00 = (y0in && x0in) ? (float)row0[c] : bg[c];
+        const float p01 = (y0in && x1in) ? (float)row0[N + c] : bg[c];
+        const float p10 = (y1in && x0in) ? (float)row1[c] : bg[c];
+        const float p11 = (y1in && x1in) ? (float)row1[N + c] : bg[c];
+        float sum = 0.0f;
+        if (y0in) { float xs = 0.0f; xs = xs + p00 * b.cx0; xs = xs + p01 * b.cx1; sum = sum + xs * b.cy0; } else sum = sum + bg[c] * b.cy0;
+        if (y1in) { float xs = 0.0f; xs = xs + p10 * b.cx0; xs = xs + p11 * b.cx1; sum = sum + xs * b.cy1; } else sum = sum + bg[c] * b.cy1;
+        out[c] = fminf(sum, limit);
+    }
+}
+// All four taps inside: 0 + x is exact for the non-negative taps, so the leading zero-adds are dropped.
+template <typename T, int N>
+__device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int stride, const Bins &b, float limit, float *out) {
+    const T *row0 = reinterpret_cast<const T *>(src + (int64_t)off0);
+    const T *row1 = reinterpret_cast<const T *>(src + (int64_t)(off0 + stride));
+    #pragma unroll
+    for (int c = 0; c < N; ++c) {
+        const float xs0 = (float)row0[c] * b.cx0 + (float)row0[N + c] * b.cx1;
+        const float xs1 = (float)row1[c] * b.cx0 + (float)row1[N + c] * b.cx1;
+        out[c] = fminf(xs0 * b.cy0 + xs1 * b.cy1, limit);
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ void store_px(uint8_t *dst, int off, const float *v) {
+    T *d = reinterpret_cast<T *>(dst + (int64_t)off);
+    #pragma unroll
+    for (int c = 0; c < N; ++c) d[c] = (T)gfw_f2u_sat(v[c], sizeof(T) == 1 ? 255.0f : 65535.0f);
+}
+// One plane.  32-bit byte offsets from the uniform plane base (planes are < 2 GiB, checked on the host).
+template <typename T, int N>
+__device__ __forceinline__ void sample_store(float u, float v, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy) {
     float out[N];
     #pragma unroll
-    for (int c = 0; c < N; ++c) out[c] = P.bg[c];
+    for (int c = 0; c < N; ++c) out[c] = bg[c];
     if (ok) {
-        const int sx0 = gfw_f2i(roundf(u * 32.0f)), sy0 = gfw_f2i(roundf(v * 32.0f));
-        const int sx = sx0 >> 5, sy = sy0 >> 5;
-        const float cx1 = (float)(sx0 & 31) * 0.03125f, cx0 = 1.0f - cx1;
-        const float cy1 = (float)(sy0 & 31) * 0.03125f, cy0 = 1.0f - cy1;
-        const T *row0 = reinterpret_cast<const T *>(P.src + (int64_t)sy * P.src_stride) + (int64_t)sx * N;
-        const T *row1 = reinterpret_cast<const T *>(reinterpret_cast<const uint8_t *>(row0) + P.src_stride);
-        float p00[N], p01[N], p10[N], p11[N];
-        if ((unsigned)sx < (unsigned)(P.w - 1) && (unsigned)sy < (unsigned)(P.h - 1)) {      // all four taps inside
-            #pragma unroll
-            for (int c = 0; c < N; ++c) { p00[c] = (float)row0[c]; p01[c] = (float)row0[N + c]; p10[c] = (float)row1[c]; p11[c] = (float)row1[N + c]; }
+        const Bins b = make_bins(u, v);
+        if (__builtin_expect((unsigned)b.sx < (unsigned)(P.w - 1) && (unsigned)b.sy < (unsigned)(P.h - 1), 1))
+            taps_inside<T, N>(P.src, b.sy * P.src_stride + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
+        else
+            taps_edge<T, N>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
+    }
+    store_px<T, N>(P.dst, oy * P.dst_stride + ox * (int)(N * sizeof(T)), out);
+}
+// Two planar chroma planes of identical geometry: one set of bins / weights / offsets, two gathers.
+template <typename T>
+__device__ __forceinline__ void sample_store_uv(float u, float v, bool ok, const GfwYuvPlane &PU, const GfwYuvPlane &PV,
+                                                float bg_u, float bg_v, float lim_u, float lim_v, int ox, int oy) {
+    float ou = bg_u, ov = bg_v;
+    if (ok) {
+        const Bins b = make_bins(u, v);
+        if (__builtin_expect((unsigned)b.sx < (unsigned)(PU.w - 1) && (unsigned)b.sy < (unsigned)(PU.h - 1), 1)) {
+            const int off0 = b.sy * PU.src_stride + b.sx * (int)sizeof(T);
+            taps_inside<T, 1>(PU.src, off0, PU.src_stride, b, lim_u, &ou);
+            taps_inside<T, 1>(PV.src, off0, PU.src_stride, b, lim_v, &ov);
         } else {
-            const bool x0in = sx >= 0 && sx < P.w, x1in = sx + 1 >= 0 && sx + 1 < P.w;
-            const bool y0in = sy >= 0 && sy < P.h, y1in = sy + 1 >= 0 && sy + 1 < P.h;
-            #pragma unroll
-            for (int c = 0; c < N; ++c) {
-                p00[c] = (y0in && x0in) ? (float)row0[c] : P.bg[c];
-                p01[c] = (y0in && x1in) ? (float)row0[N + c] : P.bg[c];
-                p10[c] = (y1in && x0in) ? (float)row1[c] : P.bg[c];
-                p11[c] = (y1in && x1in) ? (float)row1[N + c] : P.bg[c];
-            }
-            // rows outside the source rect contribute bg*cy (cpu_undistort.rs:408); identical to the tap form only
-            // through the same operations, so replay them exactly:
-            #pragma unroll
-            for (int c = 0; c < N; ++c) {
-                float sum = 0.0f;
-                if (y0in) { float xs = 0.0f; xs = xs + p00[c] * cx0; xs = xs + p01[c] * cx1; sum = sum + xs * cy0; } else sum = sum + P.bg[c] * cy0;
-                if (y1in) { float xs = 0.0f; xs = xs + p10[c] * cx0; xs = xs + p11[c] * cx1; sum = sum + xs * cy1; } else sum = sum + P.bg[c] * cy1;
-                out[c] = fminf(sum, P.limit);
-            }
-            goto store;
-        }
-        #pragma unroll
-        for (int c = 0; c < N; ++c) {
-            // xs = 0 + p0*cx0 + p1*cx1 ; sum = 0 + xs0*cy0 + xs1*cy1   (0 + x is exact; taps are non-negative)
-            const float xs0 = p00[c] * cx0 + p01[c] * cx1;
-            const float xs1 = p10[c] * cx0 + p11[c] * cx1;
-            out[c] = fminf(xs0 * cy0 + xs1 * cy1, P.limit);
+            taps_edge<T, 1>(PU.src, PU.src_stride, b, PU.w, PU.h, &bg_u, lim_u, &ou);
+            taps_edge<T, 1>(PV.src, PU.src_stride, b, PU.w, PU.h, &bg_v, lim_v, &ov);
         }
     }
-store:
-    T *dst = reinterpret_cast<T *>(P.dst + (int64_t)oy * P.dst_stride) + (int64_t)ox * N;
-    #pragma unroll
-    for (int c = 0; c < N; ++c) dst[c] = (T)gfw_f2u_sat(out[c], sizeof(T) == 1 ? 255.0f : 65535.0f);
+    const int doff = oy * PU.dst_stride + ox * (int)sizeof(T);
+    store_px<T, 1>(PU.dst, doff, &ou);
+    store_px<T, 1>(PV.dst, doff, &ov);
 }
 
 // ---- first pass (rolling-shutter row pick) -----------------------------------------------------------------
@@ -163,163 +239,207 @@ store:
 // sy = clamp(round(p.y)).  FAST1 evaluates p.y with fused arithmetic and a per-lens table of
 // s(rho) = theta_d(atan(sqrt(rho)))/sqrt(rho) (linear interpolation, rho = (X/W)^2 + (Y/W)^2) and accepts the
 // rounded value only when no half-integer lies within +-E of it, E bounding |approx - exact| (derivation in
-// DESIGN.md section 2; tests/test_gpu_pass1.py measures the real gap).  Everything else — a few percent of the
-// pixels — goes through the exact projection: queued in LDS and processed densely by the whole workgroup, so
-// the exact path costs one wave-pass per tile instead of one per wave.
-#define GFW_QCAP 256
-struct Pass1 { float X, Y, W; };
+// DESIGN.md section 2; tests/test_gpu_pass1.py audits every certificate and measures the real gap).  Everything
+// else — a percent or two of the pixels — goes through the exact projection: queued in LDS per wave and resolved
+// densely (one exact pass per few rows of the wave instead of one per pixel row).
+struct Mid { float m0, m1, m2, m3, m4, m5, m6, m7, m8; };
+struct P1 { float rho_max, rho_scale, eps, f, c, lim; };
 
-template <int MODEL, bool FAST1>
-__device__ __forceinline__ int pass1_default_row(float ox, float oy, const GfwYuvArgs &A) {
-    const int lim = A.hrs ? A.width : A.height;
-    const int sy = gfw_f2i(roundf(A.hrs ? ox : oy));
-    return max(min(sy, lim), 0);
-}
-// exact: cpu_undistort.rs:470-479
 template <int MODEL>
-__device__ __forceinline__ int pass1_exact(float ox, float oy, const GfwYuvArgs &A) {
-    int sy = pass1_default_row<MODEL, false>(ox, oy, A);
-    const GfwPt pt = rd<MODEL>(ox, oy, A.matrix_count >> 1, A);
-    if (pt.ok) { const int lim = A.hrs ? A.width : A.height; sy = gfw_f2i(roundf(A.hrs ? pt.x : pt.y)); sy = max(min(sy, lim), 0); }
+__device__ __forceinline__ int default_row(float ox, float oy, const GfwYuvArgs &A) {
+    const int lim = A.hrs ? A.width : A.height;
+    return max(min(round_i32(A.hrs ? ox : oy), lim), 0);
+}
+// exact: cpu_undistort.rs:465-479
+template <int MODEL>
+__device__ __forceinline__ int pass1_exact(float ox, float oy, const Mid &M, const Lens &L, const GfwYuvArgs &A) {
+    int sy = default_row<MODEL>(ox, oy, A);
+    const GfwPt pt = rd<MODEL>(ox, oy, float4{M.m0, M.m1, M.m2, M.m3}, float4{M.m4, M.m5, M.m6, M.m7}, M.m8, L, A);
+    if (pt.ok) { const int lim = A.hrs ? A.width : A.height; sy = max(min(round_i32(A.hrs ? pt.x : pt.y), lim), 0); }
     return sy;
 }
-// approximate + certificate; returns false when the exact path must decide
-__device__ __forceinline__ bool pass1_fast(float ox, float oy, const GfwYuvArgs &A, const float *mid, const float2 *tab, int &sy) {
-    // X, Y, W with fused multiply-adds (|error| ~ 1e-7 relative to the term magnitudes)
-    const float X = __builtin_fmaf(ox, mid[0], __builtin_fmaf(oy, mid[1], mid[2]));
-    const float Y = __builtin_fmaf(ox, mid[3], __builtin_fmaf(oy, mid[4], mid[5]));
-    const float W = __builtin_fmaf(ox, mid[6], __builtin_fmaf(oy, mid[7], mid[8]));
-    if (!(W > 0.0009765625f)) return false;                        // W not safely positive: exact path decides validity
+// approximate + certificate; returns false when the exact path must decide.
+// (ax, ay, aw) = ox*m0+m2, ox*m3+m5, ox*m6+m8 are per-lane constants of the pixel column.
+__device__ __forceinline__ bool pass1_fast(float ax, float ay, float aw, float oy, const Mid &M, const P1 &Q, const float2 *tab,
+                                           bool hrs, float rl2, int &sy, float &v_out) {
+    const float X = __builtin_fmaf(oy, M.m1, ax);
+    const float Y = __builtin_fmaf(oy, M.m4, ay);
+    const float W = __builtin_fmaf(oy, M.m7, aw);
     const float rw = gfw_hw_rcp(W);
     const float a = X * rw, b = Y * rw;
     const float rho = __builtin_fmaf(a, a, b * b);
-    if (!(rho < A.p1_rho_max)) return false;                       // outside the table (or NaN)
-    if (A.r_limit_sq > 0.0f) {                                     // :139 — decide only when clear of the boundary
-        const float lhs = __builtin_fmaf(X, X, Y * Y), rhs = A.r_limit_sq * W;
-        if (!(lhs < rhs * 0.9999f)) return false;
+    // W safely positive (the exact path decides validity otherwise) and rho inside the table (NaN fails both)
+    bool good = (W > 0.0009765625f) & (rho < Q.rho_max);
+    if (rl2 > 0.0f) {                                              // :139 — decide only when clear of the boundary
+        const float lhs = __builtin_fmaf(X, X, Y * Y), rhs = rl2 * W;
+        good = good & (lhs < rhs * 0.9999f);
     }
-    const float tpos = rho * A.p1_rho_scale;
+    const float tpos = fminf(fmaxf(rho, 0.0f), Q.rho_max) * Q.rho_scale;   // clamped: a rejected lane still indexes the table
     const float ti = floorf(tpos);
     const float2 e = tab[(int)ti];
     const float s = __builtin_fmaf(tpos - ti, e.y, e.x);
-    const float v = __builtin_fmaf((A.hrs ? a : b) * s, A.p1_f, A.p1_c);
+    const float v = __builtin_fmaf((hrs ? a : b) * s, Q.f, Q.c);
+    v_out = v;
     const float g = v - 0.5f;
     const float dist = fabsf(g - rintf(g));                        // distance of v to the nearest half-integer
-    const float lim = (float)(A.hrs ? A.width : A.height);
-    const bool inside = v > -0.25f && v < lim + 0.25f;             // outside, the clamp decides and ties cannot matter
-    if (inside && !(dist > A.p1_eps)) return false;
-    sy = max(min(gfw_f2i(rintf(v)), (int)lim), 0);
-    return true;
+    const bool outside = !(v > -0.25f) | !(v < Q.lim + 0.25f);     // there the clamp decides and ties cannot matter
+    good = good & (outside | (dist > Q.eps)) & (v == v);
+    sy = max(min(gfw_f2i(rintf(v)), (int)Q.lim), 0);
+    return good;
 }
 
-template <int MODEL, typename T, int DW, int DH, bool INTERLEAVED_UV, int RB, bool FAST1>
+template <int MODEL, typename T, int DW, int DH, bool INTERLEAVED_UV, int RB, bool FAST1, bool AUDIT>
 __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
-    // tile = 64 x 4 lanes, each lane owns RB vertically stacked DW x DH luma blocks (+ their chroma sites)
-    __shared__ float2 s_tab[FAST1 ? GFW_P1_TABLE_N + 1 : 1];
-    __shared__ float q_x[FAST1 ? GFW_QCAP : 1], q_y[FAST1 ? GFW_QCAP : 1];
-    __shared__ int q_sy[FAST1 ? GFW_QCAP : 1];
-    __shared__ unsigned q_n;
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    const bool two_pass = A.matrix_count > 1;
-    if (FAST1 && two_pass) {
-        for (int i = tid; i <= GFW_P1_TABLE_N; i += 256) s_tab[i] = A.p1_table[i];
-        if (tid == 0) q_n = 0;
-        __syncthreads();
-    }
-    const int tiles_x = A.tiles_x;
-    const int b = blockIdx.x;
-    const int n = tiles_x * A.tiles_y;
-    const int per = (n + 7) >> 3;
-    const int t = (b & 7) * per + (b >> 3);          // XCD-banded tile order (workgroup b runs on XCD b % 8)
-    const bool tile_ok = t < n;
-    const int ty = tile_ok ? t / tiles_x : 0, tx = tile_ok ? t - ty * tiles_x : 0;
-    const int cx = tx * 64 + threadIdx.x;
-    const int cy0 = (ty * 4 + threadIdx.y) * RB;     // first chroma-site row of this lane
-    const bool lane_ok = tile_ok && cx < A.cw;
+    // tile = 64 x 4 lanes; each lane owns RB vertically stacked DW x DH luma blocks (+ their chroma sites).
+    constexpr int NPX = DW * DH;
+    constexpr int QCAP = 128 * NPX;                  // a wave adds at most 64*NPX entries per row; flushed at half full
+    static_assert(RB * NPX <= 64, "slot index must fit the 6 low bits of q_dst");
+    __shared__ float q_x[FAST1 ? 4 : 1][FAST1 ? QCAP : 1], q_y[FAST1 ? 4 : 1][FAST1 ? QCAP : 1];
+    __shared__ unsigned short q_dst[FAST1 ? 4 : 1][FAST1 ? QCAP : 1];           // (owner lane << 6) | slot in s_rows
+    __shared__ unsigned q_n[4];
+    __shared__ int s_rows[RB * NPX][256];                                        // phase-1 rows, one column per lane
+    const int wave = threadIdx.y, lane = threadIdx.x, tid = wave * 64 + lane;
+    const bool two_pass = A.matrix_count > 1 && !(A.ablate & 1);
+    const bool hrs = A.hrs != 0;
 
-    // ---- phase 1: rolling-shutter row of every luma pixel of this lane --------------------------------
-    int rows[RB][DH][DW];
+    // uniform floats of the pixel loops, pinned in VGPRs once per wave
+    Lens L;
+    L.f0 = vu(A.f[0]); L.f1 = vu(A.f[1]); L.c0 = vu(A.c[0]); L.c1 = vu(A.c[1]);
+    L.k0 = vu(A.k[0]); L.k1 = vu(A.k[1]); L.k2 = vu(A.k[2]); L.k3 = vu(A.k[3]);
+    L.t2x = vu(A.t2[0]); L.t2y = vu(A.t2[1]); L.rl2 = vu(A.r_limit_sq);
+    Maps MP;
+    MP.mul_lx = vu(A.map_lx.mul); MP.mul_ly = vu(A.map_ly.mul); MP.mul_cx = vu(A.map_cx.mul); MP.mul_cy = vu(A.map_cy.mul);
+    MP.den_x = vu(A.map_lx.den); MP.rcp_x = vu(A.map_lx.rcp); MP.den_y = vu(A.map_ly.den); MP.rcp_y = vu(A.map_ly.rcp);
+    float bg_y = vu(A.pl[0].bg[0]), lim_y = vu(A.pl[0].limit);
+    float bg_c[2] = {vu(A.pl[1].bg[0]), vu(INTERLEAVED_UV ? A.pl[1].bg[1] : A.pl[2].bg[0])};
+    float lim_u = vu(A.pl[1].limit), lim_v = vu(INTERLEAVED_UV ? A.pl[1].limit : A.pl[2].limit);
+    Mid M{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    P1 Q{0, 0, 0, 0, 0, 0};
     if (two_pass) {
         const float *mid = A.matrices + (size_t)(A.matrix_count >> 1) * GFW_MAT_STRIDE;   // wave-uniform -> scalar loads
-        #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            #pragma unroll
-            for (int j = 0; j < DH; ++j) {
-                #pragma unroll
-                for (int i = 0; i < DW; ++i) {
+        M.m0 = vu(mid[0]); M.m1 = vu(mid[1]); M.m2 = vu(mid[2]); M.m3 = vu(mid[3]); M.m4 = vu(mid[4]);
+        M.m5 = vu(mid[5]); M.m6 = vu(mid[6]); M.m7 = vu(mid[7]); M.m8 = vu(mid[8]);
+        if (FAST1) {
+            Q.rho_max = vu(A.p1_rho_max); Q.rho_scale = vu(A.p1_rho_scale); Q.eps = vu(A.p1_eps);
+            Q.f = vu(A.p1_f); Q.c = vu(A.p1_c); Q.lim = vu((float)(A.hrs ? A.width : A.height));
+        }
+    }
+
+    // persistent walk over this workgroup's share of the XCD band of tiles
+    const int n_tiles = A.tiles_x * A.tiles_y;
+    const int per_xcd = (n_tiles + 7) >> 3;
+    const int wg_per_xcd = (int)gridDim.x >> 3;
+    const int xcd = (int)blockIdx.x & 7;
+    for (int tb = (int)blockIdx.x >> 3; tb < per_xcd; tb += wg_per_xcd) {
+        const int t = xcd * per_xcd + tb;
+        if (t >= n_tiles) break;
+        const int ty = t / A.tiles_x, tx = t - ty * A.tiles_x;
+        const int cx = tx * 64 + lane;
+        const int cy0 = (ty * 4 + wave) * RB;            // first chroma-site row of this lane
+        const bool lane_ok = cx < A.cw;
+
+        // ---- phase 1: rolling-shutter row of every luma pixel of this lane ----------------------------
+        if (two_pass) {
+            if (FAST1) {
+                if (lane == 0) q_n[wave] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+            #pragma unroll 1
+            for (int r = 0; r < RB; ++r) {
+                #pragma unroll (NPX <= 2 ? NPX : 1)
+                for (int k = 0; k < NPX; ++k) {
+                    const int i = k % DW, j = k / DW;
                     const int lx = cx * DW + i, ly = (cy0 + r) * DH + j;
                     int sy = 0;
                     if (lane_ok && lx < A.out_w && ly < A.out_h) {
-                        const float ox = (float)lx + A.t2[0], oy = (float)ly + A.t2[1];
+                        const float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
                         if (FAST1) {
-                            if (!pass1_fast(ox, oy, A, mid, s_tab, sy)) {
-                                const unsigned slot = atomicAdd(&q_n, 1u);
-                                if (slot < GFW_QCAP) { q_x[slot] = ox; q_y[slot] = oy; sy = -1 - (int)slot; }
-                                else sy = pass1_exact<MODEL>(ox, oy, A);          // queue full: decide inline
-                                if (A.audit) atomicAdd(&A.audit[slot < GFW_QCAP ? 2 : 3], 1ull);
-                            } else if (A.audit) {                                 // audit mode: every certificate is checked
+                            float v_fast;
+                            const float ax = __builtin_fmaf(ox, M.m0, M.m2), ay = __builtin_fmaf(ox, M.m3, M.m5), aw = __builtin_fmaf(ox, M.m6, M.m8);
+                            if (!pass1_fast(ax, ay, aw, oy, M, Q, A.p1_table, hrs, L.rl2, sy, v_fast)) {
+                                const unsigned slot = atomicAdd(&q_n[wave], 1u);      // < QCAP: flushed below before it can fill
+                                q_x[wave][slot] = ox; q_y[wave][slot] = oy;
+                                q_dst[wave][slot] = (unsigned short)((lane << 6) | (r * NPX + k));
+                                if (AUDIT) atomicAdd(&A.audit[2], 1ull);
+                            } else if (AUDIT) {                                       // audit: every certificate is checked
                                 atomicAdd(&A.audit[0], 1ull);
-                                if (pass1_exact<MODEL>(ox, oy, A) != sy) atomicAdd(&A.audit[1], 1ull);
+                                if (pass1_exact<MODEL>(ox, oy, M, L, A) != sy) atomicAdd(&A.audit[1], 1ull);
+                                const GfwPt ex = rd<MODEL>(ox, oy, float4{M.m0, M.m1, M.m2, M.m3}, float4{M.m4, M.m5, M.m6, M.m7}, M.m8, L, A);
+                                if (ex.ok) atomicMax(&A.audit[4], (unsigned long long)gfw_f2u(fabsf((hrs ? ex.x : ex.y) - v_fast)));
                             }
                         } else {
-                            sy = pass1_exact<MODEL>(ox, oy, A);
+                            sy = pass1_exact<MODEL>(ox, oy, M, L, A);
                         }
                     }
-                    rows[r][j][i] = sy;
+                    s_rows[r * NPX + k][tid] = sy;
+                }
+                if (FAST1) {
+                    // ---- phase 2: the wave resolves its queued pixels exactly, densely packed.  Flushed after
+                    // the last row, or earlier when the next row (<= 64*NPX new entries) could overflow the queue.
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const unsigned qn = q_n[wave];
+                    if (r == RB - 1 || qn + 64u * NPX > (unsigned)QCAP) {
+                        for (unsigned e = lane; e < qn; e += 64) {
+                            const int sy = pass1_exact<MODEL>(q_x[wave][e], q_y[wave][e], M, L, A);
+                            const unsigned d = q_dst[wave][e];
+                            s_rows[d & 63u][wave * 64 + (d >> 6)] = sy;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        if (lane == 0) q_n[wave] = 0;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    }
                 }
             }
         }
-        if (FAST1) {
-            // ---- phase 2: the workgroup resolves the queued pixels exactly, densely packed ---------------
-            __syncthreads();
-            const unsigned qn = min(q_n, (unsigned)GFW_QCAP);
-            for (unsigned e = tid; e < qn; e += 256) q_sy[e] = pass1_exact<MODEL>(q_x[e], q_y[e], A);
-            __syncthreads();
-        }
-    }
-    if (!lane_ok) return;
 
-    // ---- phase 3: exact projection with the row's own matrix, then taps -------------------------------
-    #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-        const int cy = cy0 + r;
-        if (cy >= A.ch) break;
-        float u0 = 0.0f, v0 = 0.0f; bool ok0 = false;
-        #pragma unroll
-        for (int j = 0; j < DH; ++j) {
-            #pragma unroll
-            for (int i = 0; i < DW; ++i) {
-                const int lx = cx * DW + i, ly = cy * DH + j;
-                if (lx >= A.out_w || ly >= A.out_h) continue;
-                const float ox = (float)lx + A.t2[0], oy = (float)ly + A.t2[1];
-                int sy;
-                if (two_pass) { sy = rows[r][j][i]; if (FAST1 && sy < 0) sy = q_sy[-1 - sy]; }
-                else sy = pass1_default_row<MODEL, false>(ox, oy, A);
-                const GfwPt p = rd<MODEL>(ox, oy, min(sy, A.matrix_count - 1), A);
-                if (i == 0 && j == 0) { u0 = p.x; v0 = p.y; ok0 = p.ok; }
-                const float lu = gfw_map_const(p.x, A.map_lx), lv = gfw_map_const(p.y, A.map_ly);   // cpu_undistort.rs:511-514
-                sample_store<T, 1>(lu, lv, A.pl[0], lx, ly, p.ok);
+        // ---- phase 3: exact projection with the row's own matrix, then taps ---------------------------
+        if (lane_ok) {
+            #pragma unroll 1
+            for (int r = 0; r < RB; ++r) {
+                const int cy = cy0 + r;
+                if (cy >= A.ch) break;
+                float u0 = 0.0f, v0 = 0.0f; bool ok0 = false;
+                #pragma unroll (NPX <= 2 ? NPX : 1)
+                for (int k = 0; k < NPX; ++k) {
+                    const int i = k % DW, j = k / DW;
+                    const int lx = cx * DW + i, ly = cy * DH + j;
+                    if (lx >= A.out_w || ly >= A.out_h) continue;
+                    const float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
+                    const int sy = two_pass ? s_rows[r * NPX + k][tid] : default_row<MODEL>(ox, oy, A);
+                    GfwPt p;
+                    if (A.ablate & 8) { p.x = ox * 0.5f; p.y = oy * 0.5f; p.ok = true; }              // timing ablation only
+                    else p = rd_row<MODEL>(ox, oy, min(sy, A.matrix_count - 1), L, A);
+                    if (k == 0) { u0 = p.x; v0 = p.y; ok0 = p.ok; }
+                    const float lu = map_c(p.x, MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c(p.y, MP.mul_ly, MP.den_y, MP.rcp_y);   // cpu_undistort.rs:511-514
+                    if (A.ablate & 2) { if (lane == 99) A.pl[0].dst[0] = (uint8_t)(lu + lv); continue; }  // timing ablation only
+                    sample_store<T, 1>(lu, lv, p.ok, A.pl[0], &bg_y, lim_y, lx, ly);
+                }
+                if (A.nplanes > 1 && !(A.ablate & 4)) {
+                    const float cu = map_c(u0, MP.mul_cx, MP.den_x, MP.rcp_x), cv = map_c(v0, MP.mul_cy, MP.den_y, MP.rcp_y);
+                    if (INTERLEAVED_UV) sample_store<T, 2>(cu, cv, ok0, A.pl[1], bg_c, lim_u, cx, cy);
+                    else if (A.nplanes == 3) sample_store_uv<T>(cu, cv, ok0, A.pl[1], A.pl[2], bg_c[0], bg_c[1], lim_u, lim_v, cx, cy);
+                    else {
+                        #pragma unroll 1
+                        for (int pi = 1; pi < A.nplanes; ++pi) { const float bgp = A.pl[pi].bg[0]; sample_store<T, 1>(cu, cv, ok0, A.pl[pi], &bgp, A.pl[pi].limit, cx, cy); }
+                    }
+                }
             }
         }
-        if (A.nplanes > 1) {
-            const float cu = gfw_map_const(u0, A.map_cx), cv = gfw_map_const(v0, A.map_cy);
-            if (INTERLEAVED_UV) {
-                sample_store<T, 2>(cu, cv, A.pl[1], cx, cy, ok0);
-            } else {
-                sample_store<T, 1>(cu, cv, A.pl[1], cx, cy, ok0);
-                if (A.nplanes > 2) sample_store<T, 1>(cu, cv, A.pl[2], cx, cy, ok0);
-                if (A.nplanes > 3) sample_store<T, 1>(cu, cv, A.pl[3], cx, cy, ok0);
-            }
-        }
+        if (FAST1 && two_pass) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // s_rows is rewritten by the next tile
     }
 }
 
-template <int MODEL, typename T, int RB, bool FAST1>
+template <int MODEL, typename T, int RB, bool FAST1, bool AUDIT>
 hipError_t launch_mt(const GfwYuvArgs &A, int dw, int dh, bool interleaved, hipStream_t s) {
-    const int grid = (((A.tiles_x * A.tiles_y) + 7) >> 3) << 3;
-    if (grid <= 0) return hipSuccess;
+    const int n_tiles = A.tiles_x * A.tiles_y;
+    if (n_tiles <= 0) return hipSuccess;
+    // persistent grid: a multiple of 8 (XCD bands), ~6 workgroups per CU by default, never more than one per tile
+    int grid = A.grid_limit > 0 ? A.grid_limit : 256 * 6;
+    const int per_xcd = (n_tiles + 7) >> 3;
+    if (grid > per_xcd * 8) grid = per_xcd * 8;
+    grid = (grid + 7) & ~7;
     dim3 block(64, 4);
-#define GFW_YUV_LAUNCH(DW, DH, IL) hipLaunchKernelGGL((gfw_yuv_kernel<MODEL, T, DW, DH, IL, RB, FAST1>), dim3(grid), block, 0, s, A)
+#define GFW_YUV_LAUNCH(DW, DH, IL) hipLaunchKernelGGL((gfw_yuv_kernel<MODEL, T, DW, DH, IL, RB, FAST1, AUDIT>), dim3(grid), block, 0, s, A)
     if (dw == 2 && dh == 1 && !interleaved) GFW_YUV_LAUNCH(2, 1, false);
     else if (dw == 2 && dh == 1 && interleaved) GFW_YUV_LAUNCH(2, 1, true);
     else if (dw == 2 && dh == 2 && !interleaved) GFW_YUV_LAUNCH(2, 2, false);
@@ -333,16 +453,30 @@ hipError_t launch_mt(const GfwYuvArgs &A, int dw, int dh, bool interleaved, hipS
 
 }  // namespace
 
-int gfw_yuv_rows_per_lane(bool fast1) { return fast1 ? GFW_YUV_RB_FAST : GFW_YUV_RB_EXACT; }
+int gfw_yuv_rows_per_lane(bool fast1, int tune_rb) {
+    if (!fast1) return GFW_YUV_RB_EXACT;
+    return (tune_rb == 1 || tune_rb == 2 || tune_rb == 4 || tune_rb == 8) ? tune_rb : GFW_YUV_RB_FAST;
+}
 
-hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int bytes_per_sample, int dw, int dh, bool interleaved, bool fast1, hipStream_t s) {
+template <int MODEL, typename T>
+static hipError_t launch_fast(const GfwYuvArgs &A, int dw, int dh, bool interleaved, int rb, hipStream_t s) {
+    if (A.audit) return launch_mt<MODEL, T, GFW_YUV_RB_FAST, true, true>(A, dw, dh, interleaved, s);
+    switch (rb) {
+    case 1: return launch_mt<MODEL, T, 1, true, false>(A, dw, dh, interleaved, s);
+    case 2: return launch_mt<MODEL, T, 2, true, false>(A, dw, dh, interleaved, s);
+    case 8: return launch_mt<MODEL, T, 8, true, false>(A, dw, dh, interleaved, s);
+    default: return launch_mt<MODEL, T, 4, true, false>(A, dw, dh, interleaved, s);
+    }
+}
+
+hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int bytes_per_sample, int dw, int dh, bool interleaved, bool fast1, int rb, hipStream_t s) {
     if (A.model == GFW_MODEL_OPENCV_FISHEYE) {
         if (fast1)
-            return bytes_per_sample == 1 ? launch_mt<GFW_MODEL_OPENCV_FISHEYE, uint8_t, GFW_YUV_RB_FAST, true>(A, dw, dh, interleaved, s)
-                                         : launch_mt<GFW_MODEL_OPENCV_FISHEYE, uint16_t, GFW_YUV_RB_FAST, true>(A, dw, dh, interleaved, s);
-        return bytes_per_sample == 1 ? launch_mt<GFW_MODEL_OPENCV_FISHEYE, uint8_t, GFW_YUV_RB_EXACT, false>(A, dw, dh, interleaved, s)
-                                     : launch_mt<GFW_MODEL_OPENCV_FISHEYE, uint16_t, GFW_YUV_RB_EXACT, false>(A, dw, dh, interleaved, s);
+            return bytes_per_sample == 1 ? launch_fast<GFW_MODEL_OPENCV_FISHEYE, uint8_t>(A, dw, dh, interleaved, rb, s)
+                                         : launch_fast<GFW_MODEL_OPENCV_FISHEYE, uint16_t>(A, dw, dh, interleaved, rb, s);
+        return bytes_per_sample == 1 ? launch_mt<GFW_MODEL_OPENCV_FISHEYE, uint8_t, GFW_YUV_RB_EXACT, false, false>(A, dw, dh, interleaved, s)
+                                     : launch_mt<GFW_MODEL_OPENCV_FISHEYE, uint16_t, GFW_YUV_RB_EXACT, false, false>(A, dw, dh, interleaved, s);
     }
-    return bytes_per_sample == 1 ? launch_mt<-1, uint8_t, GFW_YUV_RB_EXACT, false>(A, dw, dh, interleaved, s)
-                                 : launch_mt<-1, uint16_t, GFW_YUV_RB_EXACT, false>(A, dw, dh, interleaved, s);
+    return bytes_per_sample == 1 ? launch_mt<-1, uint8_t, GFW_YUV_RB_EXACT, false, false>(A, dw, dh, interleaved, s)
+                                 : launch_mt<-1, uint16_t, GFW_YUV_RB_EXACT, false, false>(A, dw, dh, interleaved, s);
 }

@@ -89,10 +89,11 @@ class Backend:
         return ms.value, n.value
 
     def get_audit(self, reset=False):
-        """First-pass audit counters: (certified, certified_but_wrong, queued, queue_overflow)."""
-        arr = (C.c_ulonglong * 4)()
+        """First-pass audit: (certified, certified_but_wrong, queued, queue_overflow, max |approx - exact| in pixels)."""
+        arr = (C.c_ulonglong * 8)()
         self._check(self.lib.gfw_get_audit(self.ctx, C.byref(arr), 1 if reset else 0))
-        return tuple(int(v) for v in arr)
+        gap = float(np.array([int(arr[4]) & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0])
+        return int(arr[0]), int(arr[1]), int(arr[2]), int(arr[3]), gap
 
     def synchronize(self):
         self._check(self.lib.gfw_synchronize(self.ctx))

@@ -253,7 +253,9 @@ enum {
     GFW_OPT_MATRICES_ON_DEVICE = 2,  /* 1: `matrices` is a device pointer */
     GFW_OPT_KERNEL_VARIANT     = 3,  /* 0 auto; 1 generic per-plane kernel; 2 fused kernel with the exact first pass;
                                         3 fused kernel, certified first pass in audit mode (see gfw_get_audit) */
-    GFW_OPT_PROFILE            = 4   /* 1: bracket every warp-kernel launch with hipEvents on the context stream */
+    GFW_OPT_PROFILE            = 4,  /* 1: bracket every warp-kernel launch with hipEvents on the context stream */
+    GFW_OPT_TUNE_ROWS          = 5,  /* tuning: luma block rows per lane of the fused kernel (1, 2, 4, 8; 0 = default) */
+    GFW_OPT_TUNE_GRID          = 6   /* tuning: persistent workgroups of the fused kernel (0 = 6 per CU) */
 };
 int   gfw_set_option(gfw_ctx *ctx, int option, int64_t value);
 /* hipStream_t the context enqueues on (as void*); caller may substitute its
@@ -280,10 +282,11 @@ const char *gfw_last_error(void);
  * gfw_debug_selftest: compares a lean routine with its generic twin on `n` device-generated operands
  *   (test 0: divide, operands in the proven range; 1: sqrt; 2: atanf_pos vs atanf over ALL non-negative floats
  *   when n == 0) and returns the number of mismatching results (0 expected), or a negative GFW_ERR_*. */
-/* First-pass audit of the fused kernel (GFW_OPT_KERNEL_VARIANT = 3): counters4 = {certified pixels,
- * certified-but-different-from-exact (must stay 0), queued to the exact path, queue overflows}.  Call with
- * reset = 1 before the frames to be audited. */
-int   gfw_get_audit(gfw_ctx *ctx, unsigned long long *counters4, int reset);
+/* First-pass audit of the fused kernel (GFW_OPT_KERNEL_VARIANT = 3): counters8 = {certified pixels,
+ * certified-but-different-from-exact (must stay 0), queued to the exact path, queue overflows,
+ * max |approximate - exact| coordinate over certified pixels as f32 bits, 3 spare}.  Call with reset = 1 before
+ * the frames to be audited. */
+int   gfw_get_audit(gfw_ctx *ctx, unsigned long long *counters8, int reset);
 int   gfw_debug_math(int op, const float *a, const float *b, float *out, size_t n);
 long long gfw_debug_selftest(int test, unsigned long long n, unsigned long long seed);
 

@@ -10,6 +10,13 @@ import _oracle as O
 pytestmark = pytest.mark.gpu
 
 
+def eps_of(fr):
+    """The certificate half-width the host computes for this frame (gfw_api.hip: p1_setup), re-derived loosely:
+    it is never below 1/4096 px + 1.8e-6 * (|c| + |f|)."""
+    p = fr.planes[0]["params"]
+    return 1.0 / 4096.0 + 1.8e-6 * (abs(p.c[1]) + abs(p.f[1]))
+
+
 def audit(fr):
     outs = [pl["dst"].copy() for pl in fr.planes]
     bufs = [warp.host_buffers(pl["src"], pl["size"], o, pl["out_size"]) for pl, o in zip(fr.planes, outs)]
@@ -30,10 +37,11 @@ def audit(fr):
 @pytest.mark.parametrize("size", [(640, 360), (1920, 1080)])
 def test_certificates_never_disagree_with_the_exact_row(seed, size):
     fr = S.SyntheticFrame("YUV422P16LE", size[0], size[1], seed=seed, timestamp_ms=500.0 + 77.7 * seed, readout_ms=8.0 + 4.0 * seed)
-    (certified, wrong, queued, overflow), outs = audit(fr)
+    (certified, wrong, queued, overflow, gap), outs = audit(fr)
     total = size[0] * size[1]
     assert certified + queued + overflow == total
     assert wrong == 0
+    assert gap < 0.5 * eps_of(fr), "approximation gap %g px is not well inside the certificate half-width" % gap
     assert queued + overflow < 0.15 * total, "certificate rejects too many pixels: %d of %d" % (queued + overflow, total)
     ref = O.run_frame(fr)
     for a, b in zip(ref, outs):
@@ -42,13 +50,13 @@ def test_certificates_never_disagree_with_the_exact_row(seed, size):
 
 def test_audit_4k_c2_and_wide_lens():
     fr = S.SyntheticFrame("YUV422P16LE", 3840, 2160, seed=0x9F10)
-    (certified, wrong, queued, overflow), _ = audit(fr)
+    (certified, wrong, queued, overflow, gap), _ = audit(fr)
     assert wrong == 0 and certified > 0.85 * 3840 * 2160
     lens = S.gopro_style_lens(1280, 720)
     lens["f"] = (0.33 * 1280, 0.33 * 1280)                      # much wider field of view: rho up to ~3.5
     lens["k"] = [0.12, -0.04, 0.01, -0.002] + [0.0] * 8
     fr = S.SyntheticFrame("NV12", 1280, 720, seed=8, lens=lens, fov=1.3)
-    (certified, wrong, queued, overflow), outs = audit(fr)
+    (certified, wrong, queued, overflow, gap), outs = audit(fr)
     assert wrong == 0
     ref = O.run_frame(fr)
     for a, b in zip(ref, outs):
@@ -57,10 +65,10 @@ def test_audit_4k_c2_and_wide_lens():
 
 def test_horizontal_rs_and_zoomed_out_audit():
     fr = S.SyntheticFrame("YUV422P16LE", 640, 360, seed=4, horizontal_rs=True)
-    (certified, wrong, queued, overflow), _ = audit(fr)
+    (certified, wrong, queued, overflow, gap), _ = audit(fr)
     assert wrong == 0 and certified > 0
     fr = S.SyntheticFrame("YUV422P16LE", 640, 360, seed=17, fov=3.0)
-    (certified, wrong, queued, overflow), outs = audit(fr)
+    (certified, wrong, queued, overflow, gap), outs = audit(fr)
     assert wrong == 0
     ref = O.run_frame(fr)
     for a, b in zip(ref, outs):
