@@ -64,7 +64,7 @@ struct gfw_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = true;
     bool synchronous = true;
-    bool matrices_on_device = false;
+    int matrices_on_device = 0;                  // 0 host rows[14]; 1 device rows[14]; 2 device rows[16] packed by gfw_pack_matrices
     int kernel_variant = 0;
     int tune_rb = 0;
     int tune_grid = 0;
@@ -73,8 +73,14 @@ struct gfw_ctx {
     int max_matrix_rows = 0;
     size_t src_len = 0, dst_len = 0;              // sizes declared at create (opencl.rs:287-293)
     std::vector<DevBuf> stage_src, stage_dst;      // per-plane staging for HOST buffers
-    DevBuf d_matrices, d_matrices_raw, d_mesh;
-    float *h_matrices = nullptr; size_t h_matrices_cap = 0;   // pinned repack staging
+    DevBuf d_mesh;
+    // per-row matrices: ring of (pinned host, device) slots so that an asynchronous caller can enqueue several frames;
+    // uploads run on their own stream and overlap the previous frame's kernel.
+    struct MatSlot { float *h = nullptr; float *d = nullptr; hipEvent_t copied = nullptr, done = nullptr; bool used = false; };
+    static constexpr int kMatSlots = 4;
+    MatSlot mslots[kMatSlots];
+    int mslot_next = 0, mslot_cur = -1;
+    hipStream_t copy_stream = nullptr;
     const char *last_backend = "";
     // certified first pass of the fused kernel: s(rho) table cache
     DevBuf d_p1_table, d_audit;
@@ -194,11 +200,14 @@ gfw_ctx *gfw_create(const gfw_kernel_params *params, int pixel_type, int distort
     c->max_matrix_rows = ((params->flags & GFW_FLAG_HORIZONTAL_RS) ? params->width : params->height);   // opencl.rs:287
     if (c->max_matrix_rows < 1) c->max_matrix_rows = 1;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && c->d_matrices.ensure((size_t)c->max_matrix_rows * GFW_MAT_STRIDE * sizeof(float)) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && c->d_mesh.ensure(GFW_MESH_MAX * sizeof(float)) == hipSuccess;
-    if (ok) {
-        c->h_matrices_cap = (size_t)c->max_matrix_rows * GFW_MAT_STRIDE * sizeof(float);
-        ok = hipHostMalloc((void **)&c->h_matrices, c->h_matrices_cap) == hipSuccess;
+    const size_t mat_bytes = (size_t)c->max_matrix_rows * GFW_MAT_STRIDE * sizeof(float);
+    for (int i = 0; i < gfw_ctx::kMatSlots && ok; ++i) {
+        gfw_ctx::MatSlot &s = c->mslots[i];
+        ok = hipHostMalloc((void **)&s.h, mat_bytes) == hipSuccess && hipMalloc((void **)&s.d, mat_bytes) == hipSuccess &&
+             hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
     }
     c->stage_src.resize(1); c->stage_dst.resize(1);
     if (ok && buffers->input.kind == GFW_BUF_HOST) ok = c->stage_src[0].ensure(c->src_len) == hipSuccess;
@@ -214,8 +223,14 @@ void gfw_destroy(gfw_ctx *c) {
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &b : c->stage_src) b.release();
     for (auto &b : c->stage_dst) b.release();
-    c->d_matrices.release(); c->d_matrices_raw.release(); c->d_mesh.release(); c->d_p1_table.release(); c->d_audit.release();
-    if (c->h_matrices) (void)hipHostFree(c->h_matrices);
+    c->d_mesh.release(); c->d_p1_table.release(); c->d_audit.release();
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (auto &s : c->mslots) {
+        if (s.h) (void)hipHostFree(s.h);
+        if (s.d) (void)hipFree(s.d);
+        if (s.copied) (void)hipEventDestroy(s.copied);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -224,7 +239,7 @@ int gfw_set_option(gfw_ctx *c, int option, int64_t value) {
     if (!c) return GFW_ERR_INVALID_ARGUMENT;
     switch (option) {
     case GFW_OPT_SYNCHRONOUS: c->synchronous = value != 0; return GFW_OK;
-    case GFW_OPT_MATRICES_ON_DEVICE: c->matrices_on_device = value != 0; return GFW_OK;
+    case GFW_OPT_MATRICES_ON_DEVICE: c->matrices_on_device = (int)value; return GFW_OK;
     case GFW_OPT_KERNEL_VARIANT: c->kernel_variant = (int)value; return GFW_OK;
     case GFW_OPT_PROFILE: c->profile = value != 0; return GFW_OK;
     case GFW_OPT_TUNE_ROWS: c->tune_rb = (int)value; return GFW_OK;
@@ -298,23 +313,35 @@ static int upload_matrices(gfw_ctx *c, const float *matrices, int matrix_count, 
     if (matrix_count > c->max_matrix_rows) {
         // opencl.rs:336 logs "Buffer size mismatch matrices!" and skips the frame
         set_error("Buffer size mismatch matrices! %d vs %d", c->max_matrix_rows, matrix_count); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
-    float *d = (float *)c->d_matrices.ptr;
+    if (c->matrices_on_device == 2) { c->mslot_cur = -1; *d_out = matrices; return GFW_OK; }   // caller-resident, already packed
+    c->mslot_cur = c->mslot_next;
+    c->mslot_next = (c->mslot_next + 1) % gfw_ctx::kMatSlots;
+    gfw_ctx::MatSlot &s = c->mslots[c->mslot_cur];
+    if (s.used) HIP_TRY(hipEventSynchronize(s.done), GFW_ERR_HIP);          // the kernel that read this slot has finished
     if (c->matrices_on_device) {
-        HIP_TRY(gfw_launch_repack(matrices, d, matrix_count, c->stream), GFW_ERR_HIP);
+        HIP_TRY(gfw_launch_repack(matrices, s.d, matrix_count, c->stream), GFW_ERR_HIP);
     } else {
         // host repack into pinned memory; cos/sin of the IBIS roll angle come from the host libm so
         // they are the very values the reference's CPU path uses (cpu_undistort.rs:159-160)
-        float *h = c->h_matrices;
         for (int r = 0; r < matrix_count; ++r) {
             const float *m = matrices + (size_t)r * 14;
-            float *o = h + (size_t)r * GFW_MAT_STRIDE;
+            float *o = s.h + (size_t)r * GFW_MAT_STRIDE;
             memcpy(o, m, 14 * sizeof(float));
             if (m[9] != 0.0f || m[10] != 0.0f || m[11] != 0.0f || m[12] != 0.0f || m[13] != 0.0f) { o[14] = cosf(-m[11]); o[15] = sinf(-m[11]); }
             else { o[14] = 1.0f; o[15] = 0.0f; }
         }
-        HIP_TRY(hipMemcpyAsync(d, h, (size_t)matrix_count * GFW_MAT_STRIDE * sizeof(float), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
+        HIP_TRY(hipMemcpyAsync(s.d, s.h, (size_t)matrix_count * GFW_MAT_STRIDE * sizeof(float), hipMemcpyHostToDevice, c->copy_stream), GFW_ERR_HIP);
+        HIP_TRY(hipEventRecord(s.copied, c->copy_stream), GFW_ERR_HIP);
+        HIP_TRY(hipStreamWaitEvent(c->stream, s.copied, 0), GFW_ERR_HIP);
     }
-    *d_out = d;
+    *d_out = s.d;
+    return GFW_OK;
+}
+static int matrices_consumed(gfw_ctx *c) {          // call after the kernels that read the current slot are enqueued
+    if (c->mslot_cur < 0) return GFW_OK;
+    gfw_ctx::MatSlot &s = c->mslots[c->mslot_cur];
+    HIP_TRY(hipEventRecord(s.done, c->stream), GFW_ERR_HIP);
+    s.used = true;
     return GFW_OK;
 }
 
@@ -426,7 +453,12 @@ static bool p1_setup(gfw_ctx *c, const gfw_kernel_params &p0, const float *h_mat
         }
         rho_max = rho_max * 1.25 + 0.01;
     } else {
-        rho_max = 16.0;                                         // device-resident matrices: no host view of the geometry
+        // device-resident matrices: no host view of the geometry.  Bound the corner ray from the intrinsics
+        // (new_k = f / fov, frame_transform.rs:37-51) and allow 15 degrees of stabilisation rotation on top (rays beyond it simply take the exact path).
+        const double hx = 0.5 * p0.output_width * (double)p0.fov / fmax(fabs((double)p0.f[0]), 1e-6) + fabs((double)p0.translation2d[0]) * (double)p0.fov / fmax(fabs((double)p0.f[0]), 1e-6);
+        const double hy = 0.5 * p0.output_height * (double)p0.fov / fmax(fabs((double)p0.f[1]), 1e-6) + fabs((double)p0.translation2d[1]) * (double)p0.fov / fmax(fabs((double)p0.f[1]), 1e-6);
+        const double ang = atan(sqrt(hx * hx + hy * hy)) + 0.26;
+        rho_max = ang < 1.45 ? tan(ang) * tan(ang) : 64.0;
     }
     if (!(rho_max == rho_max)) return false;
     if (rho_max > 64.0) rho_max = 64.0;
@@ -457,7 +489,7 @@ static bool p1_setup(gfw_ctx *c, const gfw_kernel_params &p0, const float *h_mat
 // Decide whether the frame qualifies for the fused YUV kernel and, if so, build its argument block.
 // Anything not proven here runs through the generic per-plane kernel (same results, slower).
 static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params, const int *pixel_types,
-                           const std::vector<GfwPlane> &launches, const float *h_matrices, int matrix_count, size_t mesh_len,
+                           const GfwPlane *launches, const float *h_matrices, int matrix_count, size_t mesh_len,
                            GfwYuvArgs &Y, int &bytes_per_sample, int &dw, int &dh, bool &interleaved, bool &fast1) {
     if (c->kernel_variant == 1) return false;                       // forced generic (tests / A-B benchmarking)
     if (nplanes < 1 || nplanes > 4 || mesh_len != 0) return false;
@@ -578,7 +610,10 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
                       const float *matrices, int matrix_count, const float *mesh, size_t mesh_len) {
     if (!c) { set_error("null context"); return GFW_ERR_INVALID_ARGUMENT; }
     if (nplanes < 1 || nplanes > 8) { set_error("nplanes %d", nplanes); return GFW_ERR_INVALID_ARGUMENT; }
-    HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
+    {   // hipSetDevice is not free; contexts are thread-affine, so remember what this thread last selected
+        static thread_local int tl_device = -1;
+        if (tl_device != c->device) { HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP); tl_device = c->device; }
+    }
     for (int i = 0; i < nplanes; ++i) {
         const int rc = validate_plane(&planes[i], &params[i], pixel_types[i]);
         if (rc != GFW_OK) return rc;
@@ -595,7 +630,8 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
     }
     if ((int)c->stage_src.size() < nplanes) { c->stage_src.resize(nplanes); c->stage_dst.resize(nplanes); }
 
-    std::vector<GfwPlane> launches(nplanes);
+    GfwPlane launches_arr[8];
+    GfwPlane *launches = launches_arr;
     for (int i = 0; i < nplanes; ++i) {
         const gfw_buffers &b = planes[i];
         GfwPlane &A = launches[i];
@@ -639,6 +675,7 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
         c->last_backend = "plane_generic";
     }
     prof_end(c);
+    { const int mrc = matrices_consumed(c); if (mrc != GFW_OK) return mrc; }
     if (c->ev_used > 4096) { (void)hipStreamSynchronize(c->stream); prof_harvest(c); }
 
     bool any_host_out = false;
@@ -704,4 +741,16 @@ long long gfw_debug_selftest(int test, unsigned long long n, unsigned long long 
     (void)hipFree(dbad);
     return (long long)bad;
 }
+}
+
+extern "C" int gfw_pack_matrices(const float *rows14, int count, float *rows16) {
+    if (!rows14 || !rows16 || count < 0) { set_error("null arrays"); return GFW_ERR_INVALID_ARGUMENT; }
+    for (int r = 0; r < count; ++r) {
+        const float *m = rows14 + (size_t)r * 14;
+        float *o = rows16 + (size_t)r * GFW_MAT_STRIDE;
+        memcpy(o, m, 14 * sizeof(float));
+        if (m[9] != 0.0f || m[10] != 0.0f || m[11] != 0.0f || m[12] != 0.0f || m[13] != 0.0f) { o[14] = cosf(-m[11]); o[15] = sinf(-m[11]); }
+        else { o[14] = 1.0f; o[15] = 0.0f; }
+    }
+    return GFW_OK;
 }

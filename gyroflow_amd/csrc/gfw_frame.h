@@ -14,7 +14,7 @@ struct GfwYuvPlane {
     int32_t pad_;
 };
 
-#define GFW_P1_TABLE_N 1024      // intervals of the first-pass s(rho) table
+#define GFW_P1_TABLE_N 2048      // intervals of the first-pass s(rho) table
 #define GFW_YUV_RB_FAST 4         // luma block rows per lane with the certified first pass (tile = 64 x 16 lanes-rows)
 #define GFW_YUV_RB_EXACT 1
 

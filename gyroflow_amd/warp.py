@@ -129,6 +129,39 @@ class Backend:
         self._check(self.lib.gfw_undistort_frame(self.ctx, n, barr, parr, tarr, mp, mc, meshp, meshn))
 
 
+def pack_matrices(matrices):
+    """[rows][14] f32 -> libgfwarp's packed [rows][16] layout (host libm trig for the IBIS slots)."""
+    m = np.ascontiguousarray(matrices, dtype=np.float32)
+    out = np.empty((m.shape[0], 16), dtype=np.float32)
+    rc = abi.load_library().gfw_pack_matrices(m.ctypes.data, m.shape[0], out.ctypes.data)
+    if rc != 0:
+        raise GfwError(rc, abi.load_library().gfw_last_error().decode())
+    return out
+
+
+class FrameCall:
+    """Pre-marshalled ``gfw_undistort_frame`` call (the per-frame hot loop of a renderer keeps these around so that
+    no ctypes objects are built per frame)."""
+
+    def __init__(self, backend, planes, params, pixel_types, matrices, matrix_count=None):
+        n = len(planes)
+        self.be, self.n = backend, n
+        self.barr = (abi.Buffers * n)(*planes)
+        self.parr = (abi.KernelParams * n)(*params)
+        self.tarr = (C.c_int * n)(*[abi.PIXEL_TYPES[t][0] if isinstance(t, str) else t for t in pixel_types])
+        if isinstance(matrices, np.ndarray):
+            self.m = np.ascontiguousarray(matrices, dtype=np.float32)
+            self.mp, self.mc = self.m.ctypes.data, self.m.shape[0]
+        else:                                       # device pointer (GFW_OPT_MATRICES_ON_DEVICE)
+            self.mp, self.mc = matrices, matrix_count
+        self.fn = backend.lib.gfw_undistort_frame
+
+    def __call__(self):
+        rc = self.fn(self.be.ctx, self.n, self.barr, self.parr, self.tarr, self.mp, self.mc, None, 0)
+        if rc != 0:
+            self.be._check(rc)
+
+
 def run_plane(src, in_size, dst, out_size, params, pixel_type, model, digital, matrices, mesh=None, **rects):
     """Convenience: create a backend, warp one HOST plane in place into ``dst``."""
     b = host_buffers(src, in_size, dst, out_size, **rects)

@@ -250,7 +250,10 @@ int gfw_undistort_frame(gfw_ctx *ctx, int nplanes,
 /* ---- options / stream ---------------------------------------------------*/
 enum {
     GFW_OPT_SYNCHRONOUS        = 1,  /* 1 (default): return after stream sync */
-    GFW_OPT_MATRICES_ON_DEVICE = 2,  /* 1: `matrices` is a device pointer */
+    GFW_OPT_MATRICES_ON_DEVICE = 2,  /* 0: host rows of [f32;14] (default, uploaded per call like opencl.rs:406);
+                                        1: device pointer, rows of [f32;14]; 2: device pointer, rows of 16 floats as
+                                        written by gfw_pack_matrices (no per-call work at all).  With 1 and 2 the
+                                        IBIS terms m[9..13] are honoured only if GFW_FLAG_HAS_IBIS_DATA is set. */
     GFW_OPT_KERNEL_VARIANT     = 3,  /* 0 auto; 1 generic per-plane kernel; 2 fused kernel with the exact first pass;
                                         3 fused kernel, certified first pass in audit mode (see gfw_get_audit) */
     GFW_OPT_PROFILE            = 4,  /* 1: bracket every warp-kernel launch with hipEvents on the context stream */
@@ -274,6 +277,12 @@ int   gfw_get_profile(gfw_ctx *ctx, double *kernel_ms, int64_t *launches, int re
 
 /* Thread-local, human-readable description of the last failure. */
 const char *gfw_last_error(void);
+
+/* Host helper: FrameTransform.matrices rows ([f32;14]) -> libgfwarp's 64-byte device row layout
+ * (m0..m13, cosf(-m11), sinf(-m11) evaluated with the host libm as cpu_undistort.rs:159-160 does).  A pipeline that
+ * knows its FrameTransforms ahead of time packs them once, keeps them in HBM and passes the device pointer with
+ * GFW_OPT_MATRICES_ON_DEVICE = 2. */
+int   gfw_pack_matrices(const float *rows14, int count, float *rows16);
 
 /* ---- test hooks (used by tests/test_gpu_math.py; not part of the operator surface) ---------------
  * gfw_debug_math: out[i] = f(a[i], b[i]) evaluated ON THE DEVICE with the kernels' own routines; host arrays.
