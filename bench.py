@@ -134,7 +134,7 @@ def main():
         "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 coordinates, u16 pixels", "data": "synthetic",
-        "config": {"workload": "C2: %dx%d %s (3 x Luma16), opencv_fisheye GoPro-style lens, rolling shutter "
+        "config": {"workload": ("C2" if (W, H) == (3840, 2160) else "C3" if (W, H) == (7680, 4320) else "custom") + ": %dx%d %s, opencv_fisheye GoPro-style lens, rolling shutter "
                                "matrix_count=%d, bilinear, frames + per-row matrix tables resident in HBM%s"
                                % (W, H, args.fmt, frames[0].matrices.shape[0], " (matrices re-uploaded per frame)" if args.upload_matrices else ""),
                    "frames_per_rank": args.steps, "parallelism": "frame-sharded x%d" % world,
