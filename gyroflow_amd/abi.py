@@ -76,6 +76,13 @@ PIXEL_TYPES = {
 BUF_NONE, BUF_HOST, BUF_HIP_DEVICE = 0, 1, 2
 
 
+class FrameTiming(C.Structure):
+    """``gfw_frame_timing``: inputs of the device-side per-row matrix builder."""
+    _fields_ = [("timestamp_ms", C.c_double), ("per_frame_time_offset_ms", C.c_double), ("frame_readout_time_ms", C.c_double),
+                ("new_k", C.c_double * 9), ("video_rotation_deg", C.c_double), ("rows", C.c_int32), ("readout_dim", C.c_int32),
+                ("framebuffer_inverted", C.c_int32), ("pad_", C.c_int32)]
+
+
 class BufferDesc(C.Structure):
     """``BufferDescription`` (gpu/mod.rs:17-24)."""
     _fields_ = [
@@ -124,6 +131,8 @@ def bind(lib):
     lib.gfw_synchronize.argtypes = [vp]; lib.gfw_synchronize.restype = i32
     lib.gfw_last_backend.argtypes = [vp]; lib.gfw_last_backend.restype = C.c_char_p
     lib.gfw_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]; lib.gfw_get_profile.restype = i32
+    lib.gfw_set_quaternion_tracks.argtypes = [vp, vp, vp, i32, vp, vp, i32]; lib.gfw_set_quaternion_tracks.restype = i32
+    lib.gfw_build_matrices.argtypes = [vp, C.POINTER(FrameTiming), vp, C.POINTER(vp)]; lib.gfw_build_matrices.restype = i32
     lib.gfw_pack_matrices.argtypes = [vp, i32, vp]; lib.gfw_pack_matrices.restype = i32
     lib.gfw_get_audit.argtypes = [vp, C.POINTER(C.c_ulonglong * 8), i32]; lib.gfw_get_audit.restype = i32
     lib.gfw_debug_math.argtypes = [i32, vp, vp, vp, sz]; lib.gfw_debug_math.restype = i32
@@ -136,7 +145,7 @@ def bind(lib):
 
 EXPORTS = ["gfw_abi_version", "gfw_list_devices", "gfw_set_device", "gfw_get_info", "gfw_is_buffer_supported",
            "gfw_create", "gfw_destroy", "gfw_undistort_image", "gfw_undistort_frame", "gfw_set_option",
-           "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_last_backend", "gfw_get_profile", "gfw_last_error", "gfw_debug_math", "gfw_debug_selftest", "gfw_get_audit", "gfw_pack_matrices",
+           "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_last_backend", "gfw_get_profile", "gfw_last_error", "gfw_debug_math", "gfw_debug_selftest", "gfw_get_audit", "gfw_pack_matrices", "gfw_set_quaternion_tracks", "gfw_build_matrices",
            "gfw_pixel_type_info"]
 
 

@@ -17,6 +17,7 @@
 #include "../../include/gfwarp.h"
 #include "gfw_launch.h"
 #include "gfw_frame.h"
+#include "gfw_matrices.h"
 #include <map>
 #include <mutex>
 
@@ -85,6 +86,8 @@ struct gfw_ctx {
     // certified first pass of the fused kernel: s(rho) table cache
     DevBuf d_p1_table, d_audit;
     float p1_k[4] = {0, 0, 0, 0}; float p1_rho_max = 0.0f; double p1_etab = 0.0; double p1_smax = 1.0; bool p1_valid = false;
+    DevBuf d_tracks, d_built_rows;                // quaternion tracks + context-owned table of built rows
+    GfwTracks tracks = {nullptr, nullptr, 0, nullptr, nullptr, 0};
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;   // recorded, not yet harvested
     size_t ev_used = 0;
@@ -223,7 +226,7 @@ void gfw_destroy(gfw_ctx *c) {
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &b : c->stage_src) b.release();
     for (auto &b : c->stage_dst) b.release();
-    c->d_mesh.release(); c->d_p1_table.release(); c->d_audit.release();
+    c->d_mesh.release(); c->d_p1_table.release(); c->d_audit.release(); c->d_tracks.release(); c->d_built_rows.release();
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (auto &s : c->mslots) {
         if (s.h) (void)hipHostFree(s.h);
@@ -753,4 +756,36 @@ extern "C" int gfw_pack_matrices(const float *rows14, int count, float *rows16) 
         else { o[14] = 1.0f; o[15] = 0.0f; }
     }
     return GFW_OK;
+}
+
+extern "C" {
+int gfw_set_quaternion_tracks(gfw_ctx *c, const int64_t *org_ts, const double *org_q, int org_n,
+                              const int64_t *sm_ts, const double *sm_q, int sm_n) {
+    if (!c || org_n < 0 || sm_n < 0 || (org_n && (!org_ts || !org_q)) || (sm_n && (!sm_ts || !sm_q))) { set_error("bad track arguments"); return GFW_ERR_INVALID_ARGUMENT; }
+    for (int i = 1; i < org_n; ++i) if (org_ts[i] <= org_ts[i - 1]) { set_error("original track timestamps must ascend"); return GFW_ERR_INVALID_ARGUMENT; }
+    for (int i = 1; i < sm_n; ++i) if (sm_ts[i] <= sm_ts[i - 1]) { set_error("smoothed track timestamps must ascend"); return GFW_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
+    const size_t b0 = (size_t)org_n * 8, b1 = (size_t)org_n * 32, b2 = (size_t)sm_n * 8, b3 = (size_t)sm_n * 32;
+    HIP_TRY(c->d_tracks.ensure(b0 + b1 + b2 + b3 + 64), GFW_ERR_HIP);
+    HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
+    char *base = (char *)c->d_tracks.ptr;
+    if (org_n) { HIP_TRY(hipMemcpy(base, org_ts, b0, hipMemcpyHostToDevice), GFW_ERR_HIP); HIP_TRY(hipMemcpy(base + b0, org_q, b1, hipMemcpyHostToDevice), GFW_ERR_HIP); }
+    if (sm_n) { HIP_TRY(hipMemcpy(base + b0 + b1, sm_ts, b2, hipMemcpyHostToDevice), GFW_ERR_HIP); HIP_TRY(hipMemcpy(base + b0 + b1 + b2, sm_q, b3, hipMemcpyHostToDevice), GFW_ERR_HIP); }
+    c->tracks = GfwTracks{(const int64_t *)base, (const double *)(base + b0), org_n, (const int64_t *)(base + b0 + b1), (const double *)(base + b0 + b1 + b2), sm_n};
+    return GFW_OK;
+}
+int gfw_build_matrices(gfw_ctx *c, const gfw_frame_timing *t, float *rows16_out, float **out_ptr) {
+    if (!c || !t) { set_error("null context/timing"); return GFW_ERR_INVALID_ARGUMENT; }
+    if (t->rows < 1 || t->readout_dim < 1) { set_error("rows %d, readout_dim %d", t->rows, t->readout_dim); return GFW_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
+    float *out = rows16_out;
+    if (!out) {
+        HIP_TRY(c->d_built_rows.ensure((size_t)t->rows * GFW_MAT_STRIDE * sizeof(float)), GFW_ERR_HIP);
+        out = (float *)c->d_built_rows.ptr;
+    }
+    HIP_TRY(gfw_launch_build_matrices(c->tracks, *t, out, c->stream), GFW_ERR_HIP);
+    if (out_ptr) *out_ptr = out;
+    if (c->synchronous) HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
+    return GFW_OK;
+}
 }

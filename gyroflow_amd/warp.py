@@ -95,6 +95,25 @@ class Backend:
         gap = float(np.array([int(arr[4]) & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0])
         return int(arr[0]), int(arr[1]), int(arr[2]), int(arr[3]), gap
 
+    def set_quaternion_tracks(self, org, smoothed):
+        """Upload (timestamps_us int64, quaternions f64[n,4]) tracks once per clip (device matrix builder)."""
+        ot, oq = np.ascontiguousarray(org[0], dtype=np.int64), np.ascontiguousarray(org[1], dtype=np.float64)
+        st, sq = np.ascontiguousarray(smoothed[0], dtype=np.int64), np.ascontiguousarray(smoothed[1], dtype=np.float64)
+        self._check(self.lib.gfw_set_quaternion_tracks(self.ctx, ot.ctypes.data, oq.ctypes.data, len(ot), st.ctypes.data, sq.ctypes.data, len(st)))
+
+    def build_matrices(self, nk, timestamp_ms, frame_readout_time_ms, rows, readout_dim, video_rotation_deg=0.0,
+                       framebuffer_inverted=False, per_frame_offset_ms=0.0, out_ptr=None):
+        """Build one frame's packed rows on the device; returns the device pointer (context-owned unless out_ptr given)."""
+        t = abi.FrameTiming()
+        t.timestamp_ms, t.per_frame_time_offset_ms, t.frame_readout_time_ms = timestamp_ms, per_frame_offset_ms, frame_readout_time_ms
+        for i, v in enumerate(np.asarray(nk, dtype=np.float64).reshape(9)):
+            t.new_k[i] = v
+        t.video_rotation_deg, t.rows, t.readout_dim = video_rotation_deg, rows, readout_dim
+        t.framebuffer_inverted = 1 if framebuffer_inverted else 0
+        ptr = C.c_void_p(0)
+        self._check(self.lib.gfw_build_matrices(self.ctx, C.byref(t), out_ptr, C.byref(ptr)))
+        return ptr.value
+
     def synchronize(self):
         self._check(self.lib.gfw_synchronize(self.ctx))
 

@@ -284,6 +284,28 @@ const char *gfw_last_error(void);
  * GFW_OPT_MATRICES_ON_DEVICE = 2. */
 int   gfw_pack_matrices(const float *rows14, int count, float *rows16);
 
+/* ---- per-row matrices on the device ("next" row: FrameTransform::at_timestamp, frame_transform.rs:221-308) ----
+ * gfw_set_quaternion_tracks uploads the clip's original and smoothed orientation tracks once
+ * (GyroSource.quaternions / smoothed_quaternions: BTreeMap<i64 timestamp_us, Quat64>, gyro_source/mod.rs:857-882);
+ * gfw_build_matrices then produces the packed rows of one frame directly in HBM (device pointer `rows16_out`, or a
+ * context-owned table when NULL; its address is returned through `*out_ptr`) to be passed to
+ * gfw_undistort_image/frame with GFW_OPT_MATRICES_ON_DEVICE = 2.  IBIS/OIS spline terms are not covered (rows get
+ * zeros there).  Results equal the host f64 statement to ~1 ULP of f32 (SVD vs closed-form inverse). */
+typedef struct gfw_frame_timing {
+    double timestamp_ms;               /* frame centre */
+    double per_frame_time_offset_ms;   /* file_metadata.per_frame_time_offsets[frame] */
+    double frame_readout_time_ms;      /* signed, as get_frame_readout_time returns it */
+    double new_k[9];                   /* get_new_k(), row-major (frame_transform.rs:37-51) */
+    double video_rotation_deg;
+    int32_t rows;                      /* matrix_count: H, W (horizontal readout) or 1 */
+    int32_t readout_dim;               /* divisor of the row readout time: height, or width for horizontal readout */
+    int32_t framebuffer_inverted;
+    int32_t pad_;
+} gfw_frame_timing;
+int   gfw_set_quaternion_tracks(gfw_ctx *ctx, const int64_t *org_ts_us, const double *org_wxyz, int org_count,
+                                const int64_t *smoothed_ts_us, const double *smoothed_wxyz, int smoothed_count);
+int   gfw_build_matrices(gfw_ctx *ctx, const gfw_frame_timing *timing, float *rows16_out, float **out_ptr);
+
 /* ---- test hooks (used by tests/test_gpu_math.py; not part of the operator surface) ---------------
  * gfw_debug_math: out[i] = f(a[i], b[i]) evaluated ON THE DEVICE with the kernels' own routines; host arrays.
  *   op 0 gfw_atanf  1 gfw_tanf  2 gfw_atanf_pos  3 lean a/b  4 generic a/b  5 lean sqrt  6 generic sqrt
