@@ -493,17 +493,28 @@ static bool p1_setup(gfw_ctx *c, const gfw_kernel_params &p0, const float *h_mat
 // Anything not proven here runs through the generic per-plane kernel (same results, slower).
 static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params, const int *pixel_types,
                            const GfwPlane *launches, const float *h_matrices, int matrix_count, size_t mesh_len,
-                           GfwYuvArgs &Y, int &bytes_per_sample, int &dw, int &dh, bool &interleaved, bool &fast1) {
+                           GfwYuvArgs &Y, int &bytes_per_sample, int &n0, int &dw, int &dh, bool &interleaved, bool &fast1) {
     if (c->kernel_variant == 1) return false;                       // forced generic (tests / A-B benchmarking)
     if (nplanes < 1 || nplanes > 4 || mesh_len != 0) return false;
     const gfw_kernel_params &p0 = params[0];
     const int t0 = pixel_types[0];
-    if (t0 != GFW_PIX_LUMA8 && t0 != GFW_PIX_LUMA16) return false;
-    bytes_per_sample = (t0 == GFW_PIX_LUMA8) ? 1 : 2;
+    // plane 0: sample kind (1 = u8, 2 = u16, 4 = f32) and channel count; RGBAf16 / UV-as-plane-0 stay on the generic kernel
+    switch (t0) {
+    case GFW_PIX_LUMA8:  bytes_per_sample = 1; n0 = 1; break;
+    case GFW_PIX_LUMA16: bytes_per_sample = 2; n0 = 1; break;
+    case GFW_PIX_RGB8:   bytes_per_sample = 1; n0 = 3; break;
+    case GFW_PIX_RGBA8: case GFW_PIX_BGRA8: bytes_per_sample = 1; n0 = 4; break;
+    case GFW_PIX_RGB16:  bytes_per_sample = 2; n0 = 3; break;
+    case GFW_PIX_RGBA16: case GFW_PIX_AYUV16: bytes_per_sample = 2; n0 = 4; break;
+    case GFW_PIX_RGBAF:  bytes_per_sample = 4; n0 = 4; break;
+    case GFW_PIX_R32F:   bytes_per_sample = 4; n0 = 1; break;
+    default: return false;
+    }
+    if (n0 > 1 && nplanes != 1) return false;
     interleaved = false;
     if (nplanes >= 2) {
         const int t1 = pixel_types[1];
-        if (t1 == (bytes_per_sample == 1 ? GFW_PIX_UV8 : GFW_PIX_UV16)) { if (nplanes != 2) return false; interleaved = true; }
+        if (bytes_per_sample != 4 && t1 == (bytes_per_sample == 1 ? GFW_PIX_UV8 : GFW_PIX_UV16)) { if (nplanes != 2) return false; interleaved = true; }
         else { for (int i = 1; i < nplanes; ++i) if (pixel_types[i] != t0) return false; }
     }
     if (c->digital != GFW_MODEL_NONE && (p0.flags & GFW_FLAG_HAS_DIGITAL_LENS)) return false;
@@ -532,6 +543,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
         if ((int64_t)b.output.width * p.bytes_per_pixel > b.output.stride) return false;
         // rows of the buffer beyond the plane would be visited (and skipped) by the reference; require none carry pixels
         if ((bytes_per_sample == 2) && ((p.stride | b.output.stride) & 1)) return false;
+        if ((bytes_per_sample == 4) && ((p.stride | b.output.stride) & 3)) return false;
         if ((int64_t)b.input.height * p.stride >= (1ll << 31) || (int64_t)b.output.height * b.output.stride >= (1ll << 31)) return false;   // 32-bit offsets
     }
     // stretch divisions (cpu_undistort.rs:222-223) other than "skipped" (<= 0.001) or the identity x/1 go the generic way
@@ -550,6 +562,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
         if (cw <= 0 || ch <= 0 || p0.output_width % cw || p0.output_height % ch) return false;
         dw = p0.output_width / cw; dh = p0.output_height / ch;
         if (!((dw == 1 && dh == 1) || (dw == 2 && dh == 1) || (dw == 2 && dh == 2))) return false;
+        if (bytes_per_sample == 4 && !(dw == 1 && dh == 1)) return false;
         for (int i = 1; i < nplanes; ++i) {
             if (planes[i].output.width != cw || planes[i].output.height != ch) return false;
             if (planes[i].input.width * dw != p0.width || planes[i].input.height * dh != p0.height) return false;
@@ -577,8 +590,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
         P.src = launches[i].src; P.dst = launches[i].dst;
         P.src_stride = params[i].stride; P.dst_stride = planes[i].output.stride;
         P.w = planes[i].input.width; P.h = planes[i].input.height;
-        P.bg[0] = params[i].background[0] * params[i].max_pixel_value;
-        P.bg[1] = params[i].background[1] * params[i].max_pixel_value;
+        for (int ch = 0; ch < 4; ++ch) P.bg[ch] = params[i].background[ch] * params[i].max_pixel_value;
         P.limit = params[i].pixel_value_limit;
     }
     Y.nplanes = nplanes;
@@ -661,14 +673,14 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
 
     GfwCommon C;
     GfwYuvArgs Y;
-    int bps = 0, dw = 1, dh = 1; bool interleaved = false, fast1 = false;
+    int bps = 0, n0 = 1, dw = 1, dh = 1; bool interleaved = false, fast1 = false;
     const bool fused = build_yuv_args(c, nplanes, planes, params, pixel_types, launches, c->matrices_on_device ? nullptr : matrices,
-                                      matrix_count, mesh_len, Y, bps, dw, dh, interleaved, fast1);
+                                      matrix_count, mesh_len, Y, bps, n0, dw, dh, interleaved, fast1);
     prof_begin(c);
     if (fused) {
         fill_common(c, &params[0], d_mat, nullptr, 0, Y.common);
         Y.matrices = d_mat;
-        HIP_TRY(gfw_launch_yuv(Y, bps, dw, dh, interleaved, fast1, gfw_yuv_rows_per_lane(fast1, Y.audit ? 0 : c->tune_rb), c->stream), GFW_ERR_HIP);
+        HIP_TRY(gfw_launch_yuv(Y, bps, n0, dw, dh, interleaved, fast1, c->stream), GFW_ERR_HIP);
         c->last_backend = fast1 ? "yuv_fused_p1" : "yuv_fused";
     } else {
         for (int i = 0; i < nplanes; ++i) {

@@ -9,9 +9,9 @@ struct GfwYuvPlane {
     uint8_t *dst;
     int32_t src_stride, dst_stride;   // bytes
     int32_t w, h;                     // source plane size (= source_rect w,h)
-    float bg[2];                      // background[c] * max_pixel_value
+    float bg[4];                      // background[c] * max_pixel_value
     float limit;                      // pixel_value_limit
-    int32_t pad_;
+    int32_t pad_[3];
 };
 
 #define GFW_P1_TABLE_N 2048      // intervals of the first-pass s(rho) table
@@ -49,4 +49,4 @@ struct GfwYuvArgs {
 };
 
 int gfw_yuv_rows_per_lane(bool fast1, int tune_rb);
-hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int bytes_per_sample, int dw, int dh, bool interleaved, bool fast1, int rb, hipStream_t s);
+hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int sample_kind, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s);

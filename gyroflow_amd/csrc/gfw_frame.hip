@@ -180,23 +180,36 @@ __device__ __forceinline__ void taps_edge(const uint8_t *src, int stride, const 
         out[c] = fminf(sum, limit);
     }
 }
-// All four taps inside: 0 + x is exact for the non-negative taps, so the leading zero-adds are dropped.
+template <typename T> struct is_f32 { static constexpr bool value = false; };
+template <> struct is_f32<float> { static constexpr bool value = true; };
+// All four taps inside.  For the integer pixel types every tap is >= +0, so the reference's leading zero-adds
+// (xsum = 0 + p*c, sum = 0 + xs*cy) are exact identities and are dropped; for f32 pixels (-0, negative values) they stay.
 template <typename T, int N>
 __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int stride, const Bins &b, float limit, float *out) {
     const T *row0 = reinterpret_cast<const T *>(src + (int64_t)off0);
     const T *row1 = reinterpret_cast<const T *>(src + (int64_t)(off0 + stride));
     #pragma unroll
     for (int c = 0; c < N; ++c) {
-        const float xs0 = (float)row0[c] * b.cx0 + (float)row0[N + c] * b.cx1;
-        const float xs1 = (float)row1[c] * b.cx0 + (float)row1[N + c] * b.cx1;
-        out[c] = fminf(xs0 * b.cy0 + xs1 * b.cy1, limit);
+        if (is_f32<T>::value) {
+            float xs0 = 0.0f; xs0 = xs0 + (float)row0[c] * b.cx0; xs0 = xs0 + (float)row0[N + c] * b.cx1;
+            float xs1 = 0.0f; xs1 = xs1 + (float)row1[c] * b.cx0; xs1 = xs1 + (float)row1[N + c] * b.cx1;
+            float sum = 0.0f; sum = sum + xs0 * b.cy0; sum = sum + xs1 * b.cy1;
+            out[c] = fminf(sum, limit);
+        } else {
+            const float xs0 = (float)row0[c] * b.cx0 + (float)row0[N + c] * b.cx1;
+            const float xs1 = (float)row1[c] * b.cx0 + (float)row1[N + c] * b.cx1;
+            out[c] = fminf(xs0 * b.cy0 + xs1 * b.cy1, limit);
+        }
     }
 }
 template <typename T, int N>
 __device__ __forceinline__ void store_px(uint8_t *dst, int off, const float *v) {
     T *d = reinterpret_cast<T *>(dst + (int64_t)off);
     #pragma unroll
-    for (int c = 0; c < N; ++c) d[c] = (T)gfw_f2u_sat(v[c], sizeof(T) == 1 ? 255.0f : 65535.0f);
+    for (int c = 0; c < N; ++c) {
+        if (is_f32<T>::value) d[c] = (T)v[c];                                   // f32 pixels pass through (pixel_formats.rs:247,296)
+        else d[c] = (T)gfw_f2u_sat(v[c], sizeof(T) == 1 ? 255.0f : 65535.0f);    // `as u8/u16`
+    }
 }
 // One plane.  32-bit byte offsets from the uniform plane base (planes are < 2 GiB, checked on the host).
 template <typename T, int N>
@@ -213,25 +226,29 @@ __device__ __forceinline__ void sample_store(float u, float v, bool ok, const Gf
     }
     store_px<T, N>(P.dst, oy * P.dst_stride + ox * (int)(N * sizeof(T)), out);
 }
-// Two planar chroma planes of identical geometry: one set of bins / weights / offsets, two gathers.
+// Planar planes of identical geometry (U and V; or G,B,R,A of a planar float frame): one set of bins / weights /
+// offsets, one gather pair per plane.
 template <typename T>
-__device__ __forceinline__ void sample_store_uv(float u, float v, bool ok, const GfwYuvPlane &PU, const GfwYuvPlane &PV,
-                                                float bg_u, float bg_v, float lim_u, float lim_v, int ox, int oy) {
-    float ou = bg_u, ov = bg_v;
+__device__ __forceinline__ void sample_store_shared(float u, float v, bool ok, const GfwYuvPlane *pl, int first, int last, int ox, int oy) {
+    const GfwYuvPlane &P0 = pl[first];
+    Bins b = {0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
+    bool inside = false;
+    int off0 = 0;
     if (ok) {
-        const Bins b = make_bins(u, v);
-        if (__builtin_expect((unsigned)b.sx < (unsigned)(PU.w - 1) && (unsigned)b.sy < (unsigned)(PU.h - 1), 1)) {
-            const int off0 = b.sy * PU.src_stride + b.sx * (int)sizeof(T);
-            taps_inside<T, 1>(PU.src, off0, PU.src_stride, b, lim_u, &ou);
-            taps_inside<T, 1>(PV.src, off0, PU.src_stride, b, lim_v, &ov);
-        } else {
-            taps_edge<T, 1>(PU.src, PU.src_stride, b, PU.w, PU.h, &bg_u, lim_u, &ou);
-            taps_edge<T, 1>(PV.src, PU.src_stride, b, PU.w, PU.h, &bg_v, lim_v, &ov);
-        }
+        b = make_bins(u, v);
+        inside = (unsigned)b.sx < (unsigned)(P0.w - 1) && (unsigned)b.sy < (unsigned)(P0.h - 1);
+        off0 = b.sy * P0.src_stride + b.sx * (int)sizeof(T);
     }
-    const int doff = oy * PU.dst_stride + ox * (int)sizeof(T);
-    store_px<T, 1>(PU.dst, doff, &ou);
-    store_px<T, 1>(PV.dst, doff, &ov);
+    const int doff = oy * P0.dst_stride + ox * (int)sizeof(T);
+    #pragma unroll 1
+    for (int pi = first; pi <= last; ++pi) {
+        float o = pl[pi].bg[0];
+        if (ok) {
+            if (__builtin_expect(inside, 1)) taps_inside<T, 1>(pl[pi].src, off0, P0.src_stride, b, pl[pi].limit, &o);
+            else taps_edge<T, 1>(pl[pi].src, P0.src_stride, b, P0.w, P0.h, pl[pi].bg, pl[pi].limit, &o);
+        }
+        store_px<T, 1>(pl[pi].dst, doff, &o);
+    }
 }
 
 // ---- first pass (rolling-shutter row pick) -----------------------------------------------------------------
@@ -288,7 +305,7 @@ __device__ __forceinline__ bool pass1_fast(float ax, float ay, float aw, float o
     return good;
 }
 
-template <int MODEL, typename T, int DW, int DH, bool INTERLEAVED_UV, int RB, bool FAST1, bool AUDIT>
+template <int MODEL, typename T, int N0, int DW, int DH, bool INTERLEAVED_UV, int RB, bool FAST1, bool AUDIT>
 __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
     // tile = 64 x 4 lanes; each lane owns RB vertically stacked DW x DH luma blocks (+ their chroma sites).
     constexpr int NPX = DW * DH;
@@ -310,9 +327,12 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
     Maps MP;
     MP.mul_lx = vu(A.map_lx.mul); MP.mul_ly = vu(A.map_ly.mul); MP.mul_cx = vu(A.map_cx.mul); MP.mul_cy = vu(A.map_cy.mul);
     MP.den_x = vu(A.map_lx.den); MP.rcp_x = vu(A.map_lx.rcp); MP.den_y = vu(A.map_ly.den); MP.rcp_y = vu(A.map_ly.rcp);
-    float bg_y = vu(A.pl[0].bg[0]), lim_y = vu(A.pl[0].limit);
-    float bg_c[2] = {vu(A.pl[1].bg[0]), vu(INTERLEAVED_UV ? A.pl[1].bg[1] : A.pl[2].bg[0])};
-    float lim_u = vu(A.pl[1].limit), lim_v = vu(INTERLEAVED_UV ? A.pl[1].limit : A.pl[2].limit);
+    float bg_y[N0];
+    #pragma unroll
+    for (int c = 0; c < N0; ++c) bg_y[c] = vu(A.pl[0].bg[c]);
+    const float lim_y = vu(A.pl[0].limit);
+    float bg_c[2] = {vu(A.pl[1].bg[0]), vu(A.pl[1].bg[1])};
+    const float lim_u = vu(A.pl[1].limit);
     Mid M{0, 0, 0, 0, 0, 0, 0, 0, 0};
     P1 Q{0, 0, 0, 0, 0, 0};
     if (two_pass) {
@@ -412,16 +432,12 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
                     if (k == 0) { u0 = p.x; v0 = p.y; ok0 = p.ok; }
                     const float lu = map_c(p.x, MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c(p.y, MP.mul_ly, MP.den_y, MP.rcp_y);   // cpu_undistort.rs:511-514
                     if (A.ablate & 2) { if (lane == 99) A.pl[0].dst[0] = (uint8_t)(lu + lv); continue; }  // timing ablation only
-                    sample_store<T, 1>(lu, lv, p.ok, A.pl[0], &bg_y, lim_y, lx, ly);
+                    sample_store<T, N0>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly);
                 }
                 if (A.nplanes > 1 && !(A.ablate & 4)) {
                     const float cu = map_c(u0, MP.mul_cx, MP.den_x, MP.rcp_x), cv = map_c(v0, MP.mul_cy, MP.den_y, MP.rcp_y);
                     if (INTERLEAVED_UV) sample_store<T, 2>(cu, cv, ok0, A.pl[1], bg_c, lim_u, cx, cy);
-                    else if (A.nplanes == 3) sample_store_uv<T>(cu, cv, ok0, A.pl[1], A.pl[2], bg_c[0], bg_c[1], lim_u, lim_v, cx, cy);
-                    else {
-                        #pragma unroll 1
-                        for (int pi = 1; pi < A.nplanes; ++pi) { const float bgp = A.pl[pi].bg[0]; sample_store<T, 1>(cu, cv, ok0, A.pl[pi], &bgp, A.pl[pi].limit, cx, cy); }
-                    }
+                    else sample_store_shared<T>(cu, cv, ok0, A.pl, 1, A.nplanes - 1, cx, cy);
                 }
             }
         }
@@ -429,7 +445,7 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
     }
 }
 
-template <int MODEL, typename T, int RB, bool FAST1, bool AUDIT>
+template <int MODEL, typename T, int N0, int RB, bool FAST1, bool AUDIT>
 hipError_t launch_mt(const GfwYuvArgs &A, int dw, int dh, bool interleaved, hipStream_t s) {
     const int n_tiles = A.tiles_x * A.tiles_y;
     if (n_tiles <= 0) return hipSuccess;
@@ -439,44 +455,58 @@ hipError_t launch_mt(const GfwYuvArgs &A, int dw, int dh, bool interleaved, hipS
     if (grid > per_xcd * 8) grid = per_xcd * 8;
     grid = (grid + 7) & ~7;
     dim3 block(64, 4);
-#define GFW_YUV_LAUNCH(DW, DH, IL) hipLaunchKernelGGL((gfw_yuv_kernel<MODEL, T, DW, DH, IL, RB, FAST1, AUDIT>), dim3(grid), block, 0, s, A)
-    if (dw == 2 && dh == 1 && !interleaved) GFW_YUV_LAUNCH(2, 1, false);
-    else if (dw == 2 && dh == 1 && interleaved) GFW_YUV_LAUNCH(2, 1, true);
-    else if (dw == 2 && dh == 2 && !interleaved) GFW_YUV_LAUNCH(2, 2, false);
-    else if (dw == 2 && dh == 2 && interleaved) GFW_YUV_LAUNCH(2, 2, true);
-    else if (dw == 1 && dh == 1 && !interleaved) GFW_YUV_LAUNCH(1, 1, false);
-    else if (dw == 1 && dh == 1 && interleaved) GFW_YUV_LAUNCH(1, 1, true);
-    else return hipErrorInvalidValue;
+#define GFW_YUV_LAUNCH(DW, DH, IL) hipLaunchKernelGGL((gfw_yuv_kernel<MODEL, T, N0, DW, DH, IL, RB, FAST1, AUDIT>), dim3(grid), block, 0, s, A)
+    if (N0 > 1 || is_f32<T>::value) {                    // packed single plane, or planar f32 planes: full resolution only
+        if (dw == 1 && dh == 1 && !interleaved) GFW_YUV_LAUNCH(1, 1, false);
+        else return hipErrorInvalidValue;
+    } else {
+        if (dw == 2 && dh == 1 && !interleaved) GFW_YUV_LAUNCH(2, 1, false);
+        else if (dw == 2 && dh == 1 && interleaved) GFW_YUV_LAUNCH(2, 1, true);
+        else if (dw == 2 && dh == 2 && !interleaved) GFW_YUV_LAUNCH(2, 2, false);
+        else if (dw == 2 && dh == 2 && interleaved) GFW_YUV_LAUNCH(2, 2, true);
+        else if (dw == 1 && dh == 1 && !interleaved) GFW_YUV_LAUNCH(1, 1, false);
+        else if (dw == 1 && dh == 1 && interleaved) GFW_YUV_LAUNCH(1, 1, true);
+        else return hipErrorInvalidValue;
+    }
 #undef GFW_YUV_LAUNCH
     return hipGetLastError();
 }
 
 }  // namespace
 
-int gfw_yuv_rows_per_lane(bool fast1, int tune_rb) {
-    if (!fast1) return GFW_YUV_RB_EXACT;
-    return (tune_rb == 1 || tune_rb == 2 || tune_rb == 4 || tune_rb == 8) ? tune_rb : GFW_YUV_RB_FAST;
+template <int MODEL, typename T, int N0>
+static hipError_t launch_tn(const GfwYuvArgs &A, int dw, int dh, bool interleaved, bool fast1, hipStream_t s) {
+    if (MODEL == GFW_MODEL_OPENCV_FISHEYE && fast1) {
+        if (A.audit) return launch_mt<MODEL, T, N0, GFW_YUV_RB_FAST, true, true>(A, dw, dh, interleaved, s);
+        return launch_mt<MODEL, T, N0, GFW_YUV_RB_FAST, true, false>(A, dw, dh, interleaved, s);
+    }
+    return launch_mt<MODEL, T, N0, GFW_YUV_RB_EXACT, false, false>(A, dw, dh, interleaved, s);
+}
+// This translation unit is compiled once per sample kind (-DGFW_FRAME_KIND=1|2|4: u8, u16, f32) so that the three
+// families of instantiations build in parallel; gfw_kernels.hip dispatches on the kind.
+#ifndef GFW_FRAME_KIND
+#error "compile with -DGFW_FRAME_KIND=1, 2 or 4"
+#endif
+template <int MODEL>
+static hipError_t launch_m(const GfwYuvArgs &A, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s) {
+#if GFW_FRAME_KIND == 1
+    if (n0 == 1) return launch_tn<MODEL, uint8_t, 1>(A, dw, dh, interleaved, fast1, s);
+    if (n0 == 3) return launch_tn<MODEL, uint8_t, 3>(A, dw, dh, interleaved, fast1, s);
+    if (n0 == 4) return launch_tn<MODEL, uint8_t, 4>(A, dw, dh, interleaved, fast1, s);
+#elif GFW_FRAME_KIND == 2
+    if (n0 == 1) return launch_tn<MODEL, uint16_t, 1>(A, dw, dh, interleaved, fast1, s);
+    if (n0 == 3) return launch_tn<MODEL, uint16_t, 3>(A, dw, dh, interleaved, fast1, s);
+    if (n0 == 4) return launch_tn<MODEL, uint16_t, 4>(A, dw, dh, interleaved, fast1, s);
+#else
+    if (n0 == 1) return launch_tn<MODEL, float, 1>(A, dw, dh, interleaved, fast1, s);
+    if (n0 == 4) return launch_tn<MODEL, float, 4>(A, dw, dh, interleaved, fast1, s);
+#endif
+    return hipErrorInvalidValue;
 }
 
-template <int MODEL, typename T>
-static hipError_t launch_fast(const GfwYuvArgs &A, int dw, int dh, bool interleaved, int rb, hipStream_t s) {
-    if (A.audit) return launch_mt<MODEL, T, GFW_YUV_RB_FAST, true, true>(A, dw, dh, interleaved, s);
-    switch (rb) {
-    case 1: return launch_mt<MODEL, T, 1, true, false>(A, dw, dh, interleaved, s);
-    case 2: return launch_mt<MODEL, T, 2, true, false>(A, dw, dh, interleaved, s);
-    case 8: return launch_mt<MODEL, T, 8, true, false>(A, dw, dh, interleaved, s);
-    default: return launch_mt<MODEL, T, 4, true, false>(A, dw, dh, interleaved, s);
-    }
-}
-
-hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int bytes_per_sample, int dw, int dh, bool interleaved, bool fast1, int rb, hipStream_t s) {
-    if (A.model == GFW_MODEL_OPENCV_FISHEYE) {
-        if (fast1)
-            return bytes_per_sample == 1 ? launch_fast<GFW_MODEL_OPENCV_FISHEYE, uint8_t>(A, dw, dh, interleaved, rb, s)
-                                         : launch_fast<GFW_MODEL_OPENCV_FISHEYE, uint16_t>(A, dw, dh, interleaved, rb, s);
-        return bytes_per_sample == 1 ? launch_mt<GFW_MODEL_OPENCV_FISHEYE, uint8_t, GFW_YUV_RB_EXACT, false, false>(A, dw, dh, interleaved, s)
-                                     : launch_mt<GFW_MODEL_OPENCV_FISHEYE, uint16_t, GFW_YUV_RB_EXACT, false, false>(A, dw, dh, interleaved, s);
-    }
-    return bytes_per_sample == 1 ? launch_mt<-1, uint8_t, GFW_YUV_RB_EXACT, false, false>(A, dw, dh, interleaved, s)
-                                 : launch_mt<-1, uint16_t, GFW_YUV_RB_EXACT, false, false>(A, dw, dh, interleaved, s);
+#define GFW_CAT2(a, b) a##b
+#define GFW_CAT(a, b) GFW_CAT2(a, b)
+hipError_t GFW_CAT(gfw_launch_yuv_kind, GFW_FRAME_KIND)(const GfwYuvArgs &A, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s) {
+    if (A.model == GFW_MODEL_OPENCV_FISHEYE) return launch_m<GFW_MODEL_OPENCV_FISHEYE>(A, n0, dw, dh, interleaved, fast1, s);
+    return launch_m<-1>(A, n0, dw, dh, interleaved, false, s);
 }

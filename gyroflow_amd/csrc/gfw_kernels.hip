@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include "gfw_launch.h"
 #include "gfw_fastmath.h"
+#include "gfw_frame.h"
 
 #define GFW_DECL(n) hipError_t gfw_launch_plane_pix##n(const GfwPlane &A, const GfwCommon &C, hipStream_t s);
 GFW_DECL(0) GFW_DECL(1) GFW_DECL(2) GFW_DECL(3) GFW_DECL(4) GFW_DECL(5) GFW_DECL(6)
@@ -12,6 +13,23 @@ hipError_t gfw_launch_plane(const GfwPlane &A, const GfwCommon &C, hipStream_t s
 #define GFW_CASE(n) case n: return gfw_launch_plane_pix##n(A, C, s);
     GFW_CASE(0) GFW_CASE(1) GFW_CASE(2) GFW_CASE(3) GFW_CASE(4) GFW_CASE(5) GFW_CASE(6)
     GFW_CASE(7) GFW_CASE(8) GFW_CASE(9) GFW_CASE(10) GFW_CASE(11) GFW_CASE(12)
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------- fused frame kernel dispatch
+hipError_t gfw_launch_yuv_kind1(const GfwYuvArgs &A, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s);
+hipError_t gfw_launch_yuv_kind2(const GfwYuvArgs &A, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s);
+hipError_t gfw_launch_yuv_kind4(const GfwYuvArgs &A, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s);
+int gfw_yuv_rows_per_lane(bool fast1, int tune_rb) {
+    (void)tune_rb;
+    return fast1 ? GFW_YUV_RB_FAST : GFW_YUV_RB_EXACT;
+}
+hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int sample_kind, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s) {
+    switch (sample_kind) {
+    case 1: return gfw_launch_yuv_kind1(A, n0, dw, dh, interleaved, fast1, s);
+    case 2: return gfw_launch_yuv_kind2(A, n0, dw, dh, interleaved, fast1, s);
+    case 4: return gfw_launch_yuv_kind4(A, n0, dw, dh, interleaved, fast1, s);
     default: return hipErrorInvalidValue;
     }
 }
