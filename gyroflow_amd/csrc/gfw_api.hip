@@ -801,3 +801,34 @@ int gfw_build_matrices(gfw_ctx *c, const gfw_frame_timing *t, float *rows16_out,
     return GFW_OK;
 }
 }
+
+// STMap "undist" coordinate map (src/core/stmap.rs:87-109, :127-137): coords is width*height*2 f32, host or device
+// memory (coords_on_device); pixels whose projection is None keep their previous content, as parallel_exr leaves 0.
+extern "C" int gfw_stmap_undistort(gfw_ctx *c, const gfw_kernel_params *p, const float *matrices, int matrix_count,
+                                   const float *mesh, size_t mesh_len, int width, int height, float *coords, int coords_on_device) {
+    if (!c || !p || !coords || width < 1 || height < 1) { set_error("bad stmap arguments"); return GFW_ERR_INVALID_ARGUMENT; }
+    if (p->matrix_count != matrix_count || matrix_count < 1) { set_error("matrix_count %d != %d", p->matrix_count, matrix_count); return GFW_ERR_INVALID_ARGUMENT; }
+    if (mesh_len > GFW_MESH_MAX) { set_error("mesh too large"); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
+    HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
+    const float *d_mat = nullptr;
+    int rc = upload_matrices(c, matrices, matrix_count, &d_mat);
+    if (rc != GFW_OK) return rc;
+    const float *d_mesh = nullptr;
+    if (mesh && mesh_len) { HIP_TRY(hipMemcpyAsync(c->d_mesh.ptr, mesh, mesh_len * sizeof(float), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP); d_mesh = (const float *)c->d_mesh.ptr; }
+    GfwCommon C;
+    fill_common(c, p, d_mat, d_mesh, (int)mesh_len, C);
+    const size_t bytes = (size_t)width * height * 2 * sizeof(float);
+    float *d_coords = coords;
+    if (!coords_on_device) {
+        if (c->stage_dst.empty()) c->stage_dst.resize(1);
+        HIP_TRY(c->stage_dst[0].ensure(bytes), GFW_ERR_HIP);
+        d_coords = (float *)c->stage_dst[0].ptr;
+        HIP_TRY(hipMemcpyAsync(d_coords, coords, bytes, hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
+    }
+    HIP_TRY(gfw_launch_stmap(*p, C, width, height, d_coords, c->stream), GFW_ERR_HIP);
+    c->last_backend = "stmap";
+    { const int mrc = matrices_consumed(c); if (mrc != GFW_OK) return mrc; }
+    if (!coords_on_device) HIP_TRY(hipMemcpyAsync(coords, d_coords, bytes, hipMemcpyDeviceToHost, c->stream), GFW_ERR_HIP);
+    if (c->synchronous || !coords_on_device) HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
+    return GFW_OK;
+}

@@ -34,6 +34,32 @@ hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int sample_kind, int n0, int dw, 
     }
 }
 
+// ---------------------------------------------------------------------------- STMap coordinate export
+// src/core/stmap.rs:87-109: the "undist" map is the warp's coordinate stage alone — rolling-shutter row pick, then
+// rotate_and_distort — written as two f32 per pixel instead of being sampled.
+template <int MODEL>
+__global__ __launch_bounds__(256) void gfw_stmap_kernel(const gfw_kernel_params P, const GfwCommon C, int width, int height, float *coords) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= width || y >= height) return;
+    const float fx = (float)x, fy = (float)y;
+    const float r_limit_sq = P.r_limit * P.r_limit;
+    const bool hrs = (P.flags & 16) == 16;
+    const int lim = hrs ? P.width : P.height;
+    int sy = max(min(gfw_f2i(gfw_round(hrs ? fx : fy)), lim), 0);
+    if (P.matrix_count > 1) {
+        const GfwPt pt = gfw_rotate_and_distort<MODEL>(fx, fy, P.matrix_count / 2, P, C, r_limit_sq);
+        if (pt.ok) sy = max(min(gfw_f2i(gfw_round(hrs ? pt.x : pt.y)), lim), 0);
+    }
+    const GfwPt uv = gfw_rotate_and_distort<MODEL>(fx, fy, min(sy, P.matrix_count - 1), P, C, r_limit_sq);
+    if (uv.ok) *reinterpret_cast<float2 *>(coords + ((size_t)y * width + x) * 2) = float2{uv.x, uv.y};
+}
+hipError_t gfw_launch_stmap(const gfw_kernel_params &P, const GfwCommon &C, int width, int height, float *coords, hipStream_t s) {
+    dim3 grid((width + 63) / 64, (height + 3) / 4), block(64, 4);
+    if (C.model == GFW_MODEL_OPENCV_FISHEYE && C.mesh_len == 0) hipLaunchKernelGGL(gfw_stmap_kernel<GFW_MODEL_OPENCV_FISHEYE>, grid, block, 0, s, P, C, width, height, coords);
+    else hipLaunchKernelGGL(gfw_stmap_kernel<-1>, grid, block, 0, s, P, C, width, height, coords);
+    return hipGetLastError();
+}
+
 // Row repack: [rows][14] f32 (FrameTransform.matrices) -> [rows][16] with cos(-m11), sin(-m11) slots.
 // Used only for device-resident matrices; the trig slots are 1 / 0 (no IBIS roll), see gfw_api.hip.
 __global__ void gfw_repack_matrices_kernel(const float *in, float *out, int rows) {

@@ -114,6 +114,17 @@ class Backend:
         self._check(self.lib.gfw_build_matrices(self.ctx, C.byref(t), out_ptr, C.byref(ptr)))
         return ptr.value
 
+    def stmap_undistort(self, params, matrices, width, height, mesh=None):
+        """STMap 'undist' coordinates (stmap.rs:87-109) as a float32 array [height][width][2] (0 where None)."""
+        m = np.ascontiguousarray(matrices, dtype=np.float32)
+        coords = np.zeros((height, width, 2), dtype=np.float32)
+        meshp, meshn = None, 0
+        if mesh is not None and len(mesh):
+            mesh = np.ascontiguousarray(mesh, dtype=np.float32)
+            meshp, meshn = mesh.ctypes.data, mesh.size
+        self._check(self.lib.gfw_stmap_undistort(self.ctx, C.byref(params), m.ctypes.data, m.shape[0], meshp, meshn, width, height, coords.ctypes.data, 0))
+        return coords
+
     def synchronize(self):
         self._check(self.lib.gfw_synchronize(self.ctx))
 

@@ -306,6 +306,14 @@ int   gfw_set_quaternion_tracks(gfw_ctx *ctx, const int64_t *org_ts_us, const do
                                 const int64_t *smoothed_ts_us, const double *smoothed_wxyz, int smoothed_count);
 int   gfw_build_matrices(gfw_ctx *ctx, const gfw_frame_timing *timing, float *rows16_out, float **out_ptr);
 
+/* ---- STMap coordinate export ("next" row: src/core/stmap.rs:87-109, :127-137) ----------------------------
+ * The "undist" ST map: for every pixel (x, y) of a width x height map, the rolling-shutter row pick followed by
+ * rotate_and_distort, written as two f32 (source x, y in pixels) instead of being sampled.  `params` is the
+ * KernelParams stmap.rs builds (width/height/output_* = map size, flags = HAS_DIGITAL_LENS | HORIZONTAL_RS).
+ * Pixels whose projection is None are left untouched (parallel_exr leaves them 0).  Bit-exact vs the CPU closure. */
+int   gfw_stmap_undistort(gfw_ctx *ctx, const gfw_kernel_params *params, const float *matrices, int matrix_count,
+                          const float *mesh, size_t mesh_len, int width, int height, float *coords, int coords_on_device);
+
 /* ---- test hooks (used by tests/test_gpu_math.py; not part of the operator surface) ---------------
  * gfw_debug_math: out[i] = f(a[i], b[i]) evaluated ON THE DEVICE with the kernels' own routines; host arrays.
  *   op 0 gfw_atanf  1 gfw_tanf  2 gfw_atanf_pos  3 lean a/b  4 generic a/b  5 lean sqrt  6 generic sqrt

@@ -1126,6 +1126,46 @@ void gfw_oracle_undistort_coord(const gfw_kernel_params *p, int distortion_model
     free(mesh);
 }
 
+/* STMap "undist" coordinate map: src/core/stmap.rs:87-109 (the per-pixel closure) + parallel_exr :127-137.
+ * coords[(y*width + x)*2 + {0,1}] = rotate_and_distort((x, y), row) when it is Some, else left untouched.
+ * `p` is the KernelParams stmap.rs builds (width/height = output size = map size, flags = digital-lens | horizontal-RS). */
+int gfw_oracle_stmap_undistort(const gfw_kernel_params *p, int distortion_model, int digital_lens,
+                               const float *matrices, const float *mesh_f32, size_t mesh_len,
+                               int width, int height, float *coords, int nthreads)
+{
+    double *mesh = NULL;
+    if (mesh_len) { mesh = (double *)malloc(mesh_len * sizeof(double)); for (size_t i = 0; i < mesh_len; ++i) mesh[i] = (double)mesh_f32[i]; }
+    wctx c; wctx_init(&c, p, distortion_model, digital_lens, matrices, mesh, mesh_len);
+    const int hrs = (p->flags & 16) == 16;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+    #pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < height; ++y) {
+        for (int x = 0; x < width; ++x) {
+            const float fx = (float)x, fy = (float)y;
+            int32_t sy;
+            if (hrs) { sy = f2i(roundf(fx)); if (sy > p->width)  sy = p->width;  if (sy < 0) sy = 0; }
+            else     { sy = f2i(roundf(fy)); if (sy > p->height) sy = p->height; if (sy < 0) sy = 0; }
+            if (p->matrix_count > 1) {
+                opt2 pt = rotate_and_distort(fx, fy, (size_t)p->matrix_count / 2, &c);
+                if (pt.ok) {
+                    if (hrs) { sy = f2i(roundf(pt.x)); if (sy > p->width)  sy = p->width;  if (sy < 0) sy = 0; }
+                    else     { sy = f2i(roundf(pt.y)); if (sy > p->height) sy = p->height; if (sy < 0) sy = 0; }
+                }
+            }
+            size_t idx = (size_t)sy;
+            if (idx > (size_t)p->matrix_count - 1) idx = (size_t)p->matrix_count - 1;
+            opt2 uv = rotate_and_distort(fx, fy, idx, &c);
+            if (uv.ok) { coords[((size_t)y * width + x) * 2 + 0] = uv.x; coords[((size_t)y * width + x) * 2 + 1] = uv.y; }
+        }
+    }
+    free(mesh);
+    return 1;
+}
+
 /* Per-model point functions, exposed for the lens-model parity tests. */
 void gfw_oracle_distort_point(int model, const gfw_kernel_params *p, float x, float y, float z, float *out) {
     model_distort(model, x, y, z, p, &out[0], &out[1]);

@@ -30,6 +30,8 @@ def lib():
         L.gfw_oracle_distort_point.argtypes = [C.c_int, C.POINTER(abi.KernelParams), C.c_float, C.c_float, C.c_float, vp]
         L.gfw_oracle_undistort_point.argtypes = [C.c_int, C.POINTER(abi.KernelParams), C.c_float, C.c_float, vp]
         L.gfw_oracle_undistort_point.restype = C.c_int
+        L.gfw_oracle_stmap_undistort.argtypes = [C.POINTER(abi.KernelParams), C.c_int, C.c_int, vp, vp, C.c_size_t, C.c_int, C.c_int, vp, C.c_int]
+        L.gfw_oracle_stmap_undistort.restype = C.c_int
         L.gfw_oracle_libm.argtypes = [C.c_int, vp, vp, C.c_size_t]
         L.gfw_oracle_num_threads.restype = C.c_int
         _lib = L
@@ -83,3 +85,11 @@ def run_frame(frame, nthreads=0):
         assert st == 1, "oracle returned %d" % st
         outs.append(dst)
     return outs
+
+
+def stmap_undistort(params, model, digital, matrices, width, height, nthreads=0):
+    """Oracle restatement of the stmap.rs 'undist' closure; returns float32 [height][width][2] (0 where None)."""
+    m = np.ascontiguousarray(matrices, dtype=np.float32)
+    coords = np.zeros((height, width, 2), dtype=np.float32)
+    lib().gfw_oracle_stmap_undistort(C.byref(params), model, digital, m.ctypes.data, None, 0, width, height, coords.ctypes.data, nthreads)
+    return coords
