@@ -17,9 +17,9 @@
 //
 // Shape of the kernel (all of it driven by measurements in profiles/):
 //   * VALU-issue bound, so instruction count and code size are what matter: every code path exists once (row
-//     loop not unrolled), slow paths are side branches, uniform float parameters are pinned in VGPRs so that the
-//     SGPR file is left to pointers and control flow (the first version re-loaded kernel arguments and the mid
-//     matrix inside the pixel loop — s_load + s_waitcnt per pixel);
+//     loop not unrolled) and slow paths are side branches — a fully unrolled 26 K-instruction body measured slower
+//     (instruction cache).  Pinning the uniform floats in VGPRs (GFW_PIN_UNIFORMS) was tried and rejected: it cost
+//     occupancy (100 VGPRs) and ran 15 % slower than leaving them to the scalar file;
 //   * persistent workgroups: the grid is sized to the machine and each workgroup walks a band of tiles, so the
 //     ~5 us start-up of a wave (kernel-argument loads) is paid once, not once per tile;
 //   * XCD-banded tile order (workgroup b runs on XCD b % 8): an XCD's L2 sees a contiguous band of source lines.
