@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--fmt", default=FMT)
     ap.add_argument("--fov", type=float, default=1.0)
+    ap.add_argument("--interp", type=int, default=2, help="2 bilinear (north-star), 4 bicubic, 8 Lanczos4 (the reference's render default, cli.rs:618)")
     ap.add_argument("--crop", action="store_true", help="C4: adaptive-zoom crop (fov 0.82 + non-zero translation2d)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--rows", type=int, default=0)
@@ -70,7 +71,7 @@ def main():
     fov = 0.82 if args.crop else args.fov
     ov = {"translation2d": (13.25, -7.5)} if args.crop else None
     frames = [S.SyntheticFrame(args.fmt, W, H, seed=0x9F10 + rank * 1000 + i, timestamp_ms=1000.0 + 33.3 * (rank * 1000 + i),
-                               fov=fov, base_overrides=ov)
+                               fov=fov, base_overrides=ov, interpolation=args.interp)
               for i in range(N_DISTINCT)]
     nplanes = len(frames[0].planes)
     d_src = [[torch.from_numpy(pl["src"]).to(dev) for pl in fr.planes] for fr in frames]
@@ -139,9 +140,12 @@ def main():
         "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 coordinates, %s pixels" % np.dtype(abi.PIXEL_TYPES[types[0]][1]).name, "data": "synthetic",
-        "config": {"workload": ("C2" if (W, H, args.fmt) == (3840, 2160, FMT) else "C3" if (W, H, args.fmt) == (7680, 4320, FMT) else "C4" if args.crop else "custom") + ": %dx%d %s, opencv_fisheye GoPro-style lens, rolling shutter "
-                               "matrix_count=%d, bilinear, frames + per-row matrix tables resident in HBM%s"
-                               % (W, H, args.fmt, frames[0].matrices.shape[0], " (matrices re-uploaded per frame)" if args.upload_matrices else ""),
+        "config": {"workload": "%s: %dx%d %s, opencv_fisheye GoPro-style lens, rolling shutter matrix_count=%d, %s, "
+                               "frames + per-row matrix tables resident in HBM%s"
+                               % ("C2" if (W, H, args.fmt) == (3840, 2160, FMT) else "C3" if (W, H, args.fmt) == (7680, 4320, FMT) else "C4" if args.crop else "custom",
+                                  W, H, args.fmt, frames[0].matrices.shape[0],
+                                  {2: "bilinear", 4: "bicubic", 8: "Lanczos4"}.get(args.interp, str(args.interp)),
+                                  " (matrices re-uploaded per frame)" if args.upload_matrices else ""),
                    "frames_per_rank": args.steps, "parallelism": "frame-sharded x%d" % world,
                    "backend": warp.last_backend(), "checksum": crc,
                    "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 5)},

@@ -522,7 +522,8 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     // plane-invariant parameters must really be invariant, and inside the fused kernel's feature set
     for (int i = 0; i < nplanes; ++i) {
         const gfw_kernel_params &p = params[i];
-        if (p.interpolation != 2 || p.background_mode != 0 || p.input_rotation != 0.0f) return false;
+        if ((p.interpolation != 2 && p.interpolation != 4 && p.interpolation != 8) || p.interpolation != p0.interpolation) return false;
+        if (p.background_mode != 0 || p.input_rotation != 0.0f) return false;
         if (p.lens_correction_amount < 1.0f || !(p.lens_correction_amount == p.lens_correction_amount)) return false;
         if (p.light_refraction_coefficient != 1.0f && p.light_refraction_coefficient > 0.0f) return false;
         if (!(p.light_refraction_coefficient == p.light_refraction_coefficient)) return false;
@@ -680,7 +681,7 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
     if (fused) {
         fill_common(c, &params[0], d_mat, nullptr, 0, Y.common);
         Y.matrices = d_mat;
-        HIP_TRY(gfw_launch_yuv(Y, bps, n0, dw, dh, interleaved, fast1, c->stream), GFW_ERR_HIP);
+        HIP_TRY(gfw_launch_yuv(Y, bps, params[0].interpolation, n0, dw, dh, interleaved, fast1, c->stream), GFW_ERR_HIP);
         c->last_backend = fast1 ? "yuv_fused_p1" : "yuv_fused";
     } else {
         for (int i = 0; i < nplanes; ++i) {

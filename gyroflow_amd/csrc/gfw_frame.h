@@ -49,4 +49,4 @@ struct GfwYuvArgs {
 };
 
 int gfw_yuv_rows_per_lane(bool fast1, int tune_rb);
-hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int sample_kind, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s);
+hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int sample_kind, int taps, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s);

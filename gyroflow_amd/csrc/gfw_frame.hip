@@ -35,6 +35,11 @@
 
 namespace {
 
+// 32-phase bicubic / Lanczos4 tap table (one constant copy per translation unit)
+__device__
+#include "gfw_coeffs.inc"
+
+
 // A wave-uniform float pinned in a VGPR (keeps SGPRs for pointers / exec masks; VALU reads either at no cost).
 #ifndef GFW_PIN_UNIFORMS
 #define GFW_PIN_UNIFORMS 0
@@ -150,11 +155,156 @@ __device__ __forceinline__ int round_i32(float x) {
     return gfw_f2i(r);
 }
 
-// ---- bilinear taps (cpu_undistort.rs:371-418 with I = 2) ---------------------------------------------------
-struct Bins { int sx, sy; float cx0, cx1, cy0, cy1; };
-__device__ __forceinline__ Bins make_bins(float u, float v) {
+// ---- LUT taps (cpu_undistort.rs:371-418): I = 2 bilinear, 4 bicubic, 8 Lanczos4 --------------------------------
+template <int I> struct Bins { int sx, sy; float cx[I], cy[I]; };
+template <int I>
+__device__ __forceinline__ Bins<I> make_bins(float u, float v, const float *lut) {
+    constexpr float OFFSET = (I == 2) ? 0.0f : (I == 4 ? 1.0f : 3.0f);       // :374
+    const int sx0 = round_i32((u - OFFSET) * 32.0f), sy0 = round_i32((v - OFFSET) * 32.0f);
+    Bins<I> b;
+    b.sx = sx0 >> 5; b.sy = sy0 >> 5;
+    if (I == 2) {
+        b.cx[1] = (float)(sx0 & 31) * 0.03125f; b.cx[0] = 1.0f - b.cx[1];   // {1-k/32, k/32}: the LUT row (cpu_undistort.rs:14-19)
+        b.cy[1] = (float)(sy0 & 31) * 0.03125f; b.cy[0] = 1.0f - b.cy[1];
+    } else {
+        constexpr int IND = (I == 4) ? 64 : 192, SHIFT = (I >> 2) + 1;       // :373-375
+        const float *tx = lut + IND + ((sx0 & 31) << SHIFT), *ty = lut + IND + ((sy0 & 31) << SHIFT);
+        #pragma unroll
+        for (int i = 0; i < I; ++i) { b.cx[i] = tx[i]; b.cy[i] = ty[i]; }
+    }
+    return b;
+}
+template <typename T> struct is_f32 { static constexpr bool value = false; };
+template <> struct is_f32<float> { static constexpr bool value = true; };
+// Taps that straddle the source rect: out-of-rect taps read `bg`, out-of-rect rows contribute bg*cy
+// (cpu_undistort.rs:391-411), in the reference's exact operation order.
+template <typename T, int N, int I>
+__device__ __forceinline__ void taps_edge(const uint8_t *src, int stride, const Bins<I> &b, int w, int h, const float *bg, float limit, float *out) {
+    float sum[N];
+    #pragma unroll
+    for (int c = 0; c < N; ++c) sum[c] = 0.0f;
+    #pragma unroll          // (a rolled loop would index b.cy[] dynamically and push the whole Bins struct to scratch)
+    for (int yp = 0; yp < I; ++yp) {
+        const int yy = b.sy + yp;
+        if (yy >= 0 && yy < h) {
+            const T *row = reinterpret_cast<const T *>(src + (int64_t)yy * stride);
+            float xs[N];
+            #pragma unroll
+            for (int c = 0; c < N; ++c) xs[c] = 0.0f;
+            #pragma unroll
+            for (int xp = 0; xp < I; ++xp) {
+                const int xx = b.sx + xp;
+                const bool in = xx >= 0 && xx < w;
+                #pragma unroll
+                for (int c = 0; c < N; ++c) { const float px = in ? (float)row[(int64_t)xx * N + c] : bg[c]; xs[c] = xs[c] + px * b.cx[xp]; }
+            }
+            #pragma unroll
+            for (int c = 0; c < N; ++c) sum[c] = sum[c] + xs[c] * b.cy[yp];
+        } else {
+            #pragma unroll
+            for (int c = 0; c < N; ++c) sum[c] = sum[c] + bg[c] * b.cy[yp];
+        }
+    }
+    #pragma unroll
+    for (int c = 0; c < N; ++c) out[c] = fminf(sum[c], limit);
+}
+// All I x I taps inside.  Bilinear on integer pixels: every tap is >= +0, so the reference's leading zero-adds
+// (xsum = 0 + p*c, sum = 0 + xs*cy) are exact identities and are dropped; everywhere else (negative weights, f32
+// pixels with -0 / negative values) they are kept so that signed zeros come out as the reference's.
+template <typename T, int N, int I>
+__device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int stride, const Bins<I> &b, float limit, float *out) {
+    if (I == 2 && !is_f32<T>::value) {
+        const T *row0 = reinterpret_cast<const T *>(src + (int64_t)off0);
+        const T *row1 = reinterpret_cast<const T *>(src + (int64_t)(off0 + stride));
+        #pragma unroll
+        for (int c = 0; c < N; ++c) {
+            const float xs0 = (float)row0[c] * b.cx[0] + (float)row0[N + c] * b.cx[1];
+            const float xs1 = (float)row1[c] * b.cx[0] + (float)row1[N + c] * b.cx[1];
+            out[c] = fminf(xs0 * b.cy[0] + xs1 * b.cy[1], limit);
+        }
+        return;
+    }
+    float sum[N];
+    #pragma unroll
+    for (int c = 0; c < N; ++c) sum[c] = 0.0f;
+    #pragma unroll
+    for (int yp = 0; yp < I; ++yp) {
+        const T *row = reinterpret_cast<const T *>(src + (int64_t)(off0 + yp * stride));
+        float xs[N];
+        #pragma unroll
+        for (int c = 0; c < N; ++c) xs[c] = 0.0f;
+        #pragma unroll
+        for (int xp = 0; xp < I; ++xp) {
+            #pragma unroll
+            for (int c = 0; c < N; ++c) xs[c] = xs[c] + (float)row[xp * N + c] * b.cx[xp];
+        }
+        #pragma unroll
+        for (int c = 0; c < N; ++c) sum[c] = sum[c] + xs[c] * b.cy[yp];
+    }
+    #pragma unroll
+    for (int c = 0; c < N; ++c) out[c] = fminf(sum[c], limit);
+}
+template <int I>
+__device__ __forceinline__ bool bins_inside(const Bins<I> &b, int w, int h) {
+    return (unsigned)b.sx <= (unsigned)(w - I) && (unsigned)b.sy <= (unsigned)(h - I) && w >= I && h >= I;
+}
+template <typename T, int N>
+__device__ __forceinline__ void store_px(uint8_t *dst, int off, const float *v) {
+    T *d = reinterpret_cast<T *>(dst + (int64_t)off);
+    #pragma unroll
+    for (int c = 0; c < N; ++c) {
+        if (is_f32<T>::value) d[c] = (T)v[c];                                   // f32 pixels pass through (pixel_formats.rs:247,296)
+        else d[c] = (T)gfw_f2u_sat(v[c], sizeof(T) == 1 ? 255.0f : 65535.0f);    // `as u8/u16`
+    }
+}
+// One plane.  32-bit byte offsets from the uniform plane base (planes are < 2 GiB, checked on the host).
+template <typename T, int N, int I>
+__device__ __forceinline__ void sample_store(float u, float v, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy, const float *lut) {
+    float out[N];
+    #pragma unroll
+    for (int c = 0; c < N; ++c) out[c] = bg[c];
+    if (ok) {
+        const Bins<I> b = make_bins<I>(u, v, lut);
+        if (__builtin_expect(bins_inside<I>(b, P.w, P.h), 1))
+            taps_inside<T, N, I>(P.src, b.sy * P.src_stride + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
+        else
+            taps_edge<T, N, I>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
+    }
+    store_px<T, N>(P.dst, oy * P.dst_stride + ox * (int)(N * sizeof(T)), out);
+}
+// Planar planes of identical geometry (U and V; or G,B,R,A of a planar float frame): one set of bins / weights /
+// offsets, one gather set per plane.
+template <typename T, int I>
+__device__ __forceinline__ void sample_store_shared(float u, float v, bool ok, const GfwYuvPlane *pl, int first, int last, int ox, int oy, const float *lut) {
+    const GfwYuvPlane &P0 = pl[first];
+    Bins<I> b;
+    b.sx = 0; b.sy = 0;
+    #pragma unroll
+    for (int i = 0; i < I; ++i) { b.cx[i] = 0.0f; b.cy[i] = 0.0f; }
+    bool inside = false;
+    int off0 = 0;
+    if (ok) {
+        b = make_bins<I>(u, v, lut);
+        inside = bins_inside<I>(b, P0.w, P0.h);
+        off0 = b.sy * P0.src_stride + b.sx * (int)sizeof(T);
+    }
+    const int doff = oy * P0.dst_stride + ox * (int)sizeof(T);
+    #pragma unroll 1
+    for (int pi = first; pi <= last; ++pi) {
+        float o = pl[pi].bg[0];
+        if (ok) {
+            if (__builtin_expect(inside, 1)) taps_inside<T, 1, I>(pl[pi].src, off0, P0.src_stride, b, pl[pi].limit, &o);
+            else taps_edge<T, 1, I>(pl[pi].src, P0.src_stride, b, P0.w, P0.h, pl[pi].bg, pl[pi].limit, &o);
+        }
+        store_px<T, 1>(pl[pi].dst, doff, &o);
+    }
+}
+
+// ---- bilinear specialisation (I = 2): named weights, two-compare interior test — the hot configuration ---------------------------------------------------
+struct Bins2 { int sx, sy; float cx0, cx1, cy0, cy1; };
+__device__ __forceinline__ Bins2 make_bins2(float u, float v) {
     const int sx0 = round_i32(u * 32.0f), sy0 = round_i32(v * 32.0f);
-    Bins b;
+    Bins2 b;
     b.sx = sx0 >> 5; b.sy = sy0 >> 5;
     b.cx1 = (float)(sx0 & 31) * 0.03125f; b.cx0 = 1.0f - b.cx1;     // {1-k/32, k/32}: the LUT row (cpu_undistort.rs:14-19)
     b.cy1 = (float)(sy0 & 31) * 0.03125f; b.cy0 = 1.0f - b.cy1;
@@ -163,7 +313,7 @@ __device__ __forceinline__ Bins make_bins(float u, float v) {
 // Taps that straddle the source rect: out-of-rect taps read `bg`, out-of-rect rows contribute bg*cy
 // (cpu_undistort.rs:392-409), in the reference's exact operation order.
 template <typename T, int N>
-__device__ __forceinline__ void taps_edge(const uint8_t *src, int stride, const Bins &b, int w, int h, const float *bg, float limit, float *out) {
+__device__ __forceinline__ void taps_edge2(const uint8_t *src, int stride, const Bins2 &b, int w, int h, const float *bg, float limit, float *out) {
     const bool x0in = b.sx >= 0 && b.sx < w, x1in = b.sx + 1 >= 0 && b.sx + 1 < w;
     const bool y0in = b.sy >= 0 && b.sy < h, y1in = b.sy + 1 >= 0 && b.sy + 1 < h;
     const T *row0 = reinterpret_cast<const T *>(src + (int64_t)b.sy * stride) + (int64_t)b.sx * N;
@@ -180,12 +330,10 @@ __device__ __forceinline__ void taps_edge(const uint8_t *src, int stride, const 
         out[c] = fminf(sum, limit);
     }
 }
-template <typename T> struct is_f32 { static constexpr bool value = false; };
-template <> struct is_f32<float> { static constexpr bool value = true; };
 // All four taps inside.  For the integer pixel types every tap is >= +0, so the reference's leading zero-adds
 // (xsum = 0 + p*c, sum = 0 + xs*cy) are exact identities and are dropped; for f32 pixels (-0, negative values) they stay.
 template <typename T, int N>
-__device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int stride, const Bins &b, float limit, float *out) {
+__device__ __forceinline__ void taps_inside2(const uint8_t *src, int off0, int stride, const Bins2 &b, float limit, float *out) {
     const T *row0 = reinterpret_cast<const T *>(src + (int64_t)off0);
     const T *row1 = reinterpret_cast<const T *>(src + (int64_t)(off0 + stride));
     #pragma unroll
@@ -202,40 +350,31 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
         }
     }
 }
-template <typename T, int N>
-__device__ __forceinline__ void store_px(uint8_t *dst, int off, const float *v) {
-    T *d = reinterpret_cast<T *>(dst + (int64_t)off);
-    #pragma unroll
-    for (int c = 0; c < N; ++c) {
-        if (is_f32<T>::value) d[c] = (T)v[c];                                   // f32 pixels pass through (pixel_formats.rs:247,296)
-        else d[c] = (T)gfw_f2u_sat(v[c], sizeof(T) == 1 ? 255.0f : 65535.0f);    // `as u8/u16`
-    }
-}
 // One plane.  32-bit byte offsets from the uniform plane base (planes are < 2 GiB, checked on the host).
 template <typename T, int N>
-__device__ __forceinline__ void sample_store(float u, float v, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy) {
+__device__ __forceinline__ void sample_store2(float u, float v, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy) {
     float out[N];
     #pragma unroll
     for (int c = 0; c < N; ++c) out[c] = bg[c];
     if (ok) {
-        const Bins b = make_bins(u, v);
+        const Bins2 b = make_bins2(u, v);
         if (__builtin_expect((unsigned)b.sx < (unsigned)(P.w - 1) && (unsigned)b.sy < (unsigned)(P.h - 1), 1))
-            taps_inside<T, N>(P.src, b.sy * P.src_stride + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
+            taps_inside2<T, N>(P.src, b.sy * P.src_stride + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
         else
-            taps_edge<T, N>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
+            taps_edge2<T, N>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
     }
     store_px<T, N>(P.dst, oy * P.dst_stride + ox * (int)(N * sizeof(T)), out);
 }
 // Planar planes of identical geometry (U and V; or G,B,R,A of a planar float frame): one set of bins / weights /
 // offsets, one gather pair per plane.
 template <typename T>
-__device__ __forceinline__ void sample_store_shared(float u, float v, bool ok, const GfwYuvPlane *pl, int first, int last, int ox, int oy) {
+__device__ __forceinline__ void sample_store_shared2(float u, float v, bool ok, const GfwYuvPlane *pl, int first, int last, int ox, int oy) {
     const GfwYuvPlane &P0 = pl[first];
-    Bins b = {0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
+    Bins2 b = {0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
     bool inside = false;
     int off0 = 0;
     if (ok) {
-        b = make_bins(u, v);
+        b = make_bins2(u, v);
         inside = (unsigned)b.sx < (unsigned)(P0.w - 1) && (unsigned)b.sy < (unsigned)(P0.h - 1);
         off0 = b.sy * P0.src_stride + b.sx * (int)sizeof(T);
     }
@@ -244,11 +383,33 @@ __device__ __forceinline__ void sample_store_shared(float u, float v, bool ok, c
     for (int pi = first; pi <= last; ++pi) {
         float o = pl[pi].bg[0];
         if (ok) {
-            if (__builtin_expect(inside, 1)) taps_inside<T, 1>(pl[pi].src, off0, P0.src_stride, b, pl[pi].limit, &o);
-            else taps_edge<T, 1>(pl[pi].src, P0.src_stride, b, P0.w, P0.h, pl[pi].bg, pl[pi].limit, &o);
+            if (__builtin_expect(inside, 1)) taps_inside2<T, 1>(pl[pi].src, off0, P0.src_stride, b, pl[pi].limit, &o);
+            else taps_edge2<T, 1>(pl[pi].src, P0.src_stride, b, P0.w, P0.h, pl[pi].bg, pl[pi].limit, &o);
         }
         store_px<T, 1>(pl[pi].dst, doff, &o);
     }
+}
+
+// Two planar chroma planes of identical geometry (U, V) — the C2 hot path: one set of bins / weights / offsets,
+// two gathers, no loop over a plane index (which would index the kernel-argument plane array dynamically).
+template <typename T>
+__device__ __forceinline__ void sample_store_uv2(float u, float v, bool ok, const GfwYuvPlane &PU, const GfwYuvPlane &PV,
+                                                 float bg_u, float bg_v, float lim_u, float lim_v, int ox, int oy) {
+    float ou = bg_u, ov = bg_v;
+    if (ok) {
+        const Bins2 b = make_bins2(u, v);
+        if (__builtin_expect((unsigned)b.sx < (unsigned)(PU.w - 1) && (unsigned)b.sy < (unsigned)(PU.h - 1), 1)) {
+            const int off0 = b.sy * PU.src_stride + b.sx * (int)sizeof(T);
+            taps_inside2<T, 1>(PU.src, off0, PU.src_stride, b, lim_u, &ou);
+            taps_inside2<T, 1>(PV.src, off0, PU.src_stride, b, lim_v, &ov);
+        } else {
+            taps_edge2<T, 1>(PU.src, PU.src_stride, b, PU.w, PU.h, &bg_u, lim_u, &ou);
+            taps_edge2<T, 1>(PV.src, PU.src_stride, b, PU.w, PU.h, &bg_v, lim_v, &ov);
+        }
+    }
+    const int doff = oy * PU.dst_stride + ox * (int)sizeof(T);
+    store_px<T, 1>(PU.dst, doff, &ou);
+    store_px<T, 1>(PV.dst, doff, &ov);
 }
 
 // ---- first pass (rolling-shutter row pick) -----------------------------------------------------------------
@@ -305,7 +466,7 @@ __device__ __forceinline__ bool pass1_fast(float ax, float ay, float aw, float o
     return good;
 }
 
-template <int MODEL, typename T, int N0, int DW, int DH, bool INTERLEAVED_UV, int RB, bool FAST1, bool AUDIT>
+template <int MODEL, typename T, int N0, int I, int DW, int DH, bool INTERLEAVED_UV, int RB, bool FAST1, bool AUDIT>
 __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
     // tile = 64 x 4 lanes; each lane owns RB vertically stacked DW x DH luma blocks (+ their chroma sites).
     constexpr int NPX = DW * DH;
@@ -315,7 +476,12 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
     __shared__ unsigned short q_dst[FAST1 ? 4 : 1][FAST1 ? QCAP : 1];           // (owner lane << 6) | slot in s_rows
     __shared__ unsigned q_n[4];
     __shared__ int s_rows[RB * NPX][256];                                        // phase-1 rows, one column per lane
+    __shared__ float s_lut[I == 2 ? 1 : 448];                                    // bicubic / Lanczos4 tap table
     const int wave = threadIdx.y, lane = threadIdx.x, tid = wave * 64 + lane;
+    if (I != 2) {
+        for (int i = tid; i < 448; i += 256) s_lut[i] = GFW_COEFFS[i];
+        __syncthreads();
+    }
     const bool two_pass = A.matrix_count > 1 && !(A.ablate & 1);
     const bool hrs = A.hrs != 0;
 
@@ -332,7 +498,7 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
     for (int c = 0; c < N0; ++c) bg_y[c] = vu(A.pl[0].bg[c]);
     const float lim_y = vu(A.pl[0].limit);
     float bg_c[2] = {vu(A.pl[1].bg[0]), vu(A.pl[1].bg[1])};
-    const float lim_u = vu(A.pl[1].limit);
+    const float lim_u = vu(A.pl[1].limit), bg_v = vu(A.pl[2].bg[0]), lim_v = vu(A.pl[2].limit);
     Mid M{0, 0, 0, 0, 0, 0, 0, 0, 0};
     P1 Q{0, 0, 0, 0, 0, 0};
     if (two_pass) {
@@ -432,12 +598,19 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
                     if (k == 0) { u0 = p.x; v0 = p.y; ok0 = p.ok; }
                     const float lu = map_c(p.x, MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c(p.y, MP.mul_ly, MP.den_y, MP.rcp_y);   // cpu_undistort.rs:511-514
                     if (A.ablate & 2) { if (lane == 99) A.pl[0].dst[0] = (uint8_t)(lu + lv); continue; }  // timing ablation only
-                    sample_store<T, N0>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly);
+                    if (I == 2) sample_store2<T, N0>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly);
+                    else sample_store<T, N0, I>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly, s_lut);
                 }
                 if (A.nplanes > 1 && !(A.ablate & 4)) {
                     const float cu = map_c(u0, MP.mul_cx, MP.den_x, MP.rcp_x), cv = map_c(v0, MP.mul_cy, MP.den_y, MP.rcp_y);
-                    if (INTERLEAVED_UV) sample_store<T, 2>(cu, cv, ok0, A.pl[1], bg_c, lim_u, cx, cy);
-                    else sample_store_shared<T>(cu, cv, ok0, A.pl, 1, A.nplanes - 1, cx, cy);
+                    if (I == 2) {
+                        if (INTERLEAVED_UV) sample_store2<T, 2>(cu, cv, ok0, A.pl[1], bg_c, lim_u, cx, cy);
+                        else if (A.nplanes == 3) sample_store_uv2<T>(cu, cv, ok0, A.pl[1], A.pl[2], bg_c[0], bg_v, lim_u, lim_v, cx, cy);
+                        else sample_store_shared2<T>(cu, cv, ok0, A.pl, 1, A.nplanes - 1, cx, cy);
+                    } else {
+                        if (INTERLEAVED_UV) sample_store<T, 2, I>(cu, cv, ok0, A.pl[1], bg_c, lim_u, cx, cy, s_lut);
+                        else sample_store_shared<T, I>(cu, cv, ok0, A.pl, 1, A.nplanes - 1, cx, cy, s_lut);
+                    }
                 }
             }
         }
@@ -445,7 +618,7 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
     }
 }
 
-template <int MODEL, typename T, int N0, int RB, bool FAST1, bool AUDIT>
+template <int MODEL, typename T, int N0, int I, int RB, bool FAST1, bool AUDIT>
 hipError_t launch_mt(const GfwYuvArgs &A, int dw, int dh, bool interleaved, hipStream_t s) {
     const int n_tiles = A.tiles_x * A.tiles_y;
     if (n_tiles <= 0) return hipSuccess;
@@ -455,7 +628,7 @@ hipError_t launch_mt(const GfwYuvArgs &A, int dw, int dh, bool interleaved, hipS
     if (grid > per_xcd * 8) grid = per_xcd * 8;
     grid = (grid + 7) & ~7;
     dim3 block(64, 4);
-#define GFW_YUV_LAUNCH(DW, DH, IL) hipLaunchKernelGGL((gfw_yuv_kernel<MODEL, T, N0, DW, DH, IL, RB, FAST1, AUDIT>), dim3(grid), block, 0, s, A)
+#define GFW_YUV_LAUNCH(DW, DH, IL) hipLaunchKernelGGL((gfw_yuv_kernel<MODEL, T, N0, I, DW, DH, IL, RB, FAST1, AUDIT>), dim3(grid), block, 0, s, A)
     if (N0 > 1 || is_f32<T>::value) {                    // packed single plane, or planar f32 planes: full resolution only
         if (dw == 1 && dh == 1 && !interleaved) GFW_YUV_LAUNCH(1, 1, false);
         else return hipErrorInvalidValue;
@@ -476,16 +649,18 @@ hipError_t launch_mt(const GfwYuvArgs &A, int dw, int dh, bool interleaved, hipS
 
 template <int MODEL, typename T, int N0>
 static hipError_t launch_tn(const GfwYuvArgs &A, int dw, int dh, bool interleaved, bool fast1, hipStream_t s) {
+    constexpr int I = GFW_FRAME_TAPS;
     if (MODEL == GFW_MODEL_OPENCV_FISHEYE && fast1) {
-        if (A.audit) return launch_mt<MODEL, T, N0, GFW_YUV_RB_FAST, true, true>(A, dw, dh, interleaved, s);
-        return launch_mt<MODEL, T, N0, GFW_YUV_RB_FAST, true, false>(A, dw, dh, interleaved, s);
+        if (I == 2 && A.audit) return launch_mt<MODEL, T, N0, I, GFW_YUV_RB_FAST, true, (I == 2)>(A, dw, dh, interleaved, s);
+        return launch_mt<MODEL, T, N0, I, GFW_YUV_RB_FAST, true, false>(A, dw, dh, interleaved, s);
     }
-    return launch_mt<MODEL, T, N0, GFW_YUV_RB_EXACT, false, false>(A, dw, dh, interleaved, s);
+    return launch_mt<MODEL, T, N0, I, GFW_YUV_RB_EXACT, false, false>(A, dw, dh, interleaved, s);
 }
-// This translation unit is compiled once per sample kind (-DGFW_FRAME_KIND=1|2|4: u8, u16, f32) so that the three
-// families of instantiations build in parallel; gfw_kernels.hip dispatches on the kind.
-#ifndef GFW_FRAME_KIND
-#error "compile with -DGFW_FRAME_KIND=1, 2 or 4"
+// This translation unit is compiled once per (sample kind, tap count): -DGFW_FRAME_KIND=1|2|4 (u8, u16, f32) and
+// -DGFW_FRAME_TAPS=2|4|8 (bilinear, bicubic, Lanczos4), so that the nine families of instantiations build in parallel;
+// gfw_kernels.hip dispatches on both.
+#if !defined(GFW_FRAME_KIND) || !defined(GFW_FRAME_TAPS)
+#error "compile with -DGFW_FRAME_KIND=1|2|4 -DGFW_FRAME_TAPS=2|4|8"
 #endif
 template <int MODEL>
 static hipError_t launch_m(const GfwYuvArgs &A, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s) {
@@ -506,7 +681,8 @@ static hipError_t launch_m(const GfwYuvArgs &A, int n0, int dw, int dh, bool int
 
 #define GFW_CAT2(a, b) a##b
 #define GFW_CAT(a, b) GFW_CAT2(a, b)
-hipError_t GFW_CAT(gfw_launch_yuv_kind, GFW_FRAME_KIND)(const GfwYuvArgs &A, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s) {
+#define GFW_FN GFW_CAT(GFW_CAT(gfw_launch_yuv_kind, GFW_FRAME_KIND), GFW_CAT(_taps, GFW_FRAME_TAPS))
+hipError_t GFW_FN(const GfwYuvArgs &A, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s) {
     if (A.model == GFW_MODEL_OPENCV_FISHEYE) return launch_m<GFW_MODEL_OPENCV_FISHEYE>(A, n0, dw, dh, interleaved, fast1, s);
     return launch_m<-1>(A, n0, dw, dh, interleaved, false, s);
 }
