@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)
+    ap.add_argument("--build-matrices", action="store_true",
+                    help="build every frame's per-row matrices on the device from quaternion tracks (gfw_build_matrices, "
+                         "the 'next' row f-1) inside the timed region instead of using pre-packed resident tables")
     ap.add_argument("--upload-matrices", action="store_true",
                     help="upload the per-row matrices from host memory every frame (the reference's OpenCL backend does, "
                          "opencl.rs:406) instead of keeping the pre-packed tables of the clip resident in HBM")
@@ -95,7 +98,21 @@ def main():
     if args.grid:
         be.set_option(abi.OPT_TUNE_GRID, args.grid)
 
-    if args.upload_matrices:
+    if args.build_matrices:
+        org = S.sampled_track(11 + rank, 0.0, 1000.0 + 33.4 * (args.steps + args.warmup + 2), 1000.0)
+        smo = S.sampled_track(12 + rank, 0.0, 1000.0 + 33.4 * (args.steps + args.warmup + 2), 200.0, scale=0.25)
+        be.set_quaternion_tracks(org, smo)
+        be.set_option(abi.OPT_MATRICES_ON_DEVICE, 2)
+        nk = S.new_k(frames[0].lens, fov, W, H)
+        table = be.build_matrices(nk, 1000.0, 16.0, H, H)          # context-owned table: same pointer every frame
+        be.synchronize()
+        calls = [warp.FrameCall(be, bufsets[i * 2 + j], params[i], types, table, H) for i in range(N_DISTINCT) for j in range(2)]
+        timing = abi.FrameTiming()
+        timing.frame_readout_time_ms, timing.rows, timing.readout_dim = 16.0, H, H
+        for i, v in enumerate(np.asarray(nk, dtype=np.float64).reshape(9)):
+            timing.new_k[i] = v
+        build_fn, ctxp, tref = be.lib.gfw_build_matrices, be.ctx, C.byref(timing)
+    elif args.upload_matrices:
         calls = [warp.FrameCall(be, bufsets[i * 2 + j], params[i], types, frames[i].matrices) for i in range(N_DISTINCT) for j in range(2)]
     else:
         d_mat = [torch.from_numpy(warp.pack_matrices(fr.matrices)).to(dev) for fr in frames]
@@ -104,6 +121,9 @@ def main():
                  for i in range(N_DISTINCT) for j in range(2)]
 
     def step(k):
+        if args.build_matrices:
+            timing.timestamp_ms = 1000.0 + 33.3 * k
+            build_fn(ctxp, tref, None, None)
         calls[(k % N_DISTINCT) * 2 + (k & 1)]()
 
     for k in range(args.warmup):
@@ -145,7 +165,8 @@ def main():
                                % ("C2" if (W, H, args.fmt) == (3840, 2160, FMT) else "C3" if (W, H, args.fmt) == (7680, 4320, FMT) else "C4" if args.crop else "custom",
                                   W, H, args.fmt, frames[0].matrices.shape[0],
                                   {2: "bilinear", 4: "bicubic", 8: "Lanczos4"}.get(args.interp, str(args.interp)),
-                                  " (matrices re-uploaded per frame)" if args.upload_matrices else ""),
+                                  " (matrices re-uploaded per frame)" if args.upload_matrices else
+                                  " (per-row matrices built on the device every frame from quaternion tracks)" if args.build_matrices else ""),
                    "frames_per_rank": args.steps, "parallelism": "frame-sharded x%d" % world,
                    "backend": warp.last_backend(), "checksum": crc,
                    "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 5)},
@@ -176,6 +197,7 @@ def main():
         i = (n_cpu - 1) % N_DISTINCT
         be.set_option(abi.OPT_SYNCHRONOUS, 1)
         be.set_option(abi.OPT_MATRICES_ON_DEVICE, 0)
+        be.get_profile(reset=True)
         be.undistort_frame(bufsets[i * 2], params[i], types, frames[i].matrices)
         ok = all(np.array_equal(ref[p], d_dst[0][p].cpu().numpy()) for p in range(nplanes))
         out["config"]["parity_vs_oracle"] = "bit-exact" if ok else "MISMATCH"

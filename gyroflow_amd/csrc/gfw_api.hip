@@ -523,7 +523,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     for (int i = 0; i < nplanes; ++i) {
         const gfw_kernel_params &p = params[i];
         if ((p.interpolation != 2 && p.interpolation != 4 && p.interpolation != 8) || p.interpolation != p0.interpolation) return false;
-        if (p.background_mode != 0 || p.input_rotation != 0.0f) return false;
+        if (p.background_mode < 0 || p.background_mode > 2 || p.background_mode != p0.background_mode || p.input_rotation != 0.0f) return false;
         if (p.lens_correction_amount < 1.0f || !(p.lens_correction_amount == p.lens_correction_amount)) return false;
         if (p.light_refraction_coefficient != 1.0f && p.light_refraction_coefficient > 0.0f) return false;
         if (!(p.light_refraction_coefficient == p.light_refraction_coefficient)) return false;
@@ -600,6 +600,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     Y.cw = (p0.output_width + dw - 1) / dw; Y.ch = (p0.output_height + dh - 1) / dh;
     Y.matrix_count = matrix_count;
     Y.hrs = (p0.flags & GFW_FLAG_HORIZONTAL_RS) ? 1 : 0;
+    Y.background_mode = p0.background_mode;
     Y.model = c->model;
     Y.k_all_zero = (p0.k[0] == 0.0f && p0.k[1] == 0.0f && p0.k[2] == 0.0f && p0.k[3] == 0.0f) ? 1 : 0;
     Y.hstretch = p0.input_horizontal_stretch; Y.vstretch = p0.input_vertical_stretch;

@@ -31,6 +31,7 @@ struct GfwYuvArgs {
     int32_t model;
     int32_t k_all_zero;               // k[0..3] all zero (opencv_fisheye.rs:75)
     int32_t hstretch_div, vstretch_div;
+    int32_t background_mode;          // 0 solid, 1 edge repeat, 2 edge mirror (3 = margin+feather stays on the per-plane kernel)
     int32_t grid_limit;               // persistent workgroups to launch (0 = default)
     int32_t ablate;                   // benchmark-only ablation bits (0 in production): 1 no first pass, 2 no luma taps, 4 no chroma, 8 no projection
     float hstretch, vstretch;

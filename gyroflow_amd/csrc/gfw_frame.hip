@@ -595,6 +595,20 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
                     GfwPt p;
                     if (A.ablate & 8) { p.x = ox * 0.5f; p.y = oy * 0.5f; p.ok = true; }              // timing ablation only
                     else p = rd_row<MODEL>(ox, oy, min(sy, A.matrix_count - 1), L, A);
+                    if (A.background_mode != 0 && p.ok) {                      // cpu_undistort.rs:495-509 (edge repeat / edge mirror)
+                        const float width_f = (float)A.width, height_f = (float)A.height;
+                        if (A.background_mode == 1) {
+                            p.x = fminf(fmaxf(p.x, 3.0f), width_f - 3.0f);
+                            p.y = fminf(fmaxf(p.y, 3.0f), height_f - 3.0f);
+                        } else {
+                            const float rx = roundf(p.x), ry = roundf(p.y);
+                            const float width3 = width_f - 3.0f, height3 = height_f - 3.0f;
+                            if (rx > width3)  p.x = width3  - (rx - width3);
+                            if (rx < 3.0f)    p.x = 3.0f + width_f - (width3  + rx);
+                            if (ry > height3) p.y = height3 - (ry - height3);
+                            if (ry < 3.0f)    p.y = 3.0f + height_f - (height3 + ry);
+                        }
+                    }
                     if (k == 0) { u0 = p.x; v0 = p.y; ok0 = p.ok; }
                     const float lu = map_c(p.x, MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c(p.y, MP.mul_ly, MP.den_y, MP.rcp_y);   // cpu_undistort.rs:511-514
                     if (A.ablate & 2) { if (lane == 99) A.pl[0].dst[0] = (uint8_t)(lu + lv); continue; }  // timing ablation only

@@ -20,7 +20,8 @@ def frames_for_rank(rank, world, total_frames):
 
 
 def init(backend, rank, world, device=None):
-    if world <= 1:
+    # GFW_FORCE_DIST=1 initialises the process group even for a single rank (lets a 1-GPU box exercise the RCCL calls)
+    if world <= 1 and os.environ.get("GFW_FORCE_DIST", "") == "":
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -1,0 +1,101 @@
+"""C-ABI error behaviour on a real device: mismatches are reported as codes (the reference logs and skips the frame,
+opencl.rs:336-358), nothing aborts, and the output buffer is left untouched."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gyroflow_amd import abi, synthetic as S, warp
+
+pytestmark = pytest.mark.gpu
+
+
+def setup():
+    fr = S.SyntheticFrame("NV12", 128, 64, seed=3)
+    pl = fr.planes[0]
+    dst = pl["dst"].copy()
+    b = warp.host_buffers(pl["src"], pl["size"], dst, pl["out_size"])
+    be = warp.Backend(pl["params"], pl["pixel_type"], fr.model, 0, b)
+    return fr, pl, dst, b, be
+
+
+def test_matrix_table_larger_than_created_for_is_rejected():
+    fr, pl, dst, b, be = setup()
+    try:
+        too_many = np.zeros((pl["params"].height + 5, 14), dtype=np.float32)
+        kp = pl["params"].copy()
+        kp.matrix_count = too_many.shape[0]
+        with pytest.raises(warp.GfwError) as e:
+            be.undistort_image(b, kp, too_many)
+        assert e.value.name == "BufferSizeMismatch" and "matrices" in str(e.value)
+        assert np.all(dst == 0x5A)
+    finally:
+        be.close()
+
+
+def test_input_length_mismatch_and_bad_rect_and_stride():
+    fr, pl, dst, b, be = setup()
+    try:
+        b2 = warp.host_buffers(pl["src"][:-256], pl["size"], dst, pl["out_size"])
+        with pytest.raises(warp.GfwError) as e:
+            be.undistort_image(b2, pl["params"], fr.matrices)
+        assert e.value.name == "BufferSizeMismatch"
+        kp = pl["params"].copy()
+        kp.source_rect[3] = 4096                              # source rect taller than the buffer
+        with pytest.raises(warp.GfwError) as e:
+            be.undistort_image(b, kp, fr.matrices)
+        assert e.value.name == "BufferSizeMismatch"
+        kp = pl["params"].copy()
+        kp.stride = 64                                        # < width: InvalidStride (mod.rs:639)
+        with pytest.raises(warp.GfwError) as e:
+            be.undistort_image(b, kp, fr.matrices)
+        assert e.value.name == "InvalidStride"
+        kp = pl["params"].copy()
+        kp.interpolation = 3
+        with pytest.raises(warp.GfwError) as e:
+            be.undistort_image(b, kp, fr.matrices)
+        assert e.value.name == "InvalidArgument"
+        assert np.all(dst == 0x5A)
+        be.undistort_image(b, pl["params"], fr.matrices)       # the context is still usable afterwards
+        assert not np.all(dst == 0x5A)
+    finally:
+        be.close()
+
+
+def test_device_listing_and_info():
+    lib = abi.load_library()
+    buf = C.create_string_buffer(1024)
+    n = lib.gfw_list_devices(buf, 1024)
+    assert n >= 1 and b"[HIP]" in buf.value and b"gfx950" in buf.value
+    assert lib.gfw_set_device(0) == 0
+    assert lib.gfw_set_device(99) == -10
+    assert lib.gfw_get_info(buf, 1024) == 0 and b"CUs" in buf.value
+
+
+def test_asynchronous_mode_with_many_frames_in_flight():
+    """GFW_OPT_SYNCHRONOUS = 0 with HIP_DEVICE buffers: 12 frames with different matrices are enqueued back to back
+    (more than the 4-slot matrix ring) and every result must match its own synchronous run."""
+    import torch
+    import _oracle as O
+    frames = [S.SyntheticFrame("YUV422P16LE", 256, 128, seed=60 + i, timestamp_ms=900.0 + 40.0 * i) for i in range(12)]
+    dev = torch.device("cuda", 0)
+    types = [pl["pixel_type"] for pl in frames[0].planes]
+    srcs = [[torch.from_numpy(pl["src"]).to(dev) for pl in fr.planes] for fr in frames]
+    dsts = [[torch.zeros(pl["dst"].nbytes, dtype=torch.uint8, device=dev) for pl in fr.planes] for fr in frames]
+    bufs = [[warp.device_buffers(s.data_ptr(), s.numel(), pl["size"], d.data_ptr(), d.numel(), pl["out_size"])
+             for s, d, pl in zip(ss, dd, fr.planes)] for ss, dd, fr in zip(srcs, dsts, frames)]
+    be = warp.Backend(frames[0].planes[0]["params"], types[0], frames[0].model, 0, bufs[0][0])
+    try:
+        be.set_option(abi.OPT_SYNCHRONOUS, 0)
+        for fr, bb in zip(frames, bufs):
+            be.undistort_frame(bb, [pl["params"] for pl in fr.planes], types, fr.matrices)
+        be.synchronize()
+    finally:
+        be.close()
+    for fr, dd in zip(frames, dsts):
+        ref = O.run_frame(fr)
+        for p, (r, d, pl) in enumerate(zip(ref, dd, fr.planes)):
+            h, stride = pl["out_size"][1], pl["out_size"][2]
+            w_bytes = pl["out_size"][0] * pl["params"].bytes_per_pixel
+            got = d.cpu().numpy().reshape(h, stride)[:, :w_bytes]
+            assert np.array_equal(r.reshape(h, stride)[:, :w_bytes], got)

@@ -92,6 +92,13 @@ def test_fused_kernel_out_of_frame_and_edges():
     check_frame(S.SyntheticFrame("NV12", 320, 192, seed=17, fov=3.0, background_rgba=(0.25, 0.5, 0.75, 1.0)), expect_backend="yuv_fused")
 
 
+@pytest.mark.parametrize("bgmode", [1, 2])
+def test_fused_kernel_edge_repeat_and_mirror(bgmode):
+    ov = {"background_mode": bgmode}
+    check_frame(S.SyntheticFrame("YUV422P16LE", 320, 192, seed=27, fov=2.2, base_overrides=ov), expect_backend="yuv_fused")
+    check_frame(S.SyntheticFrame("NV12", 320, 192, seed=27, fov=2.2, base_overrides=ov, interpolation=8), expect_backend="yuv_fused")
+
+
 def test_fused_kernel_odd_sizes():
     check_frame(S.SyntheticFrame("YUV422P16LE", 322, 190, seed=19), expect_backend="yuv_fused")
     check_frame(S.SyntheticFrame("YUV420P", 130, 66, seed=19), expect_backend="yuv_fused")
