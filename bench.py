@@ -32,7 +32,10 @@ from gyroflow_amd import abi, shard, synthetic as S, warp
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FMT, WIDTH, HEIGHT = "YUV422P16LE", 3840, 2160
-N_DISTINCT = 4                   # distinct resident source frames / matrix sets cycled by the steps
+N_DISTINCT = 4                   # host-generated source frames (the oracle's parity spot check runs on these)
+N_RESIDENT = 64                  # distinct source frames + per-row matrix tables resident in HBM, cycled by the steps
+                                 # (SURVEY.md 8d "64 distinct resident source frames cycled": 4.2 GB, far beyond L2 + MALL)
+N_DST = 4                        # destination frame sets written round-robin
 
 
 def main():
@@ -47,6 +50,7 @@ def main():
     ap.add_argument("--fov", type=float, default=1.0)
     ap.add_argument("--interp", type=int, default=2, help="2 bilinear (north-star), 4 bicubic, 8 Lanczos4 (the reference's render default, cli.rs:618)")
     ap.add_argument("--crop", action="store_true", help="C4: adaptive-zoom crop (fov 0.82 + non-zero translation2d)")
+    ap.add_argument("--resident", type=int, default=N_RESIDENT, help="distinct source frames / matrix tables kept in HBM and cycled")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)
@@ -77,16 +81,25 @@ def main():
                                fov=fov, base_overrides=ov, interpolation=args.interp)
               for i in range(N_DISTINCT)]
     nplanes = len(frames[0].planes)
-    d_src = [[torch.from_numpy(pl["src"]).to(dev) for pl in fr.planes] for fr in frames]
-    d_dst = [[torch.empty(pl["dst"].nbytes, dtype=torch.uint8, device=dev) for pl in frames[0].planes] for _ in range(2)]
+    NR = max(N_DISTINCT, args.resident)
+    base_src = [[torch.from_numpy(pl["src"]).to(dev) for pl in fr.planes] for fr in frames]
+    # resident set j < 4 is host frame j itself; the others are byte-rotated copies (distinct content, same statistics)
+    d_src = [[base_src[j % N_DISTINCT][p] if j < N_DISTINCT else torch.roll(base_src[j % N_DISTINCT][p], 4098 * j)
+              for p in range(nplanes)] for j in range(NR)]
+    d_dst = [[torch.empty(pl["dst"].nbytes, dtype=torch.uint8, device=dev) for pl in frames[0].planes] for _ in range(N_DST)]
     types = [pl["pixel_type"] for pl in frames[0].planes]
-    bufsets = []
-    for i, fr in enumerate(frames):
-        for j in range(2):
-            bufsets.append([warp.device_buffers(d_src[i][p].data_ptr(), d_src[i][p].numel(), pl["size"],
-                                                d_dst[j][p].data_ptr(), d_dst[j][p].numel(), pl["out_size"])
+    bufsets = []                                      # bufsets[j * N_DST + d]: source set j -> destination set d
+    for j in range(NR):
+        fr = frames[j % N_DISTINCT]
+        for d in range(N_DST):
+            bufsets.append([warp.device_buffers(d_src[j][p].data_ptr(), d_src[j][p].numel(), pl["size"],
+                                                d_dst[d][p].data_ptr(), d_dst[d][p].numel(), pl["out_size"])
                             for p, pl in enumerate(fr.planes)])
-    params = [[pl["params"] for pl in fr.planes] for fr in frames]
+    # clip-invariant block (lens + per-plane KernelParams template): rank 0's copy is the one every rank uses
+    blob = shard.broadcast_bytes(dist, b"".join(bytes(pl["params"]) for pl in frames[0].planes), dev)
+    ksz = C.sizeof(abi.KernelParams)
+    tmpl = [abi.KernelParams.from_buffer_copy(blob[k * ksz:(k + 1) * ksz]) for k in range(nplanes)]
+    params = [tmpl for _ in frames]
     be = warp.Backend(params[0][0], types[0], frames[0].model, frames[0].digital, bufsets[0][0])
     stream = torch.cuda.current_stream(dev)
     be.set_stream(stream.cuda_stream)
@@ -98,6 +111,16 @@ def main():
     if args.grid:
         be.set_option(abi.OPT_TUNE_GRID, args.grid)
 
+    rows_n = frames[0].matrices.shape[0]
+
+    def matrix_sets():
+        """One per-row matrix table per resident frame: its own timestamp on the synthetic camera track."""
+        sets = [fr.matrices for fr in frames]
+        for j in range(N_DISTINCT, NR):
+            sets.append(S.row_matrices(frames[0].lens, fov, (W, H), (W, H), 1000.0 + 33.3 * (rank * 1000 + j), 16.0,
+                                       0x9F10 + rank * 1000 + j))
+        return sets
+
     if args.build_matrices:
         org = S.sampled_track(11 + rank, 0.0, 1000.0 + 33.4 * (args.steps + args.warmup + 2), 1000.0)
         smo = S.sampled_track(12 + rank, 0.0, 1000.0 + 33.4 * (args.steps + args.warmup + 2), 200.0, scale=0.25)
@@ -106,25 +129,25 @@ def main():
         nk = S.new_k(frames[0].lens, fov, W, H)
         table = be.build_matrices(nk, 1000.0, 16.0, H, H)          # context-owned table: same pointer every frame
         be.synchronize()
-        calls = [warp.FrameCall(be, bufsets[i * 2 + j], params[i], types, table, H) for i in range(N_DISTINCT) for j in range(2)]
+        calls = [warp.FrameCall(be, bufsets[j * N_DST + (j % N_DST)], params[j % N_DISTINCT], types, table, H) for j in range(NR)]
         timing = abi.FrameTiming()
         timing.frame_readout_time_ms, timing.rows, timing.readout_dim = 16.0, H, H
         for i, v in enumerate(np.asarray(nk, dtype=np.float64).reshape(9)):
             timing.new_k[i] = v
         build_fn, ctxp, tref = be.lib.gfw_build_matrices, be.ctx, C.byref(timing)
     elif args.upload_matrices:
-        calls = [warp.FrameCall(be, bufsets[i * 2 + j], params[i], types, frames[i].matrices) for i in range(N_DISTINCT) for j in range(2)]
+        mats = matrix_sets()
+        calls = [warp.FrameCall(be, bufsets[j * N_DST + (j % N_DST)], params[j % N_DISTINCT], types, mats[j]) for j in range(NR)]
     else:
-        d_mat = [torch.from_numpy(warp.pack_matrices(fr.matrices)).to(dev) for fr in frames]
+        d_mat = [torch.from_numpy(warp.pack_matrices(m)).to(dev) for m in matrix_sets()]
         be.set_option(abi.OPT_MATRICES_ON_DEVICE, 2)
-        calls = [warp.FrameCall(be, bufsets[i * 2 + j], params[i], types, d_mat[i].data_ptr(), frames[i].matrices.shape[0])
-                 for i in range(N_DISTINCT) for j in range(2)]
+        calls = [warp.FrameCall(be, bufsets[j * N_DST + (j % N_DST)], params[j % N_DISTINCT], types, d_mat[j].data_ptr(), rows_n) for j in range(NR)]
 
     def step(k):
         if args.build_matrices:
             timing.timestamp_ms = 1000.0 + 33.3 * k
             build_fn(ctxp, tref, None, None)
-        calls[(k % N_DISTINCT) * 2 + (k & 1)]()
+        calls[k % NR]()
 
     for k in range(args.warmup):
         step(k)
@@ -146,10 +169,11 @@ def main():
 
     # checksum of the last frame's planes (checksum of checksums across ranks)
     crc = 0
-    last = (args.steps - 1) & 1
+    last = ((args.steps - 1) % NR) % N_DST
     for p in range(nplanes):
         crc = zlib.crc32(d_dst[last][p].cpu().numpy().tobytes(), crc)
     elapsed = shard.reduce_max(dist, elapsed, dev)
+    rank_crcs = [g[0] for g in shard.gather_checksums(dist, [crc], dev)]
     crc = shard.reduce_checksum(dist, crc, dev)
 
     luma_px = frames[0].luma_pixels()
@@ -161,14 +185,14 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 coordinates, %s pixels" % np.dtype(abi.PIXEL_TYPES[types[0]][1]).name, "data": "synthetic",
         "config": {"workload": "%s: %dx%d %s, opencv_fisheye GoPro-style lens, rolling shutter matrix_count=%d, %s, "
-                               "frames + per-row matrix tables resident in HBM%s"
+                               "%d frames + per-row matrix tables resident in HBM%s"
                                % ("C2" if (W, H, args.fmt) == (3840, 2160, FMT) else "C3" if (W, H, args.fmt) == (7680, 4320, FMT) else "C4" if args.crop else "custom",
                                   W, H, args.fmt, frames[0].matrices.shape[0],
-                                  {2: "bilinear", 4: "bicubic", 8: "Lanczos4"}.get(args.interp, str(args.interp)),
+                                  {2: "bilinear", 4: "bicubic", 8: "Lanczos4"}.get(args.interp, str(args.interp)), NR,
                                   " (matrices re-uploaded per frame)" if args.upload_matrices else
                                   " (per-row matrices built on the device every frame from quaternion tracks)" if args.build_matrices else ""),
                    "frames_per_rank": args.steps, "parallelism": "frame-sharded x%d" % world,
-                   "backend": warp.last_backend(), "checksum": crc,
+                   "backend": warp.last_backend(), "checksum": crc, "rank_checksums": rank_crcs,
                    "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 5)},
     }
     if launches:
@@ -198,7 +222,7 @@ def main():
         be.set_option(abi.OPT_SYNCHRONOUS, 1)
         be.set_option(abi.OPT_MATRICES_ON_DEVICE, 0)
         be.get_profile(reset=True)
-        be.undistort_frame(bufsets[i * 2], params[i], types, frames[i].matrices)
+        be.undistort_frame(bufsets[i * N_DST], params[i], types, frames[i].matrices)
         ok = all(np.array_equal(ref[p], d_dst[0][p].cpu().numpy()) for p in range(nplanes))
         out["config"]["parity_vs_oracle"] = "bit-exact" if ok else "MISMATCH"
     be.close()

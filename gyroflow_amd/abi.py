@@ -105,6 +105,8 @@ ERRORS = {
     -9: "InvalidArgument", -10: "NoDevice", -11: "HipError", -100: "Unknown",
 }
 
+ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP = -9, -10, -11
+POINT_INDEX_SINGLE, POINT_INDEX_PER_POINT, POINT_INDEX_PER_ROW, POINT_INDEX_PER_COLUMN = 0, 1, 2, 3
 OPT_SYNCHRONOUS, OPT_MATRICES_ON_DEVICE, OPT_KERNEL_VARIANT, OPT_PROFILE, OPT_TUNE_ROWS, OPT_TUNE_GRID = 1, 2, 3, 4, 5, 6
 
 _lib = None
@@ -134,6 +136,7 @@ def bind(lib):
     lib.gfw_set_quaternion_tracks.argtypes = [vp, vp, vp, i32, vp, vp, i32]; lib.gfw_set_quaternion_tracks.restype = i32
     lib.gfw_build_matrices.argtypes = [vp, C.POINTER(FrameTiming), vp, C.POINTER(vp)]; lib.gfw_build_matrices.restype = i32
     lib.gfw_stmap_undistort.argtypes = [vp, C.POINTER(KernelParams), vp, i32, vp, sz, i32, i32, vp, i32]; lib.gfw_stmap_undistort.restype = i32
+    lib.gfw_undistort_points.argtypes = [vp, C.POINTER(KernelParams), vp, sz, i32, vp, i32, vp, i32, vp, sz, vp, i32]; lib.gfw_undistort_points.restype = i32
     lib.gfw_pack_matrices.argtypes = [vp, i32, vp]; lib.gfw_pack_matrices.restype = i32
     lib.gfw_get_audit.argtypes = [vp, C.POINTER(C.c_ulonglong * 8), i32]; lib.gfw_get_audit.restype = i32
     lib.gfw_debug_math.argtypes = [i32, vp, vp, vp, sz]; lib.gfw_debug_math.restype = i32
@@ -146,7 +149,7 @@ def bind(lib):
 
 EXPORTS = ["gfw_abi_version", "gfw_list_devices", "gfw_set_device", "gfw_get_info", "gfw_is_buffer_supported",
            "gfw_create", "gfw_destroy", "gfw_undistort_image", "gfw_undistort_frame", "gfw_set_option",
-           "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_last_backend", "gfw_get_profile", "gfw_last_error", "gfw_debug_math", "gfw_debug_selftest", "gfw_get_audit", "gfw_pack_matrices", "gfw_set_quaternion_tracks", "gfw_build_matrices", "gfw_stmap_undistort",
+           "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_last_backend", "gfw_get_profile", "gfw_last_error", "gfw_debug_math", "gfw_debug_selftest", "gfw_get_audit", "gfw_pack_matrices", "gfw_set_quaternion_tracks", "gfw_build_matrices", "gfw_stmap_undistort", "gfw_undistort_points",
            "gfw_pixel_type_info"]
 
 

@@ -86,6 +86,7 @@ struct gfw_ctx {
     // certified first pass of the fused kernel: s(rho) table cache
     DevBuf d_p1_table, d_audit;
     float p1_k[4] = {0, 0, 0, 0}; float p1_rho_max = 0.0f; double p1_etab = 0.0; double p1_smax = 1.0; bool p1_valid = false;
+    DevBuf d_pts_in, d_pts_out, d_pts_rot, d_pts_shift, d_pts_mesh;   // gfw_undistort_points staging
     DevBuf d_tracks, d_built_rows;                // quaternion tracks + context-owned table of built rows
     GfwTracks tracks = {nullptr, nullptr, 0, nullptr, nullptr, 0};
     bool profile = false;
@@ -227,6 +228,7 @@ void gfw_destroy(gfw_ctx *c) {
     for (auto &b : c->stage_src) b.release();
     for (auto &b : c->stage_dst) b.release();
     c->d_mesh.release(); c->d_p1_table.release(); c->d_audit.release(); c->d_tracks.release(); c->d_built_rows.release();
+    c->d_pts_in.release(); c->d_pts_out.release(); c->d_pts_rot.release(); c->d_pts_shift.release(); c->d_pts_mesh.release();
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (auto &s : c->mslots) {
         if (s.h) (void)hipHostFree(s.h);
@@ -802,6 +804,60 @@ int gfw_build_matrices(gfw_ctx *c, const gfw_frame_timing *t, float *rows16_out,
     if (c->synchronous) HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
     return GFW_OK;
 }
+}
+
+// Inverse point map (`undistort_points`, cpu_undistort.rs:652-858 with lens_correction_amount == 1; the STMap "dist"
+// pass stmap.rs:123-127 runs it per pixel).  See include/gfwarp.h for the argument contract.
+extern "C" int gfw_undistort_points(gfw_ctx *c, const gfw_kernel_params *p, const float *points, size_t n, int grid_width,
+                                    const float *rotations, int rotation_count, const float *shifts, int index_mode,
+                                    const double *mesh, size_t mesh_len, float *out, int out_on_device) {
+    if (!c || !p || !rotations || !out || rotation_count < 1 || index_mode < 0 || index_mode > 3) { set_error("bad undistort_points arguments"); return GFW_ERR_INVALID_ARGUMENT; }
+    if (!points && grid_width < 1) { set_error("grid_width must be >= 1 when points is NULL"); return GFW_ERR_INVALID_ARGUMENT; }
+    if (p->lens_correction_amount < 1.0f) { set_error("undistort_points: lens_correction_amount < 1 (Newton inverse of the render blend, cpu_undistort.rs:792-851) is not provided"); return GFW_ERR_INVALID_ARGUMENT; }
+    if (mesh_len > GFW_MESH_MAX) { set_error("mesh too large"); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
+    if (n == 0) return GFW_OK;                                               // :637 `if distorted.is_empty() { return Vec::new(); }`
+    HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
+    GfwPointsArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n = n; A.grid_w = grid_width; A.rotation_count = rotation_count; A.index_mode = index_mode;
+    const size_t pts_bytes = n * 2 * sizeof(float);
+    if (points) {
+        HIP_TRY(c->d_pts_in.ensure(pts_bytes), GFW_ERR_HIP);
+        HIP_TRY(hipMemcpyAsync(c->d_pts_in.ptr, points, pts_bytes, hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
+        A.points = (const float *)c->d_pts_in.ptr;
+    }
+    HIP_TRY(c->d_pts_rot.ensure((size_t)rotation_count * 9 * sizeof(float)), GFW_ERR_HIP);
+    HIP_TRY(hipMemcpyAsync(c->d_pts_rot.ptr, rotations, (size_t)rotation_count * 9 * sizeof(float), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
+    A.rotations = (const float *)c->d_pts_rot.ptr;
+    std::vector<float> packed;
+    if (shifts) {
+        // cos/sin of the roll angle by the host libm, exactly what the reference evaluates per point (:756-757)
+        packed.resize((size_t)rotation_count * 6);
+        for (int i = 0; i < rotation_count; ++i) {
+            const float *s = shifts + (size_t)i * 5;
+            float *d = packed.data() + (size_t)i * 6;
+            d[0] = s[0]; d[1] = s[1]; d[2] = cosf(s[2]); d[3] = sinf(s[2]); d[4] = s[3]; d[5] = s[4];
+        }
+        HIP_TRY(c->d_pts_shift.ensure(packed.size() * sizeof(float)), GFW_ERR_HIP);
+        HIP_TRY(hipMemcpyAsync(c->d_pts_shift.ptr, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
+        A.shifts = (const float *)c->d_pts_shift.ptr;
+    }
+    if (mesh && mesh_len) {
+        HIP_TRY(c->d_pts_mesh.ensure(mesh_len * sizeof(double)), GFW_ERR_HIP);
+        HIP_TRY(hipMemcpyAsync(c->d_pts_mesh.ptr, mesh, mesh_len * sizeof(double), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
+        A.mesh = (const double *)c->d_pts_mesh.ptr; A.mesh_len = (int)mesh_len;
+    }
+    float *d_out = out;
+    if (!out_on_device) { HIP_TRY(c->d_pts_out.ensure(pts_bytes), GFW_ERR_HIP); d_out = (float *)c->d_pts_out.ptr; }
+    A.out = d_out;
+    GfwCommon C;
+    fill_common(c, p, nullptr, nullptr, 0, C);
+    HIP_TRY(gfw_launch_points(*p, C, A, c->stream), GFW_ERR_HIP);
+    c->last_backend = "points";
+    if (!out_on_device) HIP_TRY(hipMemcpyAsync(out, d_out, pts_bytes, hipMemcpyDeviceToHost, c->stream), GFW_ERR_HIP);
+    // host staging vectors (packed shifts) and pageable copies: always complete before returning
+    HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
+    return GFW_OK;
 }
 
 // STMap "undist" coordinate map (src/core/stmap.rs:87-109, :127-137): coords is width*height*2 f32, host or device

@@ -56,6 +56,95 @@ hipError_t gfw_launch_stmap(const gfw_kernel_params &P, const GfwCommon &C, int 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------- inverse point map
+// `undistort_points` (cpu_undistort.rs:652-858, lens_correction_amount == 1): source-image point -> stabilised output
+// coordinate; the STMap "dist" pass (stmap.rs:123-127) runs it over the pixel grid.  One point per lane; the rotation
+// (and optional IBIS/OIS shift) row is picked per point / grid row / grid column.  shifts rows are 6 floats:
+// sx, sy, cos(angle), sin(angle), ox, oy with the trig evaluated by the host libm (gfw_api.hip).
+template <int MODEL>
+__global__ __launch_bounds__(256) void gfw_points_kernel(const gfw_kernel_params P, const GfwCommon C, const GfwPointsArgs A) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    float x, y; size_t gx = 0, gy = 0;
+    if (A.points) { const float2 p = reinterpret_cast<const float2 *>(A.points)[i]; x = p.x; y = p.y; }
+    else { gy = i / (size_t)A.grid_w; gx = i - gy * (size_t)A.grid_w; x = (float)gx; y = (float)gy; }
+    size_t index = A.index_mode == 1 ? i : A.index_mode == 2 ? gy : A.index_mode == 3 ? gx : 0;
+    if (index >= (size_t)A.rotation_count) index = 0;
+    if (P.input_horizontal_stretch > 0.001f) x *= P.input_horizontal_stretch;                 // :704-705
+    if (P.input_vertical_stretch   > 0.001f) y *= P.input_vertical_stretch;
+    if (C.digital != GFW_MODEL_NONE) {                                                         // :707-712
+        const GfwPt d = gfw_lens::digital_undistort(C.digital, x, y, P);
+        if (d.ok) { x = d.x; y = d.y; }
+    }
+    if (A.mesh_len > 0) {
+        const double *md = A.mesh;
+        if (md[0] > 0.0 && md[gfw_mesh::d2us(md[0])] > 0.0) {                                  // :715-738
+            const int64_t o = gfw_mesh::d2us(md[0]);
+            const double ms1 = md[4];
+            const float or0 = (float)md[5], or1 = (float)md[6], cs0 = (float)md[7], cs1 = (float)md[8];
+            const double grid = ms1 / 8.0;
+            x = gfw_map_coord(x, 0.0f, (float)P.width,  or0, or0 + cs0);
+            y = gfw_map_coord(y, 0.0f, (float)P.height, or1, or1 + cs1);
+            const int64_t idx = gfw_mesh::d2us(fmin(fmax(floor((double)y / grid), 0.0), 7.0));
+            const double delta = (double)y - grid * (double)idx;
+            x += (float)(md[o + 4 + idx * 2 + 0] * delta);
+            y += (float)(md[o + 4 + idx * 2 + 1] * delta);
+            for (int64_t j = 0; j < idx; ++j) {
+                x += (float)(md[o + 4 + j * 2 + 0] * grid);
+                y += (float)(md[o + 4 + j * 2 + 1] * grid);
+            }
+            x = gfw_map_coord(x, or0, or0 + cs0, 0.0f, (float)P.width);
+            y = gfw_map_coord(y, or1, or1 + cs1, 0.0f, (float)P.height);
+        }
+        if (md[0] > 10.0) {                                                                    // :740-752
+            const double ms0 = md[3], ms1 = md[4];
+            const float or0 = (float)md[5], or1 = (float)md[6], cs0 = (float)md[7], cs1 = (float)md[8];
+            x = gfw_map_coord(x, 0.0f, (float)P.width,  or0, or0 + cs0);
+            y = gfw_map_coord(y, 0.0f, (float)P.height, or1, or1 + cs1);
+            const int nx = (int)gfw_mesh::d2us(md[1]), ny = (int)gfw_mesh::d2us(md[2]);
+            const double nxp = gfw_mesh::bivariate(nx, ny, ms0, ms1, md, 0, (double)x, (double)y);
+            const double nyp = gfw_mesh::bivariate(nx, ny, ms0, ms1, md, 1, (double)x, (double)y);
+            x = gfw_map_coord((float)nxp, or0, or0 + cs0, 0.0f, (float)P.width);
+            y = gfw_map_coord((float)nyp, or1, or1 + cs1, 0.0f, (float)P.height);
+        }
+    }
+    const float c0 = P.c[0], c1 = P.c[1];
+    if (A.shifts) {                                                                            // :754-763
+        const float *s = A.shifts + index * 6;
+        x = x - c0 - s[4] + s[0];
+        y = y - c1 - s[5] + s[1];
+        x = s[2] * x - s[3] * y + c0;
+        y = s[3] * x + s[2] * y + c1;                        // the reference rotates y with the already-rotated x
+    }
+    const float pwx = (x - c0) / P.f[0], pwy = (y - c1) / P.f[1];                              // :765
+    const GfwPt pt = gfw_lens::undistort<MODEL>(C.model, pwx, pwy, P, C);
+    float2 o = float2{-1000000.0f, -1000000.0f};                                               // :855
+    if (pt.ok) {
+        float ptx = pt.x, pty = pt.y;
+        if (P.light_refraction_coefficient != 1.0f && P.light_refraction_coefficient > 0.0f) { // :770-779
+            const float rr = sqrtf(ptx * ptx + pty * pty);
+            if (rr != 0.0f) {
+                const float sin_theta_d = (rr / sqrtf(1.0f + rr * rr)) / P.light_refraction_coefficient;
+                const float r_d = sin_theta_d / sqrtf(1.0f - sin_theta_d * sin_theta_d);
+                const float factor = r_d / rr;
+                ptx *= factor; pty *= factor;
+            }
+        }
+        const float *r = A.rotations + index * 9;                                              // :782-783 (nalgebra gemv: column axpy)
+        const float pr0 = ((r[0] * ptx) + r[1] * pty) + r[2];
+        const float pr1 = ((r[3] * ptx) + r[4] * pty) + r[5];
+        const float pr2 = ((r[6] * ptx) + r[7] * pty) + r[8];
+        o = float2{pr0 / pr2, pr1 / pr2};
+    }
+    reinterpret_cast<float2 *>(A.out)[i] = o;
+}
+hipError_t gfw_launch_points(const gfw_kernel_params &P, const GfwCommon &C, const GfwPointsArgs &A, hipStream_t s) {
+    const unsigned blocks = (unsigned)((A.n + 255) / 256);
+    if (C.model == GFW_MODEL_OPENCV_FISHEYE) hipLaunchKernelGGL(gfw_points_kernel<GFW_MODEL_OPENCV_FISHEYE>, dim3(blocks), dim3(256), 0, s, P, C, A);
+    else hipLaunchKernelGGL(gfw_points_kernel<-1>, dim3(blocks), dim3(256), 0, s, P, C, A);
+    return hipGetLastError();
+}
+
 // Row repack: [rows][14] f32 (FrameTransform.matrices) -> [rows][16] with cos(-m11), sin(-m11) slots.
 // Used only for device-resident matrices; the trig slots are 1 / 0 (no IBIS roll), see gfw_api.hip.
 __global__ void gfw_repack_matrices_kernel(const float *in, float *out, int rows) {

@@ -477,7 +477,8 @@ __device__ inline double spline_eval(const double *iv, int n, double size, doubl
     const double dx = x - size * (double)i / (double)(n - 1);
     return a[i] + b[i] * dx + c[i] * dx * dx + d[i] * dx * dx * dx;
 }
-__device__ inline double bivariate(int n_x, int n_y, double size_x, double size_y, const float *mesh, int mesh_offset, double x, double y) {
+template <typename MT>
+__device__ inline double bivariate(int n_x, int n_y, double size_x, double size_y, const MT *mesh, int mesh_offset, double x, double y) {
     double iv[GFW_GRID];
     for (int j = 0; j < GFW_GRID; ++j) iv[j] = 0.0;
     int64_t i = d2us(((double)n_x - 1.0) * x / size_x);

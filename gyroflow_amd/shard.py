@@ -2,8 +2,8 @@
 
 Frames of a clip are independent once clip-level state is fixed (frame_transform.rs:165), so the data path has no
 collective: rank r owns a contiguous-by-stride set of frame indices and its own resident buffers.  The only
-communication is a barrier either side of the timed region, a MAX reduction of the elapsed time and a reduction of
-per-rank output checksums (checksum of checksums).  Backend "nccl" is RCCL over xGMI on ROCm; tests run it on "gloo".
+communication is one broadcast of the clip-invariant parameter block, a barrier either side of the timed region, a MAX
+reduction of the elapsed time, and an all-gather / SUM reduction of output checksums (checksum of checksums).  Backend "nccl" is RCCL over xGMI on ROCm; tests run it on "gloo".
 """
 import os
 
@@ -53,6 +53,27 @@ def reduce_checksum(dist, crc, device="cpu"):
     t = torch.tensor([int(crc)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
+
+
+def broadcast_bytes(dist, payload, device="cpu", src=0):
+    """Rank `src` hands the clip-invariant block (lens + KernelParams template, a few hundred bytes) to every rank
+    (one broadcast, rank 0 -> all).  Every rank passes a payload of the same length."""
+    if dist is None:
+        return bytes(payload)
+    t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
+    dist.broadcast(t, src=src)
+    return bytes(t.cpu().numpy().tobytes())
+
+
+def gather_checksums(dist, crcs, device="cpu"):
+    """All-gather of the per-frame output checksums (8 B per frame): returns [world][len(crcs)] as lists of ints.
+    Every rank contributes the same number of frames (weak scaling)."""
+    if dist is None:
+        return [[int(c) for c in crcs]]
+    t = torch.tensor([int(c) for c in crcs], dtype=torch.int64, device=device)
+    outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [[int(v) for v in o.cpu().tolist()] for o in outs]
 
 
 def finish(dist):

@@ -137,7 +137,7 @@ def new_k(lens, fov, out_w, out_h):
 
 
 def row_matrices(lens, fov, size, out_size, timestamp_ms, frame_readout_time_ms, seed, horizontal_rs=False,
-                 constant_quat=None, ibis=None):
+                 constant_quat=None, ibis=None, return_rotations=False):
     """Per-row ``[f32;14]`` table: ``inv(new_k * R_row)`` + (sx, sy, ra, ox, oy).
 
     Mirrors frame_transform.rs:247-308: rows = H (or W for horizontal RS) when the readout
@@ -148,6 +148,7 @@ def row_matrices(lens, fov, size, out_size, timestamp_ms, frame_readout_time_ms,
     rows = (width if horizontal_rs else height) if abs(frame_readout_time_ms) > 0.0 else 1
     nk = new_k(lens, fov, out_size[0], out_size[1])
     out = np.zeros((rows, 14), dtype=np.float32)
+    fwd = np.zeros((rows, 9), dtype=np.float32)     # `new_k * R` per row: at_timestamp_for_points (frame_transform.rs:391-410)
     start_ts = timestamp_ms - frame_readout_time_ms / 2.0
     row_t = frame_readout_time_ms / (width if horizontal_rs else height)
     if constant_quat is not None:
@@ -171,9 +172,10 @@ def row_matrices(lens, fov, size, out_size, timestamp_ms, frame_readout_time_ms,
         r[1, 0] *= -1.0; r[2, 0] *= -1.0
         i_r = np.linalg.inv(nk @ r)
         out[y, :9] = i_r.reshape(9).astype(np.float32)
+        fwd[y] = (nk @ r).reshape(9).astype(np.float32)
         if ibis is not None:
             out[y, 9:14] = np.asarray(ibis(y), dtype=np.float32)
-    return out
+    return (out, fwd) if return_rotations else out
 
 
 # --------------------------------------------------------------------- KernelParams
@@ -291,8 +293,9 @@ class SyntheticFrame:
         self.lens = lens or gopro_style_lens(width, height)
         self.model = abi.MODELS[self.lens["model"]]
         self.digital = abi.MODELS[self.lens.get("digital", "none")]
-        self.matrices = row_matrices(self.lens, fov, (width, height), self.out_size, timestamp_ms, readout_ms,
-                                     seed, horizontal_rs=horizontal_rs, constant_quat=constant_quat)
+        self.matrices, self.rotations = row_matrices(self.lens, fov, (width, height), self.out_size, timestamp_ms, readout_ms,
+                                                     seed, horizontal_rs=horizontal_rs, constant_quat=constant_quat,
+                                                     return_rotations=True)
         if horizontal_rs:
             flags |= abi.FLAG_HORIZONTAL_RS
         if self.digital:

@@ -125,6 +125,33 @@ class Backend:
         self._check(self.lib.gfw_stmap_undistort(self.ctx, C.byref(params), m.ctypes.data, m.shape[0], meshp, meshn, width, height, coords.ctypes.data, 0))
         return coords
 
+    def undistort_points(self, params, rotations, points=None, grid=None, shifts=None, index_mode=0, mesh=None):
+        """Inverse point map (cpu_undistort.rs:652-858, lens_correction_amount == 1).
+
+        ``points``: [n][2] float32, or None with ``grid=(w, h)`` for the pixel grid.  ``rotations``: [count][9] float32
+        (`new_k * R` row-major), ``shifts``: None or [count][5], ``mesh``: None or float64 mesh data.
+        Returns float32 [n][2] (or [h][w][2] for a grid)."""
+        rot = np.ascontiguousarray(rotations, dtype=np.float32).reshape(-1, 9)
+        if points is not None:
+            pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 2)
+            n, gw, pp, shape = pts.shape[0], 0, pts.ctypes.data, (pts.shape[0], 2)
+        else:
+            gw, gh = grid
+            n, pp, shape = gw * gh, None, (gh, gw, 2)
+        out = np.zeros(shape, dtype=np.float32)
+        sp = None
+        if shifts is not None:
+            shifts = np.ascontiguousarray(shifts, dtype=np.float32).reshape(-1, 5)
+            assert shifts.shape[0] == rot.shape[0]
+            sp = shifts.ctypes.data
+        meshp, meshn = None, 0
+        if mesh is not None and len(mesh):
+            mesh = np.ascontiguousarray(mesh, dtype=np.float64)
+            meshp, meshn = mesh.ctypes.data, mesh.size
+        self._check(self.lib.gfw_undistort_points(self.ctx, C.byref(params), pp, n, gw, rot.ctypes.data, rot.shape[0], sp,
+                                                  index_mode, meshp, meshn, out.ctypes.data, 0))
+        return out
+
     def synchronize(self):
         self._check(self.lib.gfw_synchronize(self.ctx))
 

@@ -314,6 +314,27 @@ int   gfw_build_matrices(gfw_ctx *ctx, const gfw_frame_timing *timing, float *ro
 int   gfw_stmap_undistort(gfw_ctx *ctx, const gfw_kernel_params *params, const float *matrices, int matrix_count,
                           const float *mesh, size_t mesh_len, int width, int height, float *coords, int coords_on_device);
 
+/* ---- inverse point map ("next" row 3: cpu_undistort.rs:652-858 `undistort_points`; stmap.rs:123-127 "dist") ----
+ * Source-image points -> stabilised output coordinates, for lens_correction_amount == 1 (what the STMap "dist"
+ * pass and the optical-flow caller cpu_undistort.rs:643-650 use; params->lens_correction_amount < 1 is refused
+ * with GFW_ERR_INVALID_ARGUMENT).  The lens / digital-lens models are the ones given to gfw_create.
+ *   params     the KernelParams undistort_points builds (:669-681: width/height/output_*, f, c, k,
+ *              digital_lens_params, light_refraction_coefficient) with input_*_stretch = lens.input_*_stretch (:704-705)
+ *   points     n x 2 f32 (host), or NULL = the pixel grid parallel_exr walks: point i = (i % grid_width, i / grid_width)
+ *   rotations  [rotation_count][9] row-major f32 = nalgebra::convert::<f64,f32> of `new_k * R` per point
+ *              (FrameTransform::at_timestamp_for_points, frame_transform.rs:391-410)
+ *   shifts     NULL, or [rotation_count][5] = (sx, sy, angle_rad, ox, oy) (frame_transform.rs:412-440)
+ *   index_mode which rotation/shift row a point uses: GFW_POINT_INDEX_SINGLE (row 0: no rolling shutter),
+ *              _PER_POINT (row i), _PER_ROW (grid y; vertical rolling shutter), _PER_COLUMN (grid x; horizontal);
+ *              an index past rotation_count falls back to row 0 as `rot_per_point.get(index).unwrap_or(&rr)` does
+ *   mesh       NULL, or the f64 lens mesh `undistort_points` receives (:714-753)
+ *   out        n x 2 f32, host or device memory (out_on_device); (-1e6, -1e6) where the lens inverse is None (:855)
+ * Bit-exact vs the CPU statement.  Synchronous. */
+enum { GFW_POINT_INDEX_SINGLE = 0, GFW_POINT_INDEX_PER_POINT = 1, GFW_POINT_INDEX_PER_ROW = 2, GFW_POINT_INDEX_PER_COLUMN = 3 };
+int   gfw_undistort_points(gfw_ctx *ctx, const gfw_kernel_params *params, const float *points, size_t n, int grid_width,
+                           const float *rotations, int rotation_count, const float *shifts, int index_mode,
+                           const double *mesh, size_t mesh_len, float *out, int out_on_device);
+
 /* ---- test hooks (used by tests/test_gpu_math.py; not part of the operator surface) ---------------
  * gfw_debug_math: out[i] = f(a[i], b[i]) evaluated ON THE DEVICE with the kernels' own routines; host arrays.
  *   op 0 gfw_atanf  1 gfw_tanf  2 gfw_atanf_pos  3 lean a/b  4 generic a/b  5 lean sqrt  6 generic sqrt

@@ -1166,6 +1166,103 @@ int gfw_oracle_stmap_undistort(const gfw_kernel_params *p, int distortion_model,
     return 1;
 }
 
+/* Inverse point map: `undistort_points` cpu_undistort.rs:652-858 with lens_correction_amount == 1 (the value the
+ * STMap "dist" pass stmap.rs:123-127 and the optical-flow caller :643-650 use; the < 1 Newton branch :792-851 belongs
+ * to the zoom search and is not restated).  Source-image point -> stabilised output coordinate.
+ *   p         the KernelParams `undistort_points` builds (:669-681: width/height/output_*, f, c, k, digital_lens_params,
+ *             light_refraction_coefficient) plus input_*_stretch carrying params.lens.input_*_stretch (:704-705)
+ *   points    n x 2 f32, or NULL = the pixel grid (x = i % grid_w, y = i / grid_w) that parallel_exr walks
+ *   rotations [rotation_count][9] row-major f32: nalgebra::convert::<Matrix3<f64>, Matrix3<f32>> of `new_k * R`
+ *             (frame_transform.rs:391-410), index chosen by index_mode: 0 single, 1 point index, 2 grid row, 3 grid column
+ *   shifts    optional [rotation_count][5] (sx, sy, angle, ox, oy) (frame_transform.rs:412-440), same indexing
+ *   mesh      optional f64 undistorting mesh (file_metadata.mesh_correction[frame].0, passed as f64: :707)
+ * The 3x3 * (x, y, 1) product follows nalgebra 0.34's gemv (column axpy: ((r0*x) + r1*y) + r2*1) - third-party
+ * arithmetic absent from the tree, restated from its published source; parity unpinned like the rest of the path. */
+int gfw_oracle_undistort_points(const gfw_kernel_params *p, int distortion_model, int digital_lens,
+                                const float *points, size_t n, int grid_w,
+                                const float *rotations, int rotation_count, const float *shifts, int index_mode,
+                                const double *md, size_t mesh_len, float *out)
+{
+    const float c0 = p->c[0], c1 = p->c[1], f0 = p->f[0], f1 = p->f[1];
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) {
+        float x, y; size_t gx = 0, gy = 0;
+        if (points) { x = points[i * 2]; y = points[i * 2 + 1]; }
+        else { gx = i % (size_t)grid_w; gy = i / (size_t)grid_w; x = (float)gx; y = (float)gy; }
+        size_t index = index_mode == 1 ? i : index_mode == 2 ? gy : index_mode == 3 ? gx : 0;
+        if (index >= (size_t)rotation_count) index = 0;        /* rot_per_point.get(index).unwrap_or(&rr), rr = rotations[0] */
+        if (p->input_horizontal_stretch > 0.001f) x *= p->input_horizontal_stretch;        /* :704-705 */
+        if (p->input_vertical_stretch   > 0.001f) y *= p->input_vertical_stretch;
+        if (digital_lens != GFW_MODEL_NONE) {                                               /* :707-712 */
+            opt2 d = digital_undistort(digital_lens, x, y, p);
+            if (d.ok) { x = d.x; y = d.y; }
+        }
+        if (mesh_len > 0) {
+            if (md[0] > 0.0 && md[d2usize(md[0])] > 0.0) {                                  /* :715-738 focal plane distortion */
+                size_t o = (size_t)d2usize(md[0]);
+                double ms1 = md[4];
+                float or0 = (float)md[5], or1 = (float)md[6];
+                float cs0 = (float)md[7], cs1 = (float)md[8];
+                double stblz_grid = ms1 / 8.0;
+                x = map_coord(x, 0.0f, (float)p->width,  or0, or0 + cs0);
+                y = map_coord(y, 0.0f, (float)p->height, or1, or1 + cs1);
+                size_t idx = (size_t)d2usize(fmin(fmax(floor((double)y / stblz_grid), 0.0), 7.0));
+                double delta = (double)y - stblz_grid * (double)idx;
+                x += (float)(md[o + 4 + idx * 2 + 0] * delta);
+                y += (float)(md[o + 4 + idx * 2 + 1] * delta);
+                for (size_t j = 0; j < idx; ++j) {
+                    x += (float)(md[o + 4 + j * 2 + 0] * stblz_grid);
+                    y += (float)(md[o + 4 + j * 2 + 1] * stblz_grid);
+                }
+                x = map_coord(x, or0, or0 + cs0, 0.0f, (float)p->width);
+                y = map_coord(y, or1, or1 + cs1, 0.0f, (float)p->height);
+            }
+            if (md[0] > 10.0) {                                                             /* :740-752 */
+                double ms0 = md[3], ms1 = md[4];
+                float or0 = (float)md[5], or1 = (float)md[6];
+                float cs0 = (float)md[7], cs1 = (float)md[8];
+                x = map_coord(x, 0.0f, (float)p->width,  or0, or0 + cs0);
+                y = map_coord(y, 0.0f, (float)p->height, or1, or1 + cs1);
+                int nx = (int)d2usize(md[1]), ny = (int)d2usize(md[2]);
+                double nxp = bivariate_interpolate(nx, ny, ms0, ms1, md, 0, (double)x, (double)y);
+                double nyp = bivariate_interpolate(nx, ny, ms0, ms1, md, 1, (double)x, (double)y);
+                x = map_coord((float)nxp, or0, or0 + cs0, 0.0f, (float)p->width);
+                y = map_coord((float)nyp, or1, or1 + cs1, 0.0f, (float)p->height);
+            }
+        }
+        if (shifts) {                                                                       /* :754-763 */
+            const float *s = shifts + index * 5;
+            float cos_a = cosf(s[2]), sin_a = sinf(s[2]);
+            x = x - c0 - s[3] + s[0];
+            y = y - c1 - s[4] + s[1];
+            x = cos_a * x - sin_a * y + c0;
+            y = sin_a * x + cos_a * y + c1;                  /* uses the already-rotated x, as the reference does (:761-762) */
+        }
+        float pwx = (x - c0) / f0, pwy = (y - c1) / f1;                                     /* :765 */
+        const float *r = rotations + index * 9;
+        opt2 pt = model_undistort(distortion_model, pwx, pwy, p);
+        if (pt.ok) {
+            float ptx = pt.x, pty = pt.y;
+            if (p->light_refraction_coefficient != 1.0f && p->light_refraction_coefficient > 0.0f) {   /* :770-779 */
+                float rr = sqrtf(ptx * ptx + pty * pty);
+                if (rr != 0.0f) {
+                    float sin_theta_d = (rr / sqrtf(1.0f + rr * rr)) / p->light_refraction_coefficient;
+                    float r_d = sin_theta_d / sqrtf(1.0f - sin_theta_d * sin_theta_d);
+                    float factor = r_d / rr;
+                    ptx *= factor; pty *= factor;
+                }
+            }
+            float pr0 = ((r[0] * ptx) + r[1] * pty) + r[2] * 1.0f;                         /* :782 (nalgebra gemv order) */
+            float pr1 = ((r[3] * ptx) + r[4] * pty) + r[5] * 1.0f;
+            float pr2 = ((r[6] * ptx) + r[7] * pty) + r[8] * 1.0f;
+            out[i * 2] = pr0 / pr2; out[i * 2 + 1] = pr1 / pr2;                             /* :783 */
+        } else {
+            out[i * 2] = -1000000.0f; out[i * 2 + 1] = -1000000.0f;                         /* :855 */
+        }
+    }
+    return 1;
+}
+
 /* Per-model point functions, exposed for the lens-model parity tests. */
 void gfw_oracle_distort_point(int model, const gfw_kernel_params *p, float x, float y, float z, float *out) {
     model_distort(model, x, y, z, p, &out[0], &out[1]);

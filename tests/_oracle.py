@@ -32,6 +32,8 @@ def lib():
         L.gfw_oracle_undistort_point.restype = C.c_int
         L.gfw_oracle_stmap_undistort.argtypes = [C.POINTER(abi.KernelParams), C.c_int, C.c_int, vp, vp, C.c_size_t, C.c_int, C.c_int, vp, C.c_int]
         L.gfw_oracle_stmap_undistort.restype = C.c_int
+        L.gfw_oracle_undistort_points.argtypes = [C.POINTER(abi.KernelParams), C.c_int, C.c_int, vp, C.c_size_t, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_size_t, vp]
+        L.gfw_oracle_undistort_points.restype = C.c_int
         L.gfw_oracle_libm.argtypes = [C.c_int, vp, vp, C.c_size_t]
         L.gfw_oracle_num_threads.restype = C.c_int
         _lib = L
@@ -93,3 +95,33 @@ def stmap_undistort(params, model, digital, matrices, width, height, nthreads=0)
     coords = np.zeros((height, width, 2), dtype=np.float32)
     lib().gfw_oracle_stmap_undistort(C.byref(params), model, digital, m.ctypes.data, None, 0, width, height, coords.ctypes.data, nthreads)
     return coords
+
+
+def undistort_points(params, model, digital, rotations, points=None, grid=None, shifts=None, index_mode=0, mesh=None):
+    """Oracle restatement of `undistort_points` (cpu_undistort.rs:652-858, lens_correction_amount == 1)."""
+    rot = np.ascontiguousarray(rotations, dtype=np.float32).reshape(-1, 9)
+    if points is not None:
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 2)
+        n, gw, pp, shape = pts.shape[0], 0, pts.ctypes.data, (pts.shape[0], 2)
+    else:
+        gw, gh = grid
+        n, pp, shape = gw * gh, None, (gh, gw, 2)
+    out = np.zeros(shape, dtype=np.float32)
+    sp = None
+    if shifts is not None:
+        shifts = np.ascontiguousarray(shifts, dtype=np.float32).reshape(-1, 5)
+        sp = shifts.ctypes.data
+    meshp, meshn = None, 0
+    if mesh is not None and len(mesh):
+        mesh = np.ascontiguousarray(mesh, dtype=np.float64)
+        meshp, meshn = mesh.ctypes.data, mesh.size
+    lib().gfw_oracle_undistort_points(C.byref(params), model, digital, pp, n, gw, rot.ctypes.data, rot.shape[0], sp, index_mode,
+                                      meshp, meshn, out.ctypes.data)
+    return out
+
+
+def undistort_point(model, params, x, y):
+    """One lens-model inverse (distortion_models/*.rs `undistort_point`): (ok, x, y)."""
+    out = np.zeros(2, dtype=np.float32)
+    ok = lib().gfw_oracle_undistort_point(model, C.byref(params), float(x), float(y), out.ctypes.data)
+    return bool(ok), float(out[0]), float(out[1])

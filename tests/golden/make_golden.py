@@ -36,6 +36,36 @@ CASES = {
 }
 
 
+# coordinate maps (STMap export): CRC32 of the oracle's "undist" (stmap.rs:87-109) and "dist"
+# (stmap.rs:123-127 -> undistort_points) f32 maps
+MAP_CASES = {
+    "stmap_fisheye_384x216_rs": dict(fmt="YUV422P16LE", w=384, h=216, seed=5, fov=1.4),
+    "stmap_fisheye_256x160_hrs": dict(fmt="NV12", w=256, h=160, seed=4, fov=1.2, hrs=True),
+}
+
+
+def points_params(fr):
+    """The KernelParams `undistort_points` builds (cpu_undistort.rs:669-681)."""
+    src = fr.planes[0]["params"]
+    kp = abi.KernelParams()
+    kp.width, kp.height, kp.output_width, kp.output_height = fr.width, fr.height, fr.out_size[0], fr.out_size[1]
+    for i in range(2):
+        kp.f[i], kp.c[i] = src.f[i], src.c[i]
+    for i in range(12):
+        kp.k[i] = src.k[i]
+    kp.light_refraction_coefficient = src.light_refraction_coefficient
+    kp.lens_correction_amount = 1.0
+    return kp
+
+
+def map_inputs(case):
+    fr = build(case)
+    kp = fr.planes[0]["params"].copy()
+    kp.flags = abi.FLAG_HORIZONTAL_RS if case.get("hrs") else 0
+    mode = abi.POINT_INDEX_PER_COLUMN if case.get("hrs") else abi.POINT_INDEX_PER_ROW
+    return fr, kp, points_params(fr), mode
+
+
 def build(case):
     q = S.quat_from_euler_deg(*case["quat"]) if "quat" in case else None
     return S.SyntheticFrame(case["fmt"], case["w"], case["h"], seed=case["seed"], fov=case.get("fov", 1.0),
@@ -58,6 +88,15 @@ def main():
         entry["mid_row_first_bytes"] = row.tolist()
         out[name] = entry
         print(name, entry["planes"])
+    out["maps"] = {}
+    for name, case in MAP_CASES.items():
+        fr, kp, pp, mode = map_inputs(case)
+        undist = O.stmap_undistort(kp, fr.model, 0, fr.matrices, case["w"], case["h"])
+        dist = O.undistort_points(pp, fr.model, 0, fr.rotations, grid=(case["w"], case["h"]), index_mode=mode)
+        out["maps"][name] = {"undist": zlib.crc32(undist.tobytes()), "dist": zlib.crc32(dist.tobytes()),
+                             "rotations": zlib.crc32(fr.rotations.tobytes()),
+                             "dist_centre": [float(v) for v in dist[case["h"] // 2, case["w"] // 2]]}
+        print(name, out["maps"][name])
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
 

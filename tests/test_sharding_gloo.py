@@ -25,6 +25,14 @@ WORKER = textwrap.dedent("""
     shard.barrier(dist)
     t = shard.reduce_max(dist, 1.0 + rank)
     c = shard.reduce_checksum(dist, crc)
+    # clip-invariant block: rank 0's KernelParams template reaches every rank byte-for-byte
+    tmpl = S.SyntheticFrame("YUV422P16LE", 64, 32, seed=100 + rank).planes[0]["params"]      # rank-dependent on purpose
+    got = shard.broadcast_bytes(dist, bytes(tmpl))
+    ref0 = bytes(S.SyntheticFrame("YUV422P16LE", 64, 32, seed=100).planes[0]["params"])
+    assert got == ref0 and len(got) == 368, (rank, len(got))
+    g = shard.gather_checksums(dist, [crc, rank + 7])
+    assert len(g) == world and g[rank] == [crc, rank + 7] and g[1 - rank][1] == (1 - rank) + 7
+    assert sum(x[0] for x in g) == c
     print("RESULT", rank, mine, t, c, flush=True)
     shard.finish(dist)
 """) % (ROOT, ROOT)
