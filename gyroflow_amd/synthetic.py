@@ -17,7 +17,7 @@ import math
 
 import numpy as np
 
-from . import abi
+from . import abi, formats
 
 MASK64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
@@ -264,22 +264,11 @@ def plane_kernel_params(base, pixel_type, size, out_size, in_desc, out_desc, int
     return p
 
 
-# Appendix C of SURVEY.md (rendering/mod.rs:565-649): format -> planes
-# (pixel type, (w divisor, h divisor), yuv index for the background colour, max_val)
-FRAME_FORMATS = {
-    "NV12":        [("Luma8", (1, 1), [0], 255.0), ("UV8", (2, 2), [1, 2], 255.0)],
-    "P010":        [("Luma16", (1, 1), [0], 65535.0), ("UV16", (2, 2), [1, 2], 65535.0)],
-    "P210":        [("Luma16", (1, 1), [0], 65535.0), ("UV16", (2, 1), [1, 2], 65535.0)],
-    "YUV420P":     [("Luma8", (1, 1), [0], 255.0), ("Luma8", (2, 2), [1], 255.0), ("Luma8", (2, 2), [2], 255.0)],
-    "YUV420P10LE": [("Luma16", (1, 1), [0], 1023.0), ("Luma16", (2, 2), [1], 1023.0), ("Luma16", (2, 2), [2], 1023.0)],
-    "YUV422P10LE": [("Luma16", (1, 1), [0], 1023.0), ("Luma16", (2, 1), [1], 1023.0), ("Luma16", (2, 1), [2], 1023.0)],
-    "YUV422P16LE": [("Luma16", (1, 1), [0], 65535.0), ("Luma16", (2, 1), [1], 65535.0), ("Luma16", (2, 1), [2], 65535.0)],
-    "YUV444P16LE": [("Luma16", (1, 1), [0], 65535.0), ("Luma16", (1, 1), [1], 65535.0), ("Luma16", (1, 1), [2], 65535.0)],
-    "GBRAPF32LE":  [("R32f", (1, 1), [2], 255.0), ("R32f", (1, 1), [0], 255.0), ("R32f", (1, 1), [1], 255.0), ("R32f", (1, 1), [3], 255.0)],
-    "RGBA":        [("RGBA8", (1, 1), [], 255.0)],
-    "RGBA64":      [("RGBA16", (1, 1), [], 65535.0)],
-    "RGBAF32":     [("RGBAf", (1, 1), [], None)],
-}
+# format -> planes: gyroflow_amd/formats.py mirrors rendering/mod.rs:565-649; short aliases kept for the tests
+_ALIASES = {"P010": "P010LE", "P210": "P210LE", "RGBA64": "RGBA64BE"}
+FRAME_FORMATS = {name: [(pl.pixel_type, pl.sub, pl.yuv, pl.max_val) for pl in planes] for name, planes in formats.PLANE_TABLE.items()}
+for _a, _t in _ALIASES.items():
+    FRAME_FORMATS[_a] = FRAME_FORMATS[_t]
 
 
 class SyntheticFrame:
@@ -287,7 +276,8 @@ class SyntheticFrame:
 
     def __init__(self, fmt, width, height, seed=0x9F10, fov=1.0, readout_ms=16.0, timestamp_ms=1000.0,
                  interpolation=2, constant_quat=None, out_size=None, lens=None, horizontal_rs=False,
-                 stride_align=256, background_rgba=(0.0, 0.0, 0.0, 0.0), base_overrides=None, flags=0):
+                 stride_align=256, background_rgba=(0.0, 0.0, 0.0, 0.0), base_overrides=None, flags=0,
+                 limited_range=False):
         self.fmt, self.width, self.height = fmt, width, height
         self.out_size = out_size or (width, height)
         self.lens = lens or gopro_style_lens(width, height)
@@ -302,16 +292,17 @@ class SyntheticFrame:
             flags |= abi.FLAG_HAS_DIGITAL_LENS
         base = base_kernel_params(self.lens, fov, self.matrices.shape[0], **(base_overrides or {}))
         self.planes = []
-        for idx, (ptype, (dw, dh), _yuvi, max_val) in enumerate(FRAME_FORMATS[fmt]):
-            pw, ph = width // dw, height // dh
-            ow, oh = self.out_size[0] // dw, self.out_size[1] // dh
+        for idx, (ptype, (dw, dh), yuvi, max_val) in enumerate(FRAME_FORMATS[fmt]):
+            pw, ph = formats.plane_size(width, height, (dw, dh))
+            ow, oh = formats.plane_size(self.out_size[0], self.out_size[1], (dw, dh))
             src, stride = make_plane_buffer(pw, ph, ptype, seed + idx * 101, max_val, stride_align)
             _, dt, count, _ = abi.PIXEL_TYPES[ptype]
             ostride = align(ow * np.dtype(dt).itemsize * count, stride_align)
             dst = np.full(ostride * oh, 0x5A, dtype=np.uint8)
             kp = plane_kernel_params(base, ptype, (width, height), self.out_size,
                                      (pw, ph, stride, None, None), (ow, oh, ostride, None, None),
-                                     interpolation=interpolation, flags=flags, background=background_rgba,
+                                     interpolation=interpolation, flags=flags,
+                                     background=formats.from_rgb_color(ptype, background_rgba, yuvi, limited_range),
                                      max_val=max_val, plane_index=idx)
             self.planes.append({"pixel_type": ptype, "size": (pw, ph, stride), "out_size": (ow, oh, ostride),
                                 "src": src, "dst": dst, "params": kp})
