@@ -198,8 +198,14 @@ def main():
     if launches:
         per_launch_ms = kernel_ms / launches
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed PMC passes of this exact workload (rocprofv3 cannot run inside bench.py)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_c2_traffic.json")
+        if (W, H, args.fmt, args.interp, args.crop, args.variant) == (WIDTH, HEIGHT, FMT, 2, False, 0) and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic = int((tj["fetch_size_kib"] * tj["fetch_correction"] + tj["write_size_kib"]) * 1024)
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "kernel": warp.last_backend(), "kernel_ms_per_launch": round(per_launch_ms, 5),
                            "algorithmic_bytes_per_launch": alg_bytes, "launches": launches}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -24,10 +24,11 @@
 //     ~5 us start-up of a wave (kernel-argument loads) is paid once, not once per tile;
 //   * XCD-banded tile order (workgroup b runs on XCD b % 8): an XCD's L2 sees a contiguous band of source lines.
 //
-// Eligibility (decided on the host, gfw_api.hip): bilinear, background_mode 0, no input rotation,
-// lens_correction_amount >= 1, no refraction / mesh / digital lens / IBIS terms / colour-range fix,
-// translation3d == 0, stretches in {<=0.001, 1}, full-plane rects, Luma8/Luma16 (+UV8/UV16) planes, chroma planes
-// of identical geometry.
+// Eligibility (decided on the host, gfw_api.hip build_yuv_args): bilinear / bicubic / Lanczos4 taps (this file is
+// compiled once per tap count and sample type), background_mode 0-2, no input rotation, lens_correction_amount >= 1,
+// no refraction / mesh / digital lens / IBIS terms / colour-range fix / fill flag, translation3d == 0, stretches in
+// {<=0.001, 1}, full-plane rects; Luma8/Luma16 (+UV8/UV16) planes with chroma planes of identical geometry, one
+// packed RGB(A)8/16 / BGRA8 / AYUV16 / RGBAf plane, or planar R32f planes.
 #include <hip/hip_runtime.h>
 #include "gfw_warp.h"
 #include "gfw_fastmath.h"
