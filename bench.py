@@ -51,6 +51,11 @@ def main():
     ap.add_argument("--interp", type=int, default=2, help="2 bilinear (north-star), 4 bicubic, 8 Lanczos4 (the reference's render default, cli.rs:618)")
     ap.add_argument("--crop", action="store_true", help="C4: adaptive-zoom crop (fov 0.82 + non-zero translation2d)")
     ap.add_argument("--resident", type=int, default=N_RESIDENT, help="distinct source frames / matrix tables kept in HBM and cycled")
+    ap.add_argument("--c1", action="store_true", help="C1: 1920x1080 NV12 (u8), one constant quaternion, matrix_count = 1 "
+                                                      "(BASELINE.json configs[0], the reference's own CPU-runnable case)")
+    ap.add_argument("--host-buffers", action="store_true",
+                    help="PCIe-inclusive run: source and destination planes live in host memory (BufferSource::Cpu), every "
+                         "call stages H2D, warps, copies D2H and synchronises — never the headline value")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)
@@ -74,24 +79,33 @@ def main():
         raise SystemExit("gfw_set_device failed: %s" % lib.gfw_last_error().decode())
 
     # ---- synthetic clip, resident in HBM ------------------------------------------------------------
+    if args.c1:
+        args.width, args.height, args.fmt = 1920, 1080, "NV12"
     W, H = args.width, args.height
+    readout = 0.0 if args.c1 else 16.0
+    cquat = S.quat_from_euler_deg(5.0, 2.0, 3.0) if args.c1 else None
     fov = 0.82 if args.crop else args.fov
     ov = {"translation2d": (13.25, -7.5)} if args.crop else None
     frames = [S.SyntheticFrame(args.fmt, W, H, seed=0x9F10 + rank * 1000 + i, timestamp_ms=1000.0 + 33.3 * (rank * 1000 + i),
-                               fov=fov, base_overrides=ov, interpolation=args.interp)
+                               fov=fov, base_overrides=ov, interpolation=args.interp, readout_ms=readout, constant_quat=cquat)
               for i in range(N_DISTINCT)]
     nplanes = len(frames[0].planes)
-    NR = max(N_DISTINCT, args.resident)
+    NR = N_DISTINCT if args.host_buffers else max(N_DISTINCT, args.resident)
     base_src = [[torch.from_numpy(pl["src"]).to(dev) for pl in fr.planes] for fr in frames]
     # resident set j < 4 is host frame j itself; the others are byte-rotated copies (distinct content, same statistics)
     d_src = [[base_src[j % N_DISTINCT][p] if j < N_DISTINCT else torch.roll(base_src[j % N_DISTINCT][p], 4098 * j)
               for p in range(nplanes)] for j in range(NR)]
-    d_dst = [[torch.empty(pl["dst"].nbytes, dtype=torch.uint8, device=dev) for pl in frames[0].planes] for _ in range(N_DST)]
+    # destinations start from the same fill pattern as the host copies: stride padding is never written by the warp
+    d_dst = [[torch.from_numpy(pl["dst"]).to(dev) for pl in frames[0].planes] for _ in range(N_DST)]
     types = [pl["pixel_type"] for pl in frames[0].planes]
     bufsets = []                                      # bufsets[j * N_DST + d]: source set j -> destination set d
+    h_dst = [[pl["dst"].copy() for pl in frames[0].planes] for _ in range(N_DST)]
     for j in range(NR):
         fr = frames[j % N_DISTINCT]
         for d in range(N_DST):
+            if args.host_buffers:
+                bufsets.append([warp.host_buffers(pl["src"], pl["size"], h_dst[d][p], pl["out_size"]) for p, pl in enumerate(fr.planes)])
+                continue
             bufsets.append([warp.device_buffers(d_src[j][p].data_ptr(), d_src[j][p].numel(), pl["size"],
                                                 d_dst[d][p].data_ptr(), d_dst[d][p].numel(), pl["out_size"])
                             for p, pl in enumerate(fr.planes)])
@@ -103,7 +117,7 @@ def main():
     be = warp.Backend(params[0][0], types[0], frames[0].model, frames[0].digital, bufsets[0][0])
     stream = torch.cuda.current_stream(dev)
     be.set_stream(stream.cuda_stream)
-    be.set_option(abi.OPT_SYNCHRONOUS, 0)
+    be.set_option(abi.OPT_SYNCHRONOUS, 1 if args.host_buffers else 0)
     if args.variant:
         be.set_option(abi.OPT_KERNEL_VARIANT, args.variant)
     if args.rows:
@@ -117,8 +131,8 @@ def main():
         """One per-row matrix table per resident frame: its own timestamp on the synthetic camera track."""
         sets = [fr.matrices for fr in frames]
         for j in range(N_DISTINCT, NR):
-            sets.append(S.row_matrices(frames[0].lens, fov, (W, H), (W, H), 1000.0 + 33.3 * (rank * 1000 + j), 16.0,
-                                       0x9F10 + rank * 1000 + j))
+            sets.append(S.row_matrices(frames[0].lens, fov, (W, H), (W, H), 1000.0 + 33.3 * (rank * 1000 + j), readout,
+                                       0x9F10 + rank * 1000 + j, constant_quat=cquat))
         return sets
 
     if args.build_matrices:
@@ -171,7 +185,7 @@ def main():
     crc = 0
     last = ((args.steps - 1) % NR) % N_DST
     for p in range(nplanes):
-        crc = zlib.crc32(d_dst[last][p].cpu().numpy().tobytes(), crc)
+        crc = zlib.crc32(h_dst[last][p].tobytes() if args.host_buffers else d_dst[last][p].cpu().numpy().tobytes(), crc)
     elapsed = shard.reduce_max(dist, elapsed, dev)
     rank_crcs = [g[0] for g in shard.gather_checksums(dist, [crc], dev)]
     crc = shard.reduce_checksum(dist, crc, dev)
@@ -180,15 +194,16 @@ def main():
     alg_bytes = frames[0].algorithmic_bytes()
     value = luma_px * args.steps * world / elapsed / 1e6
     out = {
-        "metric": "Mpix/s (4K u16 YUV, rolling-shutter warp)",
+        "metric": "Mpix/s (4K u16 YUV, rolling-shutter warp)" if not args.c1 else "Mpix/s (1080p u8 NV12 warp)",
         "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 coordinates, %s pixels" % np.dtype(abi.PIXEL_TYPES[types[0]][1]).name, "data": "synthetic",
         "config": {"workload": "%s: %dx%d %s, opencv_fisheye GoPro-style lens, rolling shutter matrix_count=%d, %s, "
                                "%d frames + per-row matrix tables resident in HBM%s"
-                               % ("C2" if (W, H, args.fmt) == (3840, 2160, FMT) else "C3" if (W, H, args.fmt) == (7680, 4320, FMT) else "C4" if args.crop else "custom",
+                               % ("C1" if args.c1 else "C2" if (W, H, args.fmt) == (3840, 2160, FMT) else "C3" if (W, H, args.fmt) == (7680, 4320, FMT) else "C4" if args.crop else "custom",
                                   W, H, args.fmt, frames[0].matrices.shape[0],
                                   {2: "bilinear", 4: "bicubic", 8: "Lanczos4"}.get(args.interp, str(args.interp)), NR,
+                                  " — HOST buffers: H2D + warp + D2H + sync per frame (PCIe-inclusive)" if args.host_buffers else
                                   " (matrices re-uploaded per frame)" if args.upload_matrices else
                                   " (per-row matrices built on the device every frame from quaternion tracks)" if args.build_matrices else ""),
                    "frames_per_rank": args.steps, "parallelism": "frame-sharded x%d" % world,
@@ -201,7 +216,7 @@ def main():
         # HBM bytes per launch from the committed PMC passes of this exact workload (rocprofv3 cannot run inside bench.py)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_c2_traffic.json")
-        if (W, H, args.fmt, args.interp, args.crop, args.variant) == (WIDTH, HEIGHT, FMT, 2, False, 0) and os.path.exists(tpath):
+        if (W, H, args.fmt, args.interp, args.crop, args.variant, args.host_buffers) == (WIDTH, HEIGHT, FMT, 2, False, 0, False) and os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic = int((tj["fetch_size_kib"] * tj["fetch_correction"] + tj["write_size_kib"]) * 1024)
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -222,14 +237,14 @@ def main():
                 break
         cpu_s = time.perf_counter() - c0
         out["cpu_baseline"] = {"value": round(luma_px * n_cpu / cpu_s / 1e6, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
-                               "sample": "%d frames of the same C2 workload through oracle/gfw_oracle.c (OpenMP rows, %d threads)" % (n_cpu, cores)}
+                               "sample": "%d frames of the same workload through oracle/gfw_oracle.c (OpenMP rows, %d threads)" % (n_cpu, cores)}
         # parity spot-check on the frame the oracle just produced
         i = (n_cpu - 1) % N_DISTINCT
         be.set_option(abi.OPT_SYNCHRONOUS, 1)
         be.set_option(abi.OPT_MATRICES_ON_DEVICE, 0)
         be.get_profile(reset=True)
         be.undistort_frame(bufsets[i * N_DST], params[i], types, frames[i].matrices)
-        ok = all(np.array_equal(ref[p], d_dst[0][p].cpu().numpy()) for p in range(nplanes))
+        ok = all(np.array_equal(ref[p], h_dst[0][p] if args.host_buffers else d_dst[0][p].cpu().numpy()) for p in range(nplanes))
         out["config"]["parity_vs_oracle"] = "bit-exact" if ok else "MISMATCH"
     be.close()
     if rank == 0:

@@ -13,6 +13,7 @@
 #include "../../include/gfwarp.h"
 #include "gfw_math.h"
 
+#define GFW_EWA_MAX_TAPS (1 << 22)   // EWA bounding-box area (source pixels per output pixel) beyond which bg is written
 #define GFW_MAT_STRIDE 16   // floats per matrix row on device: m0..m13, cos(-m11), sin(-m11)
 
 struct GfwPlane {
@@ -739,7 +740,11 @@ __device__ __forceinline__ void gfw_sample(float uvx, float uvy, const float *ja
         const float B = 2.0f * a0 * cc * sn + b0v * cc * cc - b0v * sn * sn - 2.0f * c0 * cc * sn;
         const float Cc = a0 * sn * sn + b0v * cc * sn + c0 * cc * cc;
         float sum_div = 0.0f;
-        for (int in_y = b2; in_y <= b3; ++in_y) {
+        // Guard, not in the reference: its bounding box is unbounded (`as i32` saturates at +-2^31), so a degenerate
+        // jacobian makes the CPU loop run for hours and would hang a GPU queue.  Footprints above GFW_EWA_MAX_TAPS source
+        // pixels per output pixel are written as background instead.
+        const bool too_large = ((int64_t)b1 - b0 + 1) * ((int64_t)b3 - b2 + 1) > (int64_t)GFW_EWA_MAX_TAPS;
+        for (int in_y = b2; in_y <= (too_large ? b2 - 1 : b3); ++in_y) {
             const float in_fy = (float)in_y - uvy;
             const float in_fy2 = in_fy * B;
             const float in_fy3 = in_fy * in_fy * Cc;
@@ -762,7 +767,7 @@ __device__ __forceinline__ void gfw_sample(float uvx, float uvy, const float *ja
             }
         }
         #pragma unroll
-        for (int c2 = 0; c2 < N; ++c2) sum[c2] = sum[c2] / sum_div;
+        for (int c2 = 0; c2 < N; ++c2) sum[c2] = too_large ? bg[c2] : sum[c2] / sum_div;
     } else {
         constexpr int SHIFT = (I >> 2) + 1;
         constexpr float OFFSET = (I == 2) ? 0.0f : (I == 4 ? 1.0f : 3.0f);
