@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--host-buffers", action="store_true",
                     help="PCIe-inclusive run: source and destination planes live in host memory (BufferSource::Cpu), every "
                          "call stages H2D, warps, copies D2H and synchronises — never the headline value")
+    ap.add_argument("--profile-every", type=int, default=8,
+                    help="bracket every N-th launch of the timed region with hipEvents for the roofline's kernel duration "
+                         "(0 = none); the event pairs themselves cost GPU time between back-to-back kernels")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)
@@ -166,13 +169,24 @@ def main():
     for k in range(args.warmup):
         step(k)
     torch.cuda.synchronize(dev)
-    be.set_option(abi.OPT_PROFILE, 1)
+    pe = args.profile_every
+    be.set_option(abi.OPT_PROFILE, 1 if pe == 1 else 0)
     be.get_profile(reset=True)
     shard.barrier(dist)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
+    if pe > 1:
+        set_opt, ctxp2 = be.lib.gfw_set_option, be.ctx
+        for k in range(args.steps):
+            if k % pe == 0:
+                set_opt(ctxp2, abi.OPT_PROFILE, 1)
+                step(k)
+                set_opt(ctxp2, abi.OPT_PROFILE, 0)
+            else:
+                step(k)
+    else:
+        for k in range(args.steps):
+            step(k)
     t_enq = time.perf_counter() - t0                 # host time to enqueue the K steps (GPU runs behind it)
     torch.cuda.synchronize(dev)
     shard.barrier(dist)
