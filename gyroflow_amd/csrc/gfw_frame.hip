@@ -34,6 +34,17 @@
 #include "gfw_fastmath.h"
 #include "gfw_frame.h"
 
+// measured switches (1 = on): branch-free rounding, exact-FMA row sums, hardware min for the limit clamp
+#ifndef GFW_EXP_ROUND
+#define GFW_EXP_ROUND 1
+#endif
+#ifndef GFW_EXP_FMA
+#define GFW_EXP_FMA 1
+#endif
+#ifndef GFW_EXP_MIN
+#define GFW_EXP_MIN 1
+#endif
+
 namespace {
 
 // 32-phase bicubic / Lanczos4 tap table (one constant copy per translation unit)
@@ -150,10 +161,22 @@ __device__ __forceinline__ GfwPt rd_row(float px, float py, int idx, const Lens 
 }
 
 // f32::round (half away from zero) then `as i32`: rndne is exact except on ties, which take the side branch.
+// `x.round() as i32` (half away from zero, then truncating saturating cast) without the tie branch:
+// trunc(x + copysign(pred(0.5), x)) — equal to the cast of roundf(x) for every one of the 2^32 floats
+// (tests/test_math_host.py checks this exhaustively); the cast itself truncates.
 __device__ __forceinline__ int round_i32(float x) {
+#if GFW_EXP_ROUND
+    return gfw_f2i(x + copysignf(0x1.fffffep-2f, x));
+#else
     float r = rintf(x);
     if (__builtin_expect(fabsf(x - r) == 0.5f, 0)) r = truncf(x) + copysignf(1.0f, x);
     return gfw_f2i(r);
+#endif
+}
+// f32::min(v, limit) with the hardware's IEEE-mode v_min_f32 (non-NaN operand wins, as Rust's does): spares the
+// canonicalising v_max the compiler puts in front of fminf for a uniform operand.
+__device__ __forceinline__ float min_limit(float v, float limit) {
+    float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(v), "s"(limit)); return r;
 }
 
 // ---- LUT taps (cpu_undistort.rs:371-418): I = 2 bilinear, 4 bicubic, 8 Lanczos4 --------------------------------
@@ -345,9 +368,20 @@ __device__ __forceinline__ void taps_inside2(const uint8_t *src, int off0, int s
             float sum = 0.0f; sum = sum + xs0 * b.cy0; sum = sum + xs1 * b.cy1;
             out[c] = fminf(sum, limit);
         } else {
+            // tap (<= 16 bits) x weight (k/32) and the sum of two such products are exact in f32 (<= 22 bits), so the
+            // fused form rounds nowhere the reference's separate multiply and add would
+#if GFW_EXP_FMA
+            const float xs0 = __builtin_fmaf((float)row0[N + c], b.cx1, (float)row0[c] * b.cx0);
+            const float xs1 = __builtin_fmaf((float)row1[N + c], b.cx1, (float)row1[c] * b.cx0);
+#else
             const float xs0 = (float)row0[c] * b.cx0 + (float)row0[N + c] * b.cx1;
             const float xs1 = (float)row1[c] * b.cx0 + (float)row1[N + c] * b.cx1;
+#endif
+#if GFW_EXP_MIN
+            out[c] = min_limit(xs0 * b.cy0 + xs1 * b.cy1, limit);
+#else
             out[c] = fminf(xs0 * b.cy0 + xs1 * b.cy1, limit);
+#endif
         }
     }
 }

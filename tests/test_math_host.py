@@ -38,3 +38,34 @@ def test_atanf_tanf_bit_identical_to_libm_on_all_inputs(tmp_path):
     subprocess.check_call(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fno-fast-math", str(c), "-o", str(exe), "-lm"])
     out = subprocess.check_output([str(exe)], timeout=900).decode().split()
     assert out == ["0", "0"], "mismatches vs libm: atanf %s, tanf %s" % tuple(out)
+
+
+ROUND_SRC = r"""
+#include <math.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <string.h>
+/* Rust `v as i32`: truncate, saturate, NaN -> 0 (what v_cvt_i32_f32 does on the device) */
+static inline int32_t as_i32(float v) { if (v != v) return 0; if (v >= 2147483648.0f) return INT32_MAX; if (v <= -2147483648.0f) return INT32_MIN; return (int32_t)v; }
+int main(void) {
+    long bad = 0;
+    #pragma omp parallel for reduction(+:bad) schedule(static)
+    for (long i = 0; i < (1L << 32); ++i) {
+        const uint32_t u = (uint32_t)i; float x; memcpy(&x, &u, 4);
+        const int32_t want = as_i32(roundf(x));                               /* f32::round() as i32 */
+        const int32_t got = as_i32(x + copysignf(0x1.fffffep-2f, x));         /* gfw_frame.hip round_i32 */
+        if (want != got) bad++;
+    }
+    printf("%ld\n", bad);
+    return 0;
+}
+"""
+
+
+def test_branch_free_round_half_away_matches_roundf_on_all_inputs(tmp_path):
+    """The fused kernel's `round_i32` (x + copysign(pred(0.5), x), truncated by the cast) vs `roundf` + cast, all 2^32 floats."""
+    c = tmp_path / "r.c"
+    c.write_text(ROUND_SRC)
+    exe = tmp_path / "r"
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fno-fast-math", str(c), "-o", str(exe), "-lm"])
+    assert subprocess.check_output([str(exe)], timeout=900).decode().split() == ["0"]
