@@ -24,13 +24,15 @@ __device__ __forceinline__ GfwRcp gfw_rcp_prepare(float b) {
     return GfwRcp{b, __builtin_fmaf(e, r0, r0)};
 }
 // RN(a / b) for |b| in [2^-60, 2^60], |a| <= 2^60 (a == 0 allowed; the sign of a zero result may differ).
-// Same FMA chain as the generic expansion (two remainder corrections), minus v_div_scale/v_div_fixup.
+// Refined reciprocal, q0 = a*r, ONE exact-remainder correction (Markstein's scheme).  That this is the correctly
+// rounded quotient with MI355X's v_rcp_f32 is machine-checked, not assumed: tools/prove_div.py compares it with the
+// generic expansion for all 2^23 x 2^23 = 7.04e13 significand pairs on the device (0 mismatches,
+// profiles/r01_div_one_correction_proof.txt; with the raw, unrefined v_rcp the same scheme does fail), and every
+// operation scales exactly with the operands' exponents inside the stated range.
 __device__ __forceinline__ float gfw_div_prepared(float a, const GfwRcp &d) {
     const float q0 = a * d.r;
     const float r0 = __builtin_fmaf(-d.b, q0, a);
-    const float q1 = __builtin_fmaf(r0, d.r, q0);
-    const float r1 = __builtin_fmaf(-d.b, q1, a);
-    return __builtin_fmaf(r1, d.r, q1);
+    return __builtin_fmaf(r0, d.r, q0);
 }
 __device__ __forceinline__ float gfw_div_lean(float a, float b) { return gfw_div_prepared(a, gfw_rcp_prepare(b)); }
 

@@ -209,6 +209,24 @@ __global__ void gfw_debug_selftest_kernel(int test, unsigned long long n, unsign
             const float x = gfw_u2f((uint32_t)i & 0x7fffffffu);                       // every non-negative float (incl. inf/NaN)
             const float p = gfw_atanf_pos(x), q = gfw_atanf(x);
             if (gfw_f2u(p) != gfw_f2u(q) && !(p != p && q != q)) local++;
+        } else if (test >= 3 && test <= 5) {
+            // Exhaustive check of a divide sequence over significand pairs: lane i owns the denominator significand
+            // (seed & 0x7fffff) + i and walks numerator significands 0, step, 2*step, ... (step = 1 << (seed >> 32)).
+            // Operands in [1, 2) cover both quotient binades; every operation scales exactly with the exponents inside
+            // the kernels' checked range, so the significands decide.
+            //   3: refined reciprocal + ONE remainder correction (gfw_div_prepared)   4: raw v_rcp + two   5: raw v_rcp + one
+            const uint32_t mb = ((uint32_t)seed + (uint32_t)i) & 0x7fffffu;
+            const uint32_t step = 1u << (uint32_t)(seed >> 32);
+            const float b = gfw_u2f(0x3f800000u | mb);
+            const float r0 = gfw_hw_rcp(b);
+            const float r = (test == 3) ? __builtin_fmaf(__builtin_fmaf(-b, r0, 1.0f), r0, r0) : r0;
+            for (uint32_t ma = 0; ma < (1u << 23); ma += step) {
+                const float a = gfw_u2f(0x3f800000u | ma);
+                float q = a * r;
+                q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+                if (test == 4) q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+                if (gfw_f2u(q) != gfw_f2u(a / b)) local++;
+            }
         }
     }
     if (local) atomicAdd(bad, local);

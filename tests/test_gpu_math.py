@@ -92,3 +92,6 @@ def test_lean_primitives_equal_generic_on_a_billion_operands():
     assert lib.gfw_debug_selftest(0, 1 << 30, 12345) == 0, "lean divide"
     assert lib.gfw_debug_selftest(1, 1 << 30, 67890) == 0, "lean sqrt"
     assert lib.gfw_debug_selftest(2, 0, 0) == 0, "atanf_pos vs atanf over all non-negative floats"
+    # the one-correction divide over significand pairs: 16384 denominators x every 64th numerator here (1.5e9 quotients);
+    # tools/prove_div.py runs all 7.04e13 pairs (profiles/r01_div_one_correction_proof.txt)
+    assert lib.gfw_debug_selftest(3, 1 << 14, (6 << 32) | 0x2a5f13) == 0, "refined reciprocal + one correction"
