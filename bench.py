@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--build-matrices", action="store_true",
                     help="build every frame's per-row matrices on the device from quaternion tracks (gfw_build_matrices, "
                          "the 'next' row f-1) inside the timed region instead of using pre-packed resident tables")
+    ap.add_argument("--build-batch", type=int, default=16, help="with --build-matrices: frames per gfw_build_matrices_batch call (1 = one "
+                                                                 "gfw_build_matrices per frame on the auxiliary stream)")
     ap.add_argument("--upload-matrices", action="store_true",
                     help="upload the per-row matrices from host memory every frame (the reference's OpenCL backend does, "
                          "opencl.rs:406) instead of keeping the pre-packed tables of the clip resident in HBM")
@@ -152,6 +154,16 @@ def main():
         for i, v in enumerate(np.asarray(nk, dtype=np.float64).reshape(9)):
             timing.new_k[i] = v
         build_fn, ctxp, tref = be.lib.gfw_build_matrices, be.ctx, C.byref(timing)
+        tbl = C.c_void_p(0)
+        tblref = C.byref(tbl)
+        BATCH = args.build_batch
+        timings = (abi.FrameTiming * max(BATCH, 1))()
+        for t in timings:
+            t.frame_readout_time_ms, t.rows, t.readout_dim = 16.0, H, H
+            for i, v in enumerate(np.asarray(nk, dtype=np.float64).reshape(9)):
+                t.new_k[i] = v
+        tptrs = (C.c_void_p * max(BATCH, 1))()
+        batch_fn = be.lib.gfw_build_matrices_batch
     elif args.upload_matrices:
         mats = matrix_sets()
         calls = [warp.FrameCall(be, bufsets[j * N_DST + (j % N_DST)], params[j % N_DISTINCT], types, mats[j]) for j in range(NR)]
@@ -161,10 +173,20 @@ def main():
         calls = [warp.FrameCall(be, bufsets[j * N_DST + (j % N_DST)], params[j % N_DISTINCT], types, d_mat[j].data_ptr(), rows_n) for j in range(NR)]
 
     def step(k):
-        if args.build_matrices:
+        call = calls[k % NR]
+        if args.build_matrices and BATCH > 1:
+            # every BATCH frames: one launch builds the tables of the next BATCH frames, in order on the warp's stream
+            if k % BATCH == 0:
+                for i in range(BATCH):
+                    timings[i].timestamp_ms = 1000.0 + 33.3 * (k + i)
+                batch_fn(ctxp, timings, BATCH, tptrs)
+            call.mp = tptrs[k % BATCH]
+        elif args.build_matrices:
+            # the context builds this frame's table on its auxiliary stream (ring of tables) while the previous frame warps
             timing.timestamp_ms = 1000.0 + 33.3 * k
-            build_fn(ctxp, tref, None, None)
-        calls[k % NR]()
+            build_fn(ctxp, tref, None, tblref)
+            call.mp = tbl.value
+        call()
 
     for k in range(args.warmup):
         step(k)

@@ -135,6 +135,7 @@ def bind(lib):
     lib.gfw_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]; lib.gfw_get_profile.restype = i32
     lib.gfw_set_quaternion_tracks.argtypes = [vp, vp, vp, i32, vp, vp, i32]; lib.gfw_set_quaternion_tracks.restype = i32
     lib.gfw_build_matrices.argtypes = [vp, C.POINTER(FrameTiming), vp, C.POINTER(vp)]; lib.gfw_build_matrices.restype = i32
+    lib.gfw_build_matrices_batch.argtypes = [vp, C.POINTER(FrameTiming), i32, C.POINTER(vp)]; lib.gfw_build_matrices_batch.restype = i32
     lib.gfw_stmap_undistort.argtypes = [vp, C.POINTER(KernelParams), vp, i32, vp, sz, i32, i32, vp, i32]; lib.gfw_stmap_undistort.restype = i32
     lib.gfw_undistort_points.argtypes = [vp, C.POINTER(KernelParams), vp, sz, i32, vp, i32, vp, i32, vp, sz, vp, i32]; lib.gfw_undistort_points.restype = i32
     lib.gfw_pack_matrices.argtypes = [vp, i32, vp]; lib.gfw_pack_matrices.restype = i32
@@ -149,7 +150,7 @@ def bind(lib):
 
 EXPORTS = ["gfw_abi_version", "gfw_list_devices", "gfw_set_device", "gfw_get_info", "gfw_is_buffer_supported",
            "gfw_create", "gfw_destroy", "gfw_undistort_image", "gfw_undistort_frame", "gfw_set_option",
-           "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_last_backend", "gfw_get_profile", "gfw_last_error", "gfw_debug_math", "gfw_debug_selftest", "gfw_get_audit", "gfw_pack_matrices", "gfw_set_quaternion_tracks", "gfw_build_matrices", "gfw_stmap_undistort", "gfw_undistort_points",
+           "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_last_backend", "gfw_get_profile", "gfw_last_error", "gfw_debug_math", "gfw_debug_selftest", "gfw_get_audit", "gfw_pack_matrices", "gfw_set_quaternion_tracks", "gfw_build_matrices", "gfw_build_matrices_batch", "gfw_stmap_undistort", "gfw_undistort_points",
            "gfw_pixel_type_info"]
 
 

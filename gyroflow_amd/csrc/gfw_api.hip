@@ -87,7 +87,20 @@ struct gfw_ctx {
     DevBuf d_p1_table, d_audit;
     float p1_k[4] = {0, 0, 0, 0}; float p1_rho_max = 0.0f; double p1_etab = 0.0; double p1_smax = 1.0; bool p1_valid = false;
     DevBuf d_pts_in, d_pts_out, d_pts_rot, d_pts_shift, d_pts_mesh;   // gfw_undistort_points staging
-    DevBuf d_tracks, d_built_rows;                // quaternion tracks + context-owned table of built rows
+    DevBuf d_tracks;                              // quaternion tracks
+    // context-owned per-row tables built on the device (gfw_build_matrices): a small ring, built on copy_stream so that
+    // frame N+1's table is produced while frame N is being warped; events order builder and consumer both ways
+    struct BuiltSlot { DevBuf buf; hipEvent_t built = nullptr, consumed = nullptr; bool used = false; };   // buf = rows + 4 doubles of builder scratch
+    DevBuf d_prefix;                              // builder scratch for caller-owned tables
+    // frame descriptors of the builder: pinned host ring + device ring (one entry of up to kMaxBatch descriptors per build)
+    static constexpr int kTimingSlots = 8, kMaxBatch = 64;
+    gfw_frame_timing *h_timings = nullptr; DevBuf d_timings; int timing_next = 0;
+    hipEvent_t timing_copied[kTimingSlots] = {};
+    // gfw_build_matrices_batch: two context-owned batches of tables, alternated; built in order on the context stream
+    DevBuf d_batch[2]; int batch_next = 0;
+    static constexpr int kBuiltSlots = 4;
+    BuiltSlot bslots[kBuiltSlots];
+    int bslot_next = 0, bslot_cur = -1;
     GfwTracks tracks = {nullptr, nullptr, 0, nullptr, nullptr, 0};
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;   // recorded, not yet harvested
@@ -204,7 +217,12 @@ gfw_ctx *gfw_create(const gfw_kernel_params *params, int pixel_type, int distort
     c->max_matrix_rows = ((params->flags & GFW_FLAG_HORIZONTAL_RS) ? params->width : params->height);   // opencl.rs:287
     if (c->max_matrix_rows < 1) c->max_matrix_rows = 1;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    {   // auxiliary stream for uploads and the matrix builder: highest priority, so its small kernels are not starved by a
+        // warp that fills the machine
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        ok = ok && hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, prio_hi) == hipSuccess;
+    }
     ok = ok && c->d_mesh.ensure(GFW_MESH_MAX * sizeof(float)) == hipSuccess;
     const size_t mat_bytes = (size_t)c->max_matrix_rows * GFW_MAT_STRIDE * sizeof(float);
     for (int i = 0; i < gfw_ctx::kMatSlots && ok; ++i) {
@@ -227,7 +245,10 @@ void gfw_destroy(gfw_ctx *c) {
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &b : c->stage_src) b.release();
     for (auto &b : c->stage_dst) b.release();
-    c->d_mesh.release(); c->d_p1_table.release(); c->d_audit.release(); c->d_tracks.release(); c->d_built_rows.release();
+    c->d_mesh.release(); c->d_p1_table.release(); c->d_audit.release(); c->d_tracks.release(); c->d_prefix.release(); c->d_timings.release(); c->d_batch[0].release(); c->d_batch[1].release();
+    if (c->h_timings) (void)hipHostFree(c->h_timings);
+    for (auto &e : c->timing_copied) if (e) (void)hipEventDestroy(e);
+    for (auto &b : c->bslots) { b.buf.release(); if (b.built) (void)hipEventDestroy(b.built); if (b.consumed) (void)hipEventDestroy(b.consumed); }
     c->d_pts_in.release(); c->d_pts_out.release(); c->d_pts_rot.release(); c->d_pts_shift.release(); c->d_pts_mesh.release();
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (auto &s : c->mslots) {
@@ -318,7 +339,16 @@ static int upload_matrices(gfw_ctx *c, const float *matrices, int matrix_count, 
     if (matrix_count > c->max_matrix_rows) {
         // opencl.rs:336 logs "Buffer size mismatch matrices!" and skips the frame
         set_error("Buffer size mismatch matrices! %d vs %d", c->max_matrix_rows, matrix_count); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
-    if (c->matrices_on_device == 2) { c->mslot_cur = -1; *d_out = matrices; return GFW_OK; }   // caller-resident, already packed
+    if (c->matrices_on_device == 2) {                                                          // device-resident, already packed
+        c->mslot_cur = -1; c->bslot_cur = -1; *d_out = matrices;
+        for (int i = 0; i < gfw_ctx::kBuiltSlots; ++i)
+            if (c->bslots[i].buf.ptr == (const void *)matrices && c->bslots[i].built) {         // a table gfw_build_matrices produced
+                HIP_TRY(hipStreamWaitEvent(c->stream, c->bslots[i].built, 0), GFW_ERR_HIP);
+                c->bslot_cur = i;
+            }
+        return GFW_OK;
+    }
+    c->bslot_cur = -1;
     c->mslot_cur = c->mslot_next;
     c->mslot_next = (c->mslot_next + 1) % gfw_ctx::kMatSlots;
     gfw_ctx::MatSlot &s = c->mslots[c->mslot_cur];
@@ -343,6 +373,11 @@ static int upload_matrices(gfw_ctx *c, const float *matrices, int matrix_count, 
     return GFW_OK;
 }
 static int matrices_consumed(gfw_ctx *c) {          // call after the kernels that read the current slot are enqueued
+    if (c->bslot_cur >= 0) {
+        gfw_ctx::BuiltSlot &b = c->bslots[c->bslot_cur];
+        HIP_TRY(hipEventRecord(b.consumed, c->stream), GFW_ERR_HIP);
+        b.used = true;
+    }
     if (c->mslot_cur < 0) return GFW_OK;
     gfw_ctx::MatSlot &s = c->mslots[c->mslot_cur];
     HIP_TRY(hipEventRecord(s.done, c->stream), GFW_ERR_HIP);
@@ -790,17 +825,74 @@ int gfw_set_quaternion_tracks(gfw_ctx *c, const int64_t *org_ts, const double *o
     c->tracks = GfwTracks{(const int64_t *)base, (const double *)(base + b0), org_n, (const int64_t *)(base + b0 + b1), (const double *)(base + b0 + b1 + b2), sm_n};
     return GFW_OK;
 }
+// Copies `count` frame descriptors into the next slot of the pinned/device rings on `stream`; returns the device pointer.
+static int stage_timings(gfw_ctx *c, const gfw_frame_timing *t, int count, hipStream_t stream, const gfw_frame_timing **d_out) {
+    if (!c->h_timings) {
+        HIP_TRY(hipHostMalloc((void **)&c->h_timings, sizeof(gfw_frame_timing) * gfw_ctx::kTimingSlots * gfw_ctx::kMaxBatch), GFW_ERR_HIP);
+        HIP_TRY(c->d_timings.ensure(sizeof(gfw_frame_timing) * gfw_ctx::kTimingSlots * gfw_ctx::kMaxBatch), GFW_ERR_HIP);
+        for (auto &e : c->timing_copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming), GFW_ERR_HIP);
+    }
+    const int slot = c->timing_next;
+    c->timing_next = (slot + 1) % gfw_ctx::kTimingSlots;
+    HIP_TRY(hipEventSynchronize(c->timing_copied[slot]), GFW_ERR_HIP);         // the copy that last read this pinned slot is done
+    gfw_frame_timing *h = c->h_timings + (size_t)slot * gfw_ctx::kMaxBatch;
+    gfw_frame_timing *d = (gfw_frame_timing *)c->d_timings.ptr + (size_t)slot * gfw_ctx::kMaxBatch;
+    memcpy(h, t, sizeof(gfw_frame_timing) * count);
+    HIP_TRY(hipMemcpyAsync(d, h, sizeof(gfw_frame_timing) * count, hipMemcpyHostToDevice, stream), GFW_ERR_HIP);
+    HIP_TRY(hipEventRecord(c->timing_copied[slot], stream), GFW_ERR_HIP);
+    *d_out = d;
+    return GFW_OK;
+}
+static bool timing_ok(const gfw_frame_timing *t) { return t->rows >= 1 && t->readout_dim >= 1; }
+
 int gfw_build_matrices(gfw_ctx *c, const gfw_frame_timing *t, float *rows16_out, float **out_ptr) {
     if (!c || !t) { set_error("null context/timing"); return GFW_ERR_INVALID_ARGUMENT; }
-    if (t->rows < 1 || t->readout_dim < 1) { set_error("rows %d, readout_dim %d", t->rows, t->readout_dim); return GFW_ERR_INVALID_ARGUMENT; }
+    if (!timing_ok(t)) { set_error("rows %d, readout_dim %d", t->rows, t->readout_dim); return GFW_ERR_INVALID_ARGUMENT; }
     HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
-    float *out = rows16_out;
-    if (!out) {
-        HIP_TRY(c->d_built_rows.ensure((size_t)t->rows * GFW_MAT_STRIDE * sizeof(float)), GFW_ERR_HIP);
-        out = (float *)c->d_built_rows.ptr;
+    const size_t table_floats = (size_t)t->rows * GFW_MAT_STRIDE;
+    const gfw_frame_timing *d_t = nullptr;
+    if (rows16_out) {                                        // caller-owned table: built in order on the context's stream
+        HIP_TRY(c->d_prefix.ensure(4 * sizeof(double)), GFW_ERR_HIP);
+        { const int rc = stage_timings(c, t, 1, c->stream, &d_t); if (rc != GFW_OK) return rc; }
+        HIP_TRY(gfw_launch_build_matrices(c->tracks, d_t, 1, t->rows, (double *)c->d_prefix.ptr, rows16_out, table_floats, c->stream), GFW_ERR_HIP);
+        if (out_ptr) *out_ptr = rows16_out;
+        if (c->synchronous) HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
+        return GFW_OK;
     }
-    HIP_TRY(gfw_launch_build_matrices(c->tracks, *t, out, c->stream), GFW_ERR_HIP);
-    if (out_ptr) *out_ptr = out;
+    // context-owned table: next slot of the ring, built on the auxiliary stream (overlaps the warp in flight)
+    gfw_ctx::BuiltSlot &b = c->bslots[c->bslot_next];
+    c->bslot_next = (c->bslot_next + 1) % gfw_ctx::kBuiltSlots;
+    const size_t table_bytes = table_floats * sizeof(float);
+    HIP_TRY(b.buf.ensure(table_bytes + 4 * sizeof(double)), GFW_ERR_HIP);
+    if (!b.built) { HIP_TRY(hipEventCreateWithFlags(&b.built, hipEventDisableTiming), GFW_ERR_HIP); HIP_TRY(hipEventCreateWithFlags(&b.consumed, hipEventDisableTiming), GFW_ERR_HIP); }
+    if (b.used) HIP_TRY(hipStreamWaitEvent(c->copy_stream, b.consumed, 0), GFW_ERR_HIP);   // the warp that read this slot is done
+    { const int rc = stage_timings(c, t, 1, c->copy_stream, &d_t); if (rc != GFW_OK) return rc; }
+    HIP_TRY(gfw_launch_build_matrices(c->tracks, d_t, 1, t->rows, (double *)((char *)b.buf.ptr + table_bytes), (float *)b.buf.ptr, table_floats, c->copy_stream), GFW_ERR_HIP);
+    HIP_TRY(hipEventRecord(b.built, c->copy_stream), GFW_ERR_HIP);
+    if (out_ptr) *out_ptr = (float *)b.buf.ptr;
+    if (c->synchronous) HIP_TRY(hipStreamSynchronize(c->copy_stream), GFW_ERR_HIP);
+    return GFW_OK;
+}
+// The tables of `count` upcoming frames in one launch, in order on the context's stream: no cross-stream events, and the
+// builder's latency (a few slerps in f64 per row) is paid once per batch instead of once per frame.
+int gfw_build_matrices_batch(gfw_ctx *c, const gfw_frame_timing *t, int count, float **out_ptrs) {
+    if (!c || !t || !out_ptrs || count < 1 || count > gfw_ctx::kMaxBatch) { set_error("bad batch arguments (1 <= count <= %d)", gfw_ctx::kMaxBatch); return GFW_ERR_INVALID_ARGUMENT; }
+    int max_rows = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!timing_ok(&t[i])) { set_error("frame %d: rows %d, readout_dim %d", i, t[i].rows, t[i].readout_dim); return GFW_ERR_INVALID_ARGUMENT; }
+        if (t[i].rows > max_rows) max_rows = t[i].rows;
+    }
+    HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
+    // two batches alternate: the stream is in order, so the batch being overwritten was consumed by launches enqueued before this one
+    DevBuf &buf = c->d_batch[c->batch_next];
+    c->batch_next ^= 1;
+    const size_t table_floats = (size_t)max_rows * GFW_MAT_STRIDE;
+    const size_t tables_bytes = table_floats * sizeof(float) * count;
+    HIP_TRY(buf.ensure(tables_bytes + 4 * sizeof(double) * count), GFW_ERR_HIP);
+    const gfw_frame_timing *d_t = nullptr;
+    { const int rc = stage_timings(c, t, count, c->stream, &d_t); if (rc != GFW_OK) return rc; }
+    HIP_TRY(gfw_launch_build_matrices(c->tracks, d_t, count, max_rows, (double *)((char *)buf.ptr + tables_bytes), (float *)buf.ptr, table_floats, c->stream), GFW_ERR_HIP);
+    for (int i = 0; i < count; ++i) out_ptrs[i] = (float *)buf.ptr + table_floats * i;
     if (c->synchronous) HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
     return GFW_OK;
 }

@@ -7,4 +7,8 @@ struct GfwTracks {            // device-resident quaternion tracks (timestamp_us
     const int64_t *org_ts; const double *org_q; int org_n;
     const int64_t *sm_ts;  const double *sm_q;  int sm_n;
 };
-hipError_t gfw_launch_build_matrices(const GfwTracks &T, const gfw_frame_timing &F, float *out, hipStream_t s);
+// Builds `frames` tables of packed rows: d_timings[frames] (device), table f at out + f * table_floats, rows of frame f =
+// d_timings[f].rows (<= max_rows).  prefix_scratch: 4 * frames doubles of device memory owned by the caller for the
+// duration of the launch.
+hipError_t gfw_launch_build_matrices(const GfwTracks &T, const gfw_frame_timing *d_timings, int frames, int max_rows, double *prefix_scratch,
+                                     float *out, size_t table_floats, hipStream_t s);

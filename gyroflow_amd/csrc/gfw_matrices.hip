@@ -48,7 +48,26 @@ __device__ Q quat_at(const int64_t *ts, const double *q, int n, double timestamp
     return slerp(q1, q2, fract);
 }
 
-__global__ void gfw_build_matrices_kernel(const GfwTracks T, const gfw_frame_timing F, float *out) {
+// The row-independent factor smoothed(ts) * org(ts)^-1 (frame_transform.rs:255-256,289-291), once per frame: a
+// one-lane kernel in front of the row kernel, so that the 34 row waves do one slerp each instead of three.
+// Batched form: `frames` frame descriptors in device memory, one prefix lane per frame, blockIdx.y = frame.
+__global__ void gfw_build_prefix_kernel(const GfwTracks T, const gfw_frame_timing *Fs, int frames, double *prefix) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames) return;
+    const gfw_frame_timing &F = Fs[f];
+    prefix += (size_t)f * 4;
+    const double ts = F.timestamp_ms + F.per_frame_time_offset_ms;
+    Q q1 = quat_at(T.org_ts, T.org_q, T.org_n, ts);
+    const double n1 = q1.w * q1.w + q1.x * q1.x + q1.y * q1.y + q1.z * q1.z;
+    q1 = Q{q1.w / n1, -q1.x / n1, -q1.y / n1, -q1.z / n1};                         // inverse()
+    const Q sm = quat_at(T.sm_ts, T.sm_q, T.sm_n, ts);
+    const Q pre = qmul(sm, q1);
+    prefix[0] = pre.w; prefix[1] = pre.x; prefix[2] = pre.y; prefix[3] = pre.z;
+}
+__global__ void gfw_build_matrices_kernel(const GfwTracks T, const gfw_frame_timing *Fs, const double *prefix, float *out, size_t table_floats) {
+    const gfw_frame_timing &F = Fs[blockIdx.y];
+    prefix += (size_t)blockIdx.y * 4;
+    out += (size_t)blockIdx.y * table_floats;
     const int y = blockIdx.x * blockDim.x + threadIdx.x;
     if (y >= F.rows) return;
     const double frt = F.frame_readout_time_ms;
@@ -56,11 +75,8 @@ __global__ void gfw_build_matrices_kernel(const GfwTracks T, const gfw_frame_tim
     const double start_ts = ts - frt / 2.0;
     const double row_t = frt / (double)F.readout_dim;
     const double qt = (fabs(frt) > 0.0) ? start_ts + row_t * (double)y : start_ts;
-    Q q1 = quat_at(T.org_ts, T.org_q, T.org_n, ts);
-    const double n1 = q1.w * q1.w + q1.x * q1.x + q1.y * q1.y + q1.z * q1.z;
-    q1 = Q{q1.w / n1, -q1.x / n1, -q1.y / n1, -q1.z / n1};                         // inverse()
-    const Q sm = quat_at(T.sm_ts, T.sm_q, T.sm_n, ts);
-    Q q = qmul(sm, qmul(q1, quat_at(T.org_ts, T.org_q, T.org_n, qt)));
+    const Q pre{prefix[0], prefix[1], prefix[2], prefix[3]};
+    Q q = qmul(pre, quat_at(T.org_ts, T.org_q, T.org_n, qt));
     const double nn = sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
     q = Q{q.w / nn, q.x / nn, q.y / nn, q.z / nn};
     double r[3][3] = {
@@ -87,8 +103,10 @@ __global__ void gfw_build_matrices_kernel(const GfwTracks T, const gfw_frame_tim
 
 }  // namespace
 
-hipError_t gfw_launch_build_matrices(const GfwTracks &T, const gfw_frame_timing &F, float *out, hipStream_t s) {
-    if (F.rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gfw_build_matrices_kernel, dim3((F.rows + 127) / 128), dim3(128), 0, s, T, F, out);
+hipError_t gfw_launch_build_matrices(const GfwTracks &T, const gfw_frame_timing *d_timings, int frames, int max_rows, double *prefix_scratch,
+                                     float *out, size_t table_floats, hipStream_t s) {
+    if (frames <= 0 || max_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gfw_build_prefix_kernel, dim3((frames + 63) / 64), dim3(64), 0, s, T, d_timings, frames, prefix_scratch);
+    hipLaunchKernelGGL(gfw_build_matrices_kernel, dim3((max_rows + 63) / 64, frames), dim3(64), 0, s, T, d_timings, (const double *)prefix_scratch, out, table_floats);
     return hipGetLastError();
 }

@@ -114,6 +114,23 @@ class Backend:
         self._check(self.lib.gfw_build_matrices(self.ctx, C.byref(t), out_ptr, C.byref(ptr)))
         return ptr.value
 
+    def build_matrices_batch(self, nk, timestamps_ms, frame_readout_time_ms, rows, readout_dim, video_rotation_deg=0.0,
+                             framebuffer_inverted=False, per_frame_offset_ms=0.0):
+        """Tables of several upcoming frames in one launch (gfw_build_matrices_batch); returns the device pointers."""
+        n = len(timestamps_ms)
+        arr = (abi.FrameTiming * n)()
+        nkf = np.asarray(nk, dtype=np.float64).reshape(9)
+        for k, ts in enumerate(timestamps_ms):
+            t = arr[k]
+            t.timestamp_ms, t.per_frame_time_offset_ms, t.frame_readout_time_ms = ts, per_frame_offset_ms, frame_readout_time_ms
+            for i in range(9):
+                t.new_k[i] = nkf[i]
+            t.video_rotation_deg, t.rows, t.readout_dim = video_rotation_deg, rows, readout_dim
+            t.framebuffer_inverted = 1 if framebuffer_inverted else 0
+        ptrs = (C.c_void_p * n)()
+        self._check(self.lib.gfw_build_matrices_batch(self.ctx, arr, n, ptrs))
+        return [p for p in ptrs]
+
     def stmap_undistort(self, params, matrices, width, height, mesh=None):
         """STMap 'undist' coordinates (stmap.rs:87-109) as a float32 array [height][width][2] (0 where None)."""
         m = np.ascontiguousarray(matrices, dtype=np.float32)

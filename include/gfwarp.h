@@ -257,7 +257,7 @@ enum {
     GFW_OPT_KERNEL_VARIANT     = 3,  /* 0 auto; 1 generic per-plane kernel; 2 fused kernel with the exact first pass;
                                         3 fused kernel, certified first pass in audit mode (see gfw_get_audit) */
     GFW_OPT_PROFILE            = 4,  /* 1: bracket every warp-kernel launch with hipEvents on the context stream */
-    GFW_OPT_TUNE_ROWS          = 5,  /* tuning: luma block rows per lane of the fused kernel (1, 2, 4, 8; 0 = default) */
+    GFW_OPT_TUNE_ROWS          = 5,  /* reserved (ignored) */
     GFW_OPT_TUNE_GRID          = 6   /* tuning: persistent workgroups of the fused kernel (0 = 6 per CU) */
 };
 int   gfw_set_option(gfw_ctx *ctx, int option, int64_t value);
@@ -305,6 +305,11 @@ typedef struct gfw_frame_timing {
 int   gfw_set_quaternion_tracks(gfw_ctx *ctx, const int64_t *org_ts_us, const double *org_wxyz, int org_count,
                                 const int64_t *smoothed_ts_us, const double *smoothed_wxyz, int smoothed_count);
 int   gfw_build_matrices(gfw_ctx *ctx, const gfw_frame_timing *timing, float *rows16_out, float **out_ptr);
+/* The tables of `count` (<= 64) upcoming frames in one launch, in order on the context's stream, into context-owned
+ * memory (two batches alternate: a batch stays valid until the second next call).  out_ptrs[i] = device table of frame i,
+ * to be passed as `matrices` with GFW_OPT_MATRICES_ON_DEVICE = 2.  Amortises the builder's latency and needs no
+ * cross-stream synchronisation: the per-frame cost in a render loop drops to ~1 us of GPU time. */
+int   gfw_build_matrices_batch(gfw_ctx *ctx, const gfw_frame_timing *timings, int count, float **out_ptrs);
 
 /* ---- STMap coordinate export ("next" row: src/core/stmap.rs:87-109, :127-137) ----------------------------
  * The "undist" ST map: for every pixel (x, y) of a width x height map, the rolling-shutter row pick followed by

@@ -77,3 +77,72 @@ def test_warp_with_device_built_rows_is_bit_exact_against_oracle_fed_the_same_ro
     ref = O.run_frame(fr)
     for a, b in zip(ref, outs):
         assert np.array_equal(a, b)
+
+
+def test_async_ring_of_built_tables_overlaps_without_changing_results():
+    """Ten frames enqueued back to back in asynchronous mode: each frame's table is built on the context's auxiliary
+    stream while earlier frames are still being warped (ring of 4 tables, ordered by events).  Every frame must equal the
+    result of the same build + warp done synchronously."""
+    import torch
+    w, h = 640, 360
+    fr = S.SyntheticFrame("YUV422P16LE", w, h, seed=9)
+    org = S.sampled_track(21, 0.0, 3000.0, 1000.0)
+    sm = S.sampled_track(22, 0.0, 3000.0, 200.0, scale=0.25)
+    nk = S.new_k(fr.lens, 1.0, w, h)
+    params = [pl["params"] for pl in fr.planes]
+    types = [pl["pixel_type"] for pl in fr.planes]
+    dev = torch.device("cuda", 0)
+    d_src = [torch.from_numpy(pl["src"]).to(dev) for pl in fr.planes]
+    stamps = [1000.0 + 33.3 * i for i in range(10)]
+
+    def run(asynchronous):
+        d_dst = [[torch.from_numpy(pl["dst"]).to(dev) for pl in fr.planes] for _ in stamps]
+        bufs = [[warp.device_buffers(d_src[p].data_ptr(), d_src[p].numel(), pl["size"], d_dst[i][p].data_ptr(), d_dst[i][p].numel(), pl["out_size"])
+                 for p, pl in enumerate(fr.planes)] for i in range(len(stamps))]
+        be = warp.Backend(params[0], types[0], fr.model, 0, bufs[0][0])
+        try:
+            be.set_quaternion_tracks(org, sm)
+            be.set_option(abi.OPT_MATRICES_ON_DEVICE, 2)
+            be.set_option(abi.OPT_SYNCHRONOUS, 0 if asynchronous else 1)
+            ptrs = []
+            for i, ts in enumerate(stamps):
+                ptr = be.build_matrices(nk, ts, 16.0, h, h)
+                ptrs.append(ptr)
+                be.undistort_frame(bufs[i], params, types, ptr, matrix_count=h)
+            be.synchronize()
+            assert len(set(ptrs)) == 4                      # the ring
+            assert warp.last_backend() == "yuv_fused_p1"
+        finally:
+            be.close()
+        torch.cuda.synchronize()
+        return [[t.cpu().numpy() for t in planes] for planes in d_dst]
+
+    sync, asyn = run(False), run(True)
+    for i in range(len(stamps)):
+        for a, b in zip(sync[i], asyn[i]):
+            assert np.array_equal(a, b), "frame %d" % i
+    assert not np.array_equal(sync[0][0], sync[5][0])       # the frames do differ
+
+
+def test_batch_build_equals_single_builds():
+    """gfw_build_matrices_batch: every table of a batch is byte-identical to the single-frame build of the same frame."""
+    w, h = 640, 360
+    fr = S.SyntheticFrame("YUV422P16LE", w, h, seed=9)
+    org = S.sampled_track(21, 0.0, 3000.0, 1000.0)
+    sm = S.sampled_track(22, 0.0, 3000.0, 200.0, scale=0.25)
+    nk = S.new_k(fr.lens, 1.0, w, h)
+    pl = fr.planes[0]
+    be = warp.Backend(pl["params"], pl["pixel_type"], fr.model, 0, warp.host_buffers(pl["src"], pl["size"], pl["dst"].copy(), pl["out_size"]))
+    try:
+        be.set_quaternion_tracks(org, sm)
+        stamps = [1000.0 + 33.3 * i for i in range(7)]
+        ptrs = be.build_matrices_batch(nk, stamps, 16.0, h, h)
+        assert len(set(ptrs)) == 7
+        batch = [fetch_rows(p, h) for p in ptrs]
+        for ts, rows in zip(stamps, batch):
+            single = fetch_rows(be.build_matrices(nk, ts, 16.0, h, h), h)
+            assert np.array_equal(rows.view(np.uint32), single.view(np.uint32))
+        with pytest.raises(warp.GfwError):
+            be.build_matrices_batch(nk, [0.0] * 65, 16.0, h, h)
+    finally:
+        be.close()
