@@ -15,6 +15,7 @@ template <int OP> __global__ __launch_bounds__(256) void k(float *out, float a0,
     const float t = (float)threadIdx.x * 1e-7f;
     for (int i = 0; i < 8; ++i) { v[i] = a0 + t + i * 0.001f; p[i] = (f2){v[i], v[i] + 0.5f}; }
     const float b = b0; const f2 pb = {b0, b0 * 1.0001f};
+    unsigned long long mask = __ballot(threadIdx.x & 1), m2 = 0;
     for (int it = 0; it < ITER; ++it) {
         #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -39,9 +40,24 @@ template <int OP> __global__ __launch_bounds__(256) void k(float *out, float a0,
             if (OP == 18) asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(v[i]) : "v"(v[i]), "v"(b), "v"(b));
             if (OP == 19) asm volatile("v_max_f32 %0, %1, %2" : "=v"(v[i]) : "v"(v[i]), "v"(b));
             if (OP == 20) asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(v[i]), "v"(b) : "vcc");
+            if (OP == 21) asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(v[i]) : "v"(v[i]), "v"(b), "s"(mask));
+            if (OP == 22) asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, %1, %2, vcc" : "=v"(v[i]) : "v"(v[i]), "v"(b) : "vcc");
+            if (OP == 23) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[i]) : "v"(b), "v"(b));
+            if (OP == 24) asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(v[i]) : "v"(v[i]), "v"(b), "v"(b));
+            if (OP == 25) asm volatile("v_min_f32 %0, %1, %2" : "=v"(v[i]) : "v"(v[i]), "v"(b));
+            if (OP == 26) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(v[i]) : "v"(v[i]), "v"(b));
+            if (OP == 27) asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(v[i]) : "v"(v[i]));
+            if (OP == 28) asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(v[i]) : "v"(v[i]), "v"(b), "v"(b));
+            if (OP == 29) asm volatile("v_lshlrev_b32 %0, 1, %1" : "=v"(v[i]) : "v"(v[i]));
+            if (OP == 30) asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(m2) : "v"(v[i]), "v"(b));
+            if (OP == 31) asm volatile("v_mov_b32 %0, %1" : "=v"(v[i]) : "v"(v[i]));
+            if (OP == 32) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(v[i]) : "s"(b), "v"(v[i]));
+            if (OP == 33) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(v[i]) : "v"(v[i]), "s"(b), "v"(v[i]));
+            if (OP == 34) asm volatile("v_add_u32 %0, %1, %2" : "=v"(v[i]) : "v"(v[i]), "v"(b));
+            if (OP == 35) asm volatile("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(v[i]) : "v"(v[i]));
         }
     }
-    float s = 0; for (int i = 0; i < 8; ++i) s += v[i] + p[i].x + p[i].y;
+    float s = (float)(m2 & 1); for (int i = 0; i < 8; ++i) s += v[i] + p[i].x + p[i].y;
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -83,6 +99,21 @@ int main() {
         run<18>("v_mad_u32_u24", d, 1, 1.5f, 1.0f, bpc);
         run<19>("v_max_f32", d, 1, 1.5f, 1.0f, bpc);
         run<20>("v_cmp_lt_f32", d, 1, 1.5f, 1.0f, bpc);
+        run<21>("v_cndmask_b32_e64 (sgpr mask)", d, 1, 1.5f, 1.0f, bpc);
+        run<22>("v_cmp + v_cndmask (vcc) pair", d, 1, 1.5f, 1.0f, bpc);
+        run<30>("v_cmp_lt_f32_e64 -> sgpr", d, 1, 1.5f, 1.0f, bpc);
+        run<23>("v_fmac_f32 (asm)", d, 1, 1.0f, 0.001f, bpc);
+        run<24>("v_fma_f32 neg mod (asm)", d, 1, 1.0f, 0.999f, bpc);
+        run<33>("v_fma_f32 sgpr src (asm)", d, 1, 1.0f, 0.5f, bpc);
+        run<32>("v_mul_f32 sgpr src", d, 1, 1.0f, 0.999f, bpc);
+        run<25>("v_min_f32", d, 1, 1.5f, 1.0f, bpc);
+        run<26>("v_sub_f32", d, 1, 1.5f, 0.001f, bpc);
+        run<27>("v_cvt_f32_u32", d, 1, 1.5f, 1.0f, bpc);
+        run<35>("v_cvt_f32_u32_sdwa", d, 1, 1.5f, 1.0f, bpc);
+        run<28>("v_bfi_b32", d, 1, 1.5f, 1.0f, bpc);
+        run<29>("v_lshlrev_b32", d, 1, 1.5f, 1.0f, bpc);
+        run<34>("v_add_u32", d, 1, 1.5f, 1.0f, bpc);
+        run<31>("v_mov_b32", d, 1, 1.5f, 1.0f, bpc);
         run<11>("IEEE a/b + add", d, 1, 1.5f, 1.0001f, bpc);
         run<12>("IEEE sqrtf + add", d, 1, 1.5f, 1.0f, bpc);
         run<13>("ocml atanf + add", d, 1, 0.7f, 1.0f, bpc);
