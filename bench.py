@@ -60,7 +60,6 @@ def main():
                     help="bracket every N-th launch of the timed region with hipEvents for the roofline's kernel duration "
                          "(0 = none); the event pairs themselves cost GPU time between back-to-back kernels")
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--build-matrices", action="store_true",
                     help="build every frame's per-row matrices on the device from quaternion tracks (gfw_build_matrices, "
@@ -125,8 +124,6 @@ def main():
     be.set_option(abi.OPT_SYNCHRONOUS, 1 if args.host_buffers else 0)
     if args.variant:
         be.set_option(abi.OPT_KERNEL_VARIANT, args.variant)
-    if args.rows:
-        be.set_option(abi.OPT_TUNE_ROWS, args.rows)
     if args.grid:
         be.set_option(abi.OPT_TUNE_GRID, args.grid)
 
