@@ -898,14 +898,13 @@ int gfw_build_matrices_batch(gfw_ctx *c, const gfw_frame_timing *t, int count, f
 }
 }
 
-// Inverse point map (`undistort_points`, cpu_undistort.rs:652-858 with lens_correction_amount == 1; the STMap "dist"
+// Inverse point map (`undistort_points`, cpu_undistort.rs:652-858; the STMap "dist"
 // pass stmap.rs:123-127 runs it per pixel).  See include/gfwarp.h for the argument contract.
 extern "C" int gfw_undistort_points(gfw_ctx *c, const gfw_kernel_params *p, const float *points, size_t n, int grid_width,
                                     const float *rotations, int rotation_count, const float *shifts, int index_mode,
                                     const double *mesh, size_t mesh_len, float *out, int out_on_device) {
     if (!c || !p || !rotations || !out || rotation_count < 1 || index_mode < 0 || index_mode > 3) { set_error("bad undistort_points arguments"); return GFW_ERR_INVALID_ARGUMENT; }
     if (!points && grid_width < 1) { set_error("grid_width must be >= 1 when points is NULL"); return GFW_ERR_INVALID_ARGUMENT; }
-    if (p->lens_correction_amount < 1.0f) { set_error("undistort_points: lens_correction_amount < 1 (Newton inverse of the render blend, cpu_undistort.rs:792-851) is not provided"); return GFW_ERR_INVALID_ARGUMENT; }
     if (mesh_len > GFW_MESH_MAX) { set_error("mesh too large"); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
     if (n == 0) return GFW_OK;                                               // :637 `if distorted.is_empty() { return Vec::new(); }`
     HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);

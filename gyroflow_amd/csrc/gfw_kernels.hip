@@ -57,10 +57,73 @@ hipError_t gfw_launch_stmap(const gfw_kernel_params &P, const GfwCommon &C, int 
 }
 
 // ---------------------------------------------------------------------------- inverse point map
-// `undistort_points` (cpu_undistort.rs:652-858, lens_correction_amount == 1): source-image point -> stabilised output
+// `undistort_points` (cpu_undistort.rs:652-858): source-image point -> stabilised output
 // coordinate; the STMap "dist" pass (stmap.rs:123-127) runs it over the pixel grid.  One point per lane; the rotation
 // (and optional IBIS/OIS shift) row is picked per point / grid row / grid column.  shifts rows are 6 floats:
 // sx, sy, cos(angle), sin(angle), ox, oy with the trig evaluated by the host libm (gfw_api.hip).
+// undistort_points' lens-correction branch (cpu_undistort.rs:785-851): Newton solve of amount*o + (1-amount)*R(o) = pt,
+// R = the render's forward map (digital undistort -> /out_f -> radial undistort -> refraction -> *out_f), :804-826.
+struct GfwLc { float out_c0, out_c1, out_f0, out_f1, amount, factor, fov; };
+template <int MODEL>
+__device__ inline float2 gfw_lc_r_of(const GfwLc &L, float o0, float o1, const gfw_kernel_params &P, const GfwCommon &C) {
+    float q0 = o0, q1 = o1;
+    if (C.digital != GFW_MODEL_NONE) {
+        const float uz0 = (q0 - L.out_c0) * L.fov + L.out_c0, uz1 = (q1 - L.out_c1) * L.fov + L.out_c1;
+        const GfwPt d = gfw_lens::digital_undistort(C.digital, uz0, uz1, P);
+        if (d.ok) { q0 = (d.x - L.out_c0) / L.fov + L.out_c0; q1 = (d.y - L.out_c1) / L.fov + L.out_c1; }
+    }
+    float n0 = (q0 - L.out_c0) / L.out_f0, n1 = (q1 - L.out_c1) / L.out_f1;
+    const GfwPt d = gfw_lens::undistort<MODEL>(C.model, n0, n1, P, C);
+    if (d.ok) { n0 = d.x; n1 = d.y; }
+    if (P.light_refraction_coefficient != 1.0f && P.light_refraction_coefficient > 0.0f) {
+        const float r = sqrtf(n0 * n0 + n1 * n1);
+        if (r != 0.0f) {
+            const float sin_theta_d = (r / sqrtf(1.0f + r * r)) / P.light_refraction_coefficient;
+            const float r_d = sin_theta_d / sqrtf(1.0f - sin_theta_d * sin_theta_d);
+            const float sc = r_d / r;
+            n0 = n0 * sc; n1 = n1 * sc;
+        }
+    }
+    return float2{(n0 * L.out_f0) + L.out_c0, (n1 * L.out_f1) + L.out_c1};
+}
+__device__ __forceinline__ bool gfw_finite(float x) { return fabsf(x) < __builtin_inff(); }   // false for inf and NaN
+template <int MODEL>
+__device__ inline float2 gfw_lc_solve(const GfwLc &L, float p0, float p1, const gfw_kernel_params &P, const GfwCommon &C) {
+    float inv0, inv1;
+    {
+        const float n0 = (p0 - L.out_c0) / L.out_f0, n1 = (p1 - L.out_c1) / L.out_f1;
+        float d0, d1;
+        gfw_lens::distort<MODEL>(C.model, n0, n1, 1.0f, P, C, d0, d1);
+        inv0 = (d0 * L.out_f0) + L.out_c0; inv1 = (d1 * L.out_f1) + L.out_c1;
+        if (C.digital != GFW_MODEL_NONE) {
+            const float uz0 = (inv0 - L.out_c0) * L.fov + L.out_c0, uz1 = (inv1 - L.out_c1) * L.fov + L.out_c1;
+            float dd0, dd1;
+            gfw_lens::digital_distort(C.digital, uz0, uz1, P, dd0, dd1);
+            inv0 = (dd0 - L.out_c0) / L.fov + L.out_c0; inv1 = (dd1 - L.out_c1) / L.fov + L.out_c1;
+        }
+    }
+    float o0 = p0, o1 = p1;
+    if (gfw_finite(inv0) && gfw_finite(inv1)) { o0 = inv0 * L.factor + p0 * L.amount; o1 = inv1 * L.factor + p1 * L.amount; }
+    #pragma unroll 1
+    for (int it = 0; it < 10; ++it) {
+        const float2 r = gfw_lc_r_of<MODEL>(L, o0, o1, P, C);
+        const float g0 = L.amount * o0 + L.factor * r.x - p0, g1 = L.amount * o1 + L.factor * r.y - p1;
+        if (fabsf(g0) < 0.02f && fabsf(g1) < 0.02f) break;
+        const float eps = 1.0f;
+        const float2 rx = gfw_lc_r_of<MODEL>(L, o0 + eps, o1, P, C);
+        const float2 ry = gfw_lc_r_of<MODEL>(L, o0, o1 + eps, P, C);
+        const float j11 = L.amount + L.factor * (rx.x - r.x) / eps, j21 = L.factor * (rx.y - r.y) / eps;
+        const float j12 = L.factor * (ry.x - r.x) / eps,            j22 = L.amount + L.factor * (ry.y - r.y) / eps;
+        const float det = j11 * j22 - j12 * j21;
+        if (!gfw_finite(det) || fabsf(det) < 1e-9f) break;
+        const float dx = ( j22 * g0 - j12 * g1) / det;
+        const float dy = (-j21 * g0 + j11 * g1) / det;
+        if (!gfw_finite(dx) || !gfw_finite(dy)) break;
+        o0 = o0 - dx; o1 = o1 - dy;
+    }
+    return float2{o0, o1};
+}
+
 template <int MODEL>
 __global__ __launch_bounds__(256) void gfw_points_kernel(const gfw_kernel_params P, const GfwCommon C, const GfwPointsArgs A) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -135,6 +198,15 @@ __global__ __launch_bounds__(256) void gfw_points_kernel(const gfw_kernel_params
         const float pr1 = ((r[3] * ptx) + r[4] * pty) + r[5];
         const float pr2 = ((r[6] * ptx) + r[7] * pty) + r[8];
         o = float2{pr0 / pr2, pr1 / pr2};
+        if (P.lens_correction_amount < 1.0f) {                                                 // :683-692, :785-851
+            GfwLc L;
+            L.out_c0 = (float)P.output_width / 2.0f; L.out_c1 = (float)P.output_height / 2.0f;
+            L.amount = P.lens_correction_amount;
+            L.factor = fmaxf(1.0f - L.amount, 0.001f);
+            L.out_f0 = P.f[0] / P.fov / L.factor; L.out_f1 = P.f[1] / P.fov / L.factor;
+            L.fov = P.fov;
+            o = gfw_lc_solve<MODEL>(L, o.x, o.y, P, C);
+        }
     }
     reinterpret_cast<float2 *>(A.out)[i] = o;
 }

@@ -320,9 +320,10 @@ int   gfw_stmap_undistort(gfw_ctx *ctx, const gfw_kernel_params *params, const f
                           const float *mesh, size_t mesh_len, int width, int height, float *coords, int coords_on_device);
 
 /* ---- inverse point map ("next" row 3: cpu_undistort.rs:652-858 `undistort_points`; stmap.rs:123-127 "dist") ----
- * Source-image points -> stabilised output coordinates, for lens_correction_amount == 1 (what the STMap "dist"
- * pass and the optical-flow caller cpu_undistort.rs:643-650 use; params->lens_correction_amount < 1 is refused
- * with GFW_ERR_INVALID_ARGUMENT).  The lens / digital-lens models are the ones given to gfw_create.
+ * Source-image points -> stabilised output coordinates.  The STMap "dist" pass and the optical-flow caller
+ * (cpu_undistort.rs:643-650) run it with lens_correction_amount == 1; with params->lens_correction_amount < 1 the
+ * Newton inverse of the render's lens-correction blend follows (:785-851, what the zoom search uses), with
+ * params->fov as its `fov`.  The lens / digital-lens models are the ones given to gfw_create.
  *   params     the KernelParams undistort_points builds (:669-681: width/height/output_*, f, c, k,
  *              digital_lens_params, light_refraction_coefficient) with input_*_stretch = lens.input_*_stretch (:704-705)
  *   points     n x 2 f32 (host), or NULL = the pixel grid parallel_exr walks: point i = (i % grid_width, i / grid_width)

@@ -1166,9 +1166,74 @@ int gfw_oracle_stmap_undistort(const gfw_kernel_params *p, int distortion_model,
     return 1;
 }
 
-/* Inverse point map: `undistort_points` cpu_undistort.rs:652-858 with lens_correction_amount == 1 (the value the
- * STMap "dist" pass stmap.rs:123-127 and the optical-flow caller :643-650 use; the < 1 Newton branch :792-851 belongs
- * to the zoom search and is not restated).  Source-image point -> stabilised output coordinate.
+/* `r_of` of undistort_points' lens-correction branch (cpu_undistort.rs:804-826): the render's forward map R(o) of an
+ * in-frame output pixel o = digital_undistort -> /out_f -> radial undistort -> refraction -> *out_f. */
+typedef struct { float out_c[2], out_f[2], amount, factor, fov; int model, digital; const KP *p; } lc_ctx;
+static void lc_r_of(const lc_ctx *L, float o0, float o1, float *r0, float *r1) {
+    float q0 = o0, q1 = o1;
+    if (L->digital != GFW_MODEL_NONE) {
+        float uz0 = (q0 - L->out_c[0]) * L->fov + L->out_c[0], uz1 = (q1 - L->out_c[1]) * L->fov + L->out_c[1];
+        opt2 d = digital_undistort(L->digital, uz0, uz1, L->p);
+        if (d.ok) { q0 = (d.x - L->out_c[0]) / L->fov + L->out_c[0]; q1 = (d.y - L->out_c[1]) / L->fov + L->out_c[1]; }
+    }
+    float n0 = (q0 - L->out_c[0]) / L->out_f[0], n1 = (q1 - L->out_c[1]) / L->out_f[1];
+    opt2 d = model_undistort(L->model, n0, n1, L->p);
+    if (d.ok) { n0 = d.x; n1 = d.y; }
+    if (L->p->light_refraction_coefficient != 1.0f && L->p->light_refraction_coefficient > 0.0f) {
+        float r = sqrtf(n0 * n0 + n1 * n1);
+        if (r != 0.0f) {
+            float sin_theta_d = (r / sqrtf(1.0f + r * r)) / L->p->light_refraction_coefficient;
+            float r_d = sin_theta_d / sqrtf(1.0f - sin_theta_d * sin_theta_d);
+            float sc = r_d / r;
+            n0 = n0 * sc; n1 = n1 * sc;
+        }
+    }
+    *r0 = (n0 * L->out_f[0]) + L->out_c[0]; *r1 = (n1 * L->out_f[1]) + L->out_c[1];
+}
+/* cpu_undistort.rs:792-851: solve amount*o + (1-amount)*R(o) = pt for the output position o (Newton, forward differences) */
+static void lc_solve(const lc_ctx *L, float *pt0, float *pt1) {
+    const float p0 = *pt0, p1 = *pt1;
+    float inv0, inv1;
+    {
+        float n0 = (p0 - L->out_c[0]) / L->out_f[0], n1 = (p1 - L->out_c[1]) / L->out_f[1];
+        float d0, d1;
+        model_distort(L->model, n0, n1, 1.0f, L->p, &d0, &d1);
+        inv0 = (d0 * L->out_f[0]) + L->out_c[0]; inv1 = (d1 * L->out_f[1]) + L->out_c[1];
+        if (L->digital != GFW_MODEL_NONE) {
+            float uz0 = (inv0 - L->out_c[0]) * L->fov + L->out_c[0], uz1 = (inv1 - L->out_c[1]) * L->fov + L->out_c[1];
+            float dd0, dd1;
+            digital_distort(L->digital, uz0, uz1, L->p, &dd0, &dd1);
+            inv0 = (dd0 - L->out_c[0]) / L->fov + L->out_c[0]; inv1 = (dd1 - L->out_c[1]) / L->fov + L->out_c[1];
+        }
+    }
+    float o0, o1;
+    if (isfinite(inv0) && isfinite(inv1)) { o0 = inv0 * L->factor + p0 * L->amount; o1 = inv1 * L->factor + p1 * L->amount; }
+    else { o0 = p0; o1 = p1; }
+    for (int it = 0; it < 10; ++it) {
+        float r0, r1;
+        lc_r_of(L, o0, o1, &r0, &r1);
+        float g0 = L->amount * o0 + L->factor * r0 - p0, g1 = L->amount * o1 + L->factor * r1 - p1;
+        if (fabsf(g0) < 0.02f && fabsf(g1) < 0.02f) break;
+        const float eps = 1.0f;
+        float rx0, rx1, ry0, ry1;
+        lc_r_of(L, o0 + eps, o1, &rx0, &rx1);
+        lc_r_of(L, o0, o1 + eps, &ry0, &ry1);
+        float j11 = L->amount + L->factor * (rx0 - r0) / eps, j21 = L->factor * (rx1 - r1) / eps;
+        float j12 = L->factor * (ry0 - r0) / eps,             j22 = L->amount + L->factor * (ry1 - r1) / eps;
+        float det = j11 * j22 - j12 * j21;
+        if (!isfinite(det) || fabsf(det) < 1e-9f) break;
+        float dx = ( j22 * g0 - j12 * g1) / det;
+        float dy = (-j21 * g0 + j11 * g1) / det;
+        if (!isfinite(dx) || !isfinite(dy)) break;
+        o0 = o0 - dx; o1 = o1 - dy;
+    }
+    *pt0 = o0; *pt1 = o1;
+}
+
+/* Inverse point map: `undistort_points` cpu_undistort.rs:652-858 (the STMap "dist" pass stmap.rs:123-127 and
+ * the optical-flow caller :643-650 run it with lens_correction_amount == 1; the zoom search reaches the < 1 branch,
+ * :785-851: Newton inverse of the render's blend, taken when p->lens_correction_amount < 1, with p->fov as `fov`).
+ * Source-image point -> stabilised output coordinate.
  *   p         the KernelParams `undistort_points` builds (:669-681: width/height/output_*, f, c, k, digital_lens_params,
  *             light_refraction_coefficient) plus input_*_stretch carrying params.lens.input_*_stretch (:704-705)
  *   points    n x 2 f32, or NULL = the pixel grid (x = i % grid_w, y = i / grid_w) that parallel_exr walks
@@ -1184,6 +1249,16 @@ int gfw_oracle_undistort_points(const gfw_kernel_params *p, int distortion_model
                                 const double *md, size_t mesh_len, float *out)
 {
     const float c0 = p->c[0], c1 = p->c[1], f0 = p->f[0], f1 = p->f[1];
+    /* :683-692 lens-correction blend constants (point-independent) */
+    lc_ctx L; memset(&L, 0, sizeof(L));
+    const int has_lc = p->lens_correction_amount < 1.0f;
+    if (has_lc) {
+        L.out_c[0] = (float)p->output_width / 2.0f; L.out_c[1] = (float)p->output_height / 2.0f;
+        L.amount = p->lens_correction_amount;
+        L.factor = fmaxf(1.0f - L.amount, 0.001f);
+        L.out_f[0] = f0 / p->fov / L.factor; L.out_f[1] = f1 / p->fov / L.factor;
+        L.fov = p->fov; L.model = distortion_model; L.digital = digital_lens; L.p = p;
+    }
     #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; ++i) {
         float x, y; size_t gx = 0, gy = 0;
@@ -1255,7 +1330,9 @@ int gfw_oracle_undistort_points(const gfw_kernel_params *p, int distortion_model
             float pr0 = ((r[0] * ptx) + r[1] * pty) + r[2] * 1.0f;                         /* :782 (nalgebra gemv order) */
             float pr1 = ((r[3] * ptx) + r[4] * pty) + r[5] * 1.0f;
             float pr2 = ((r[6] * ptx) + r[7] * pty) + r[8] * 1.0f;
-            out[i * 2] = pr0 / pr2; out[i * 2 + 1] = pr1 / pr2;                             /* :783 */
+            float q0 = pr0 / pr2, q1 = pr1 / pr2;                                           /* :783 */
+            if (has_lc) lc_solve(&L, &q0, &q1);                                              /* :785-851 */
+            out[i * 2] = q0; out[i * 2 + 1] = q1;
         } else {
             out[i * 2] = -1000000.0f; out[i * 2 + 1] = -1000000.0f;                         /* :855 */
         }

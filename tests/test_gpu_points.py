@@ -119,6 +119,35 @@ def test_points_sony_mesh_f64(with_mesh, with_fpd):
     assert same_bits(ref, got)
 
 
+@pytest.mark.parametrize("model", ["opencv_fisheye", "opencv_standard", "poly5", "sony", "gopro", "insta360"])
+@pytest.mark.parametrize("lca,digital", [(0.35, None), (0.8, "gopro_superview"), (0.0, "digital_stretch")])
+def test_points_lens_correction_branch_bit_exact(model, lca, digital):
+    """lens_correction_amount < 1: the Newton inverse of the render blend (cpu_undistort.rs:785-851) on the device."""
+    w, h = 256, 144
+    lens = S.gopro_style_lens(w, h)
+    lens["model"] = model
+    lens["k"] = PHYSICAL[model] + [0.0] * (12 - len(PHYSICAL[model]))
+    ov = {"lens_correction_amount": lca}
+    if digital:
+        lens["digital"] = digital
+        ov["digital_lens_params"] = DIGITAL[digital]
+    fr = S.SyntheticFrame("YUV422P16LE", w, h, seed=83, lens=lens, fov=1.25, base_overrides=ov)
+    kp = points_params(fr)
+    kp.lens_correction_amount = lca
+    kp.fov = fr.planes[0]["params"].fov
+    kp.light_refraction_coefficient = 1.0 if model != "sony" else 1.33
+    pts = wild_points(w, h, 6000, 13)
+    rows = np.nan_to_num(np.clip(np.round(pts[:, 1]), 0, h - 1), nan=0.0, posinf=h - 1, neginf=0).astype(np.int64)
+    rot = fr.rotations[rows]
+    ref = O.undistort_points(kp, fr.model, fr.digital, rot, points=pts, index_mode=abi.POINT_INDEX_PER_POINT)
+    be = backend_for(fr)
+    try:
+        got = be.undistort_points(kp, rot, points=pts, index_mode=abi.POINT_INDEX_PER_POINT)
+    finally:
+        be.close()
+    assert same_bits(ref, got)
+
+
 def test_points_argument_errors():
     w, h = 64, 48
     fr = S.SyntheticFrame("NV12", w, h, seed=3)
@@ -126,12 +155,8 @@ def test_points_argument_errors():
     be = backend_for(fr)
     try:
         assert be.undistort_points(kp, fr.rotations, points=np.zeros((0, 2), np.float32)).shape == (0, 2)
-        kp.lens_correction_amount = 0.5
         with pytest.raises(warp.GfwError) as e:
-            be.undistort_points(kp, fr.rotations, points=np.ones((4, 2), np.float32))
-        assert e.value.code == abi.ERR_INVALID_ARGUMENT
-        kp.lens_correction_amount = 1.0
-        with pytest.raises(warp.GfwError):
             be.undistort_points(kp, fr.rotations, points=np.ones((4, 2), np.float32), index_mode=9)
+        assert e.value.code == abi.ERR_INVALID_ARGUMENT
     finally:
         be.close()

@@ -69,3 +69,33 @@ def test_inverse_map_failed_lens_inverse_and_empty_input():
         assert out[0, 0] == -1000000.0 and out[0, 1] == -1000000.0          # cpu_undistort.rs:855
     assert abs(out[1, 0]) < 1000.0
     assert O.undistort_points(kp, fr.model, 0, fr.rotations, points=np.zeros((0, 2), np.float32)).shape == (0, 2)
+
+
+@pytest.mark.parametrize("model", ["opencv_fisheye", "opencv_standard", "sony"])
+@pytest.mark.parametrize("lca", [0.3, 0.75])
+def test_lens_correction_branch_inverts_the_render_blend(model, lca):
+    """lens_correction_amount < 1: `undistort_points` (cpu_undistort.rs:785-851) must undo the blend `undistort_coord`
+    applies on the way in (:429-460).  Newton stops at |g| < 0.02 px, so the round trip is good to a few hundredths."""
+    w, h = 192, 108
+    lens = S.gopro_style_lens(w, h)
+    lens["model"] = model
+    lens["k"] = CASES[model] + [0.0] * (12 - len(CASES[model]))
+    fr = S.SyntheticFrame("YUV422P16LE", w, h, seed=9, lens=lens, fov=1.3, readout_ms=0.0, base_overrides={"lens_correction_amount": lca})
+    kp = fr.planes[0]["params"]
+    pts, want = [], []
+    for y in range(10, h - 10, 11):
+        for x in range(10, w - 10, 13):
+            ok, u, v = O.undistort_coord(kp, fr.model, 0, fr.matrices, float(x), float(y))
+            if ok:
+                pts.append((u, v)); want.append((x, y))
+    assert len(pts) > 50
+    pp = points_params(fr)
+    pp.lens_correction_amount = lca
+    pp.fov = kp.fov
+    back = O.undistort_points(pp, fr.model, 0, fr.rotations, points=np.array(pts, np.float32))
+    err = np.abs(back - np.array(want, np.float32))
+    assert err.max() < 0.06, err.max()
+    # and the branch really is taken: with lens_correction_amount = 1 the same points land elsewhere
+    pp.lens_correction_amount = 1.0
+    plain = O.undistort_points(pp, fr.model, 0, fr.rotations, points=np.array(pts, np.float32))
+    assert np.abs(plain - back).max() > 0.1
