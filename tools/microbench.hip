@@ -54,6 +54,12 @@ template <int OP> __global__ __launch_bounds__(256) void k(float *out, float a0,
             if (OP == 32) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(v[i]) : "s"(b), "v"(v[i]));
             if (OP == 33) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(v[i]) : "v"(v[i]), "s"(b), "v"(v[i]));
             if (OP == 34) asm volatile("v_add_u32 %0, %1, %2" : "=v"(v[i]) : "v"(v[i]), "v"(b));
+            if (OP == 36) asm volatile("v_mul_f32 %0, 2.0, %1" : "=v"(v[i]) : "v"(v[i]));
+            if (OP == 37) asm volatile("v_mul_f32 %0, 0x3f7fbe77, %1" : "=v"(v[i]) : "v"(v[i]));
+            if (OP == 38) asm volatile("v_add_f32 %0, 0x3a83126f, %1" : "=v"(v[i]) : "v"(v[i]));
+            if (OP == 39) asm volatile("v_add_f32 %0, %1, %2" : "=v"(v[i]) : "s"(b), "v"(v[i]));
+            if (OP == 40) asm volatile("v_fmac_f32 %0, 0x3f7fbe77, %1" : "+v"(v[i]) : "v"(b));
+            if (OP == 41) asm volatile("v_fmaak_f32 %0, %1, %2, 0x3e800000" : "=v"(v[i]) : "v"(v[i]), "v"(b));
             if (OP == 35) asm volatile("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(v[i]) : "v"(v[i]));
         }
     }
@@ -106,6 +112,12 @@ int main() {
         run<24>("v_fma_f32 neg mod (asm)", d, 1, 1.0f, 0.999f, bpc);
         run<33>("v_fma_f32 sgpr src (asm)", d, 1, 1.0f, 0.5f, bpc);
         run<32>("v_mul_f32 sgpr src", d, 1, 1.0f, 0.999f, bpc);
+        run<36>("v_mul_f32 inline const", d, 1, 1.0f, 0.999f, bpc);
+        run<37>("v_mul_f32 literal", d, 1, 1.0f, 0.999f, bpc);
+        run<38>("v_add_f32 literal", d, 1, 1.0f, 0.999f, bpc);
+        run<39>("v_add_f32 sgpr src", d, 1, 1.0f, 0.001f, bpc);
+        run<40>("v_fmac_f32 literal", d, 1, 1.0f, 0.001f, bpc);
+        run<41>("v_fmaak_f32", d, 1, 1.0f, 0.999f, bpc);
         run<25>("v_min_f32", d, 1, 1.5f, 1.0f, bpc);
         run<26>("v_sub_f32", d, 1, 1.5f, 0.001f, bpc);
         run<27>("v_cvt_f32_u32", d, 1, 1.5f, 1.0f, bpc);
