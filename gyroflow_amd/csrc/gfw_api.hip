@@ -7,6 +7,7 @@
 // runtime or a gfx950 device is missing every entry point fails with GFW_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cmath>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -554,7 +555,8 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
         if (bytes_per_sample != 4 && t1 == (bytes_per_sample == 1 ? GFW_PIX_UV8 : GFW_PIX_UV16)) { if (nplanes != 2) return false; interleaved = true; }
         else { for (int i = 1; i < nplanes; ++i) if (pixel_types[i] != t0) return false; }
     }
-    if (c->digital != GFW_MODEL_NONE && (p0.flags & GFW_FLAG_HAS_DIGITAL_LENS)) return false;
+    int extras = 0;
+    if (c->digital != GFW_MODEL_NONE && (p0.flags & GFW_FLAG_HAS_DIGITAL_LENS)) extras |= 2;
     if (c->model < GFW_MODEL_OPENCV_FISHEYE || c->model > GFW_MODEL_GOPRO) return false;
     // plane-invariant parameters must really be invariant, and inside the fused kernel's feature set
     for (int i = 0; i < nplanes; ++i) {
@@ -562,8 +564,10 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
         if ((p.interpolation != 2 && p.interpolation != 4 && p.interpolation != 8) || p.interpolation != p0.interpolation) return false;
         if (p.background_mode < 0 || p.background_mode > 2 || p.background_mode != p0.background_mode || p.input_rotation != 0.0f) return false;
         if (p.lens_correction_amount < 1.0f || !(p.lens_correction_amount == p.lens_correction_amount)) return false;
-        if (p.light_refraction_coefficient != 1.0f && p.light_refraction_coefficient > 0.0f) return false;
-        if (!(p.light_refraction_coefficient == p.light_refraction_coefficient)) return false;
+        if (!(p.light_refraction_coefficient == p.light_refraction_coefficient) || p.light_refraction_coefficient != p0.light_refraction_coefficient) return false;
+        if (p.light_refraction_coefficient != 1.0f && p.light_refraction_coefficient > 0.0f) extras |= 4;
+        if ((p.flags ^ p0.flags) & GFW_FLAG_HAS_DIGITAL_LENS) return false;
+        if (memcmp(p.digital_lens_params, p0.digital_lens_params, sizeof(p.digital_lens_params))) return false;
         if (p.flags & (GFW_FLAG_FIX_COLOR_RANGE | GFW_FLAG_FILL_WITH_BACKGROUND)) return false;
         if (p.translation3d[0] != 0.0f || p.translation3d[1] != 0.0f || p.translation3d[2] != 0.0f) return false;
         if (p.width != p0.width || p.height != p0.height || p.output_width != p0.output_width || p.output_height != p0.output_height) return false;
@@ -589,7 +593,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
         (p0.input_vertical_stretch > 0.001f && p0.input_vertical_stretch != 1.0f)) return false;
     if (!(p0.input_horizontal_stretch == p0.input_horizontal_stretch) || !(p0.input_vertical_stretch == p0.input_vertical_stretch)) return false;
     for (int i = 0; i < 12; ++i) { const float k = p0.k[i]; if (!(k == k) || fabsf(k) > 1024.0f) return false; }
-    if (!(p0.f[0] == p0.f[0]) || !(p0.f[1] == p0.f[1]) || !(p0.c[0] == p0.c[0]) || !(p0.c[1] == p0.c[1])) return false;
+    if (!std::isfinite(p0.f[0]) || !std::isfinite(p0.f[1]) || !std::isfinite(p0.c[0]) || !std::isfinite(p0.c[1])) return false;
     if (!(p0.translation2d[0] == p0.translation2d[0]) || !(p0.translation2d[1] == p0.translation2d[1])) return false;
     // luma plane is full resolution on both sides
     if (planes[0].input.width != p0.width || planes[0].input.height != p0.height) return false;
@@ -613,11 +617,15 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     // luma output pixel -> output space identity: x*ow/ow = x
     if (!int_products_exact(p0.output_width, p0.output_width) || !int_products_exact(p0.output_height, p0.output_height)) return false;
     if (p0.output_width >= (1 << 23) || p0.output_height >= (1 << 23)) return false;
-    // IBIS/OIS terms (matrices[9..13]) must be absent: host matrices are scanned, device matrices rely on the flag
+    // IBIS/OIS terms (matrices[9..13]): host matrices are scanned, device matrices rely on the flag; packed device rows
+    // carry the host-evaluated cos/sin of the roll, raw device rows[14] do not (gfw_repack_matrices_kernel)
     if (h_matrices) {
-        for (int r = 0; r < matrix_count; ++r) { const float *m = h_matrices + (size_t)r * 14;
-            if (m[9] != 0.0f || m[10] != 0.0f || m[11] != 0.0f || m[12] != 0.0f || m[13] != 0.0f) return false; }
-    } else if (p0.flags & GFW_FLAG_HAS_IBIS_DATA) return false;
+        for (int r = 0; r < matrix_count && !(extras & 1); ++r) { const float *m = h_matrices + (size_t)r * 14;
+            if (m[9] != 0.0f || m[10] != 0.0f || m[11] != 0.0f || m[12] != 0.0f || m[13] != 0.0f) extras |= 1; }
+    } else if (p0.flags & GFW_FLAG_HAS_IBIS_DATA) {
+        if (c->matrices_on_device != 2) return false;
+        extras |= 1;
+    }
     // source_rect map constants: u * pw / W  (cpu_undistort.rs:511-514 with frame_size = (width, height))
     const float Wf = (float)p0.width, Hf = (float)p0.height;
     if (!map_const_valid(Wf) || !map_const_valid(Hf)) return false;
@@ -639,6 +647,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     Y.hrs = (p0.flags & GFW_FLAG_HORIZONTAL_RS) ? 1 : 0;
     Y.background_mode = p0.background_mode;
     Y.model = c->model;
+    Y.extras = extras;
     Y.k_all_zero = (p0.k[0] == 0.0f && p0.k[1] == 0.0f && p0.k[2] == 0.0f && p0.k[3] == 0.0f) ? 1 : 0;
     Y.hstretch = p0.input_horizontal_stretch; Y.vstretch = p0.input_vertical_stretch;
     Y.hstretch_div = 0; Y.vstretch_div = 0;
@@ -654,7 +663,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     Y.kp = p0;
     Y.grid_limit = c->tune_grid > 0 ? c->tune_grid : c->num_cus * 6;
     Y.ablate = (c->kernel_variant >= 16) ? (c->kernel_variant - 16) : 0;      // timing ablations (results are wrong by design)
-    fast1 = p1_setup(c, p0, h_matrices, matrix_count, Y);
+    fast1 = extras ? false : p1_setup(c, p0, h_matrices, matrix_count, Y);
     const int rb = gfw_yuv_rows_per_lane(fast1, Y.audit ? 0 : c->tune_rb);
     Y.tiles_x = (Y.cw + 63) / 64; Y.tiles_y = (Y.ch + 4 * rb - 1) / (4 * rb);
     return true;

@@ -26,7 +26,8 @@
 //
 // Eligibility (decided on the host, gfw_api.hip build_yuv_args): bilinear / bicubic / Lanczos4 taps (this file is
 // compiled once per tap count and sample type), background_mode 0-2, no input rotation, lens_correction_amount >= 1,
-// no refraction / mesh / digital lens / IBIS terms / colour-range fix / fill flag, translation3d == 0, stretches in
+// no mesh / colour-range fix / fill flag, translation3d == 0 (refraction, digital lens and IBIS/OIS terms are served by
+// the generic-model instantiation with the exact first pass), stretches in
 // {<=0.001, 1}, full-plane rects; Luma8/Luma16 (+UV8/UV16) planes with chroma planes of identical geometry, one
 // packed RGB(A)8/16 / BGRA8 / AYUV16 / RGBAf plane, or planar R32f planes.
 #include <hip/hip_runtime.h>
@@ -103,10 +104,16 @@ struct Lens {
 struct Maps {                       // source_rect maps: u * mul / den  (den, rcp shared by luma and chroma)
     float mul_lx, mul_ly, mul_cx, mul_cy, den_x, rcp_x, den_y, rcp_y;
 };
+// INF_SAFE: an infinite coordinate must stay infinite (x*mul/den in IEEE; the reference then casts it to i32::MIN/MAX and
+// reads background), but the remainder step turns it into inf - inf = NaN; clamping the NaN remainder to a finite value
+// restores q0's infinity and changes nothing for finite or NaN inputs.  The specialised fisheye projection cannot produce
+// an infinite coordinate (a*s is bounded by theta_d), so only the generic-model instantiation pays for the guard.
+template <bool INF_SAFE>
 __device__ __forceinline__ float map_c(float x, float mul, float den, float rcp) {
     const float a = x * mul;
     const float q0 = a * rcp;
-    const float r0 = __builtin_fmaf(-den, q0, a);
+    float r0 = __builtin_fmaf(-den, q0, a);
+    if (INF_SAFE) r0 = fmaxf(r0, -3.4028234664e38f);
     return __builtin_fmaf(r0, rcp, q0);
 }
 
@@ -128,9 +135,9 @@ __device__ __forceinline__ void fisheye_project(float X, float Y, float W, const
 }
 
 // rotate_and_distort (cpu_undistort.rs:133-228) restricted to the eligible configuration
-// (no IBIS/mesh/digital/refraction, translation3d == 0).  ma/mb/m8 = the 9 matrix entries of the chosen row.
+// (no mesh, translation3d == 0; IBIS terms, digital lens and refraction only through the generic-model instantiation).  ma/mb/m8 = the 9 matrix entries of the chosen row.
 template <int MODEL>
-__device__ __forceinline__ GfwPt rd(float px, float py, const float4 ma, const float4 mb, const float m8, const Lens &L, const GfwYuvArgs &A) {
+__device__ __forceinline__ GfwPt rd(float px, float py, const float4 ma, const float4 mb, const float m8, const float *ext, const Lens &L, const GfwYuvArgs &A) {
     const float X = (px * ma.x) + (py * ma.y) + ma.z;
     const float Y = (px * ma.w) + (py * mb.x) + mb.y;
     const float W = (px * mb.z) + (py * mb.w) + m8;
@@ -145,10 +152,34 @@ __device__ __forceinline__ GfwPt rd(float px, float py, const float4 ma, const f
         if (__builtin_expect(lean, 1)) fisheye_project<LeanOps>(X, Y, W, L, A.k_all_zero != 0, o.x, o.y);
         else fisheye_project<IeeeOps>(X, Y, W, L, A.k_all_zero != 0, o.x, o.y);      // generic IEEE expansions
     } else {
+        // every lens model through the generic IEEE routines, plus the optional stages of rotate_and_distort in the
+        // reference's order: refraction (:143-152), model, *f, IBIS/OIS rotate + shift (:157-165), +c, digital lens (:216-220)
+        float Wd = W;
+        if ((A.extras & 4) && W != 0.0f) {
+            const float r = sqrtf(X * X + Y * Y) / W;
+            const float sin_theta_d = (r / sqrtf(1.0f + r * r)) * A.kp.light_refraction_coefficient;
+            const float r_d = sin_theta_d / sqrtf(1.0f - sin_theta_d * sin_theta_d);
+            if (r_d != 0.0f) Wd *= r / r_d;
+        }
         float du, dv;
-        gfw_lens::distort<MODEL>(A.model, X, Y, W, A.kp, A.common, du, dv);
-        o.x = du * L.f0 + L.c0;
-        o.y = dv * L.f1 + L.c1;
+        gfw_lens::distort<MODEL>(A.model, X, Y, Wd, A.kp, A.common, du, dv);
+        float u = du * L.f0, v = dv * L.f1;
+        if (A.extras & 1) {
+            const float m9 = ext[1], m10 = ext[2], m11 = ext[3], m12 = ext[4], m13 = ext[5];
+            if (m9 != 0.0f || m10 != 0.0f || m11 != 0.0f || m12 != 0.0f || m13 != 0.0f) {
+                const float cos_a = ext[6], sin_a = ext[7];               // cosf(-m11), sinf(-m11) from the host libm
+                const float nu = cos_a * u - sin_a * v - m9 + m12;
+                const float nv = sin_a * u + cos_a * v - m10 + m13;
+                u = nu; v = nv;
+            }
+        }
+        u = u + L.c0; v = v + L.c1;
+        if (A.extras & 2) {
+            float d0, d1;
+            gfw_lens::distort<-1>(A.common.digital, u, v, 1.0f, A.kp, A.common, d0, d1);
+            u = d0; v = d1;
+        }
+        o.x = u; o.y = v;
     }
     // input_{horizontal,vertical}_stretch (cpu_undistort.rs:222-223): only <= 0.001 (skipped) or 1.0 (x/1 == x) reach
     // this kernel; any other value is routed to the per-plane kernel by the host.
@@ -157,7 +188,7 @@ __device__ __forceinline__ GfwPt rd(float px, float py, const float4 ma, const f
 template <int MODEL>
 __device__ __forceinline__ GfwPt rd_row(float px, float py, int idx, const Lens &L, const GfwYuvArgs &A) {
     const float *m = A.matrices + (size_t)idx * GFW_MAT_STRIDE;
-    return rd<MODEL>(px, py, *reinterpret_cast<const float4 *>(m), *reinterpret_cast<const float4 *>(m + 4), m[8], L, A);
+    return rd<MODEL>(px, py, *reinterpret_cast<const float4 *>(m), *reinterpret_cast<const float4 *>(m + 4), m[8], m + 8, L, A);
 }
 
 // f32::round (half away from zero) then `as i32`: rndne is exact except on ties, which take the side branch.
@@ -467,7 +498,7 @@ __device__ __forceinline__ int default_row(float ox, float oy, const GfwYuvArgs 
 template <int MODEL>
 __device__ __forceinline__ int pass1_exact(float ox, float oy, const Mid &M, const Lens &L, const GfwYuvArgs &A) {
     int sy = default_row<MODEL>(ox, oy, A);
-    const GfwPt pt = rd<MODEL>(ox, oy, float4{M.m0, M.m1, M.m2, M.m3}, float4{M.m4, M.m5, M.m6, M.m7}, M.m8, L, A);
+    const GfwPt pt = rd<MODEL>(ox, oy, float4{M.m0, M.m1, M.m2, M.m3}, float4{M.m4, M.m5, M.m6, M.m7}, M.m8, A.matrices + (size_t)(A.matrix_count / 2) * GFW_MAT_STRIDE + 8, L, A);
     if (pt.ok) { const int lim = A.hrs ? A.width : A.height; sy = max(min(round_i32(A.hrs ? pt.x : pt.y), lim), 0); }
     return sy;
 }
@@ -585,7 +616,7 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
                             } else if (AUDIT) {                                       // audit: every certificate is checked
                                 atomicAdd(&A.audit[0], 1ull);
                                 if (pass1_exact<MODEL>(ox, oy, M, L, A) != sy) atomicAdd(&A.audit[1], 1ull);
-                                const GfwPt ex = rd<MODEL>(ox, oy, float4{M.m0, M.m1, M.m2, M.m3}, float4{M.m4, M.m5, M.m6, M.m7}, M.m8, L, A);
+                                const GfwPt ex = rd<MODEL>(ox, oy, float4{M.m0, M.m1, M.m2, M.m3}, float4{M.m4, M.m5, M.m6, M.m7}, M.m8, A.matrices + (size_t)(A.matrix_count / 2) * GFW_MAT_STRIDE + 8, L, A);
                                 if (ex.ok) atomicMax(&A.audit[4], (unsigned long long)gfw_f2u(fabsf((hrs ? ex.x : ex.y) - v_fast)));
                             }
                         } else {
@@ -645,13 +676,13 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
                         }
                     }
                     if (k == 0) { u0 = p.x; v0 = p.y; ok0 = p.ok; }
-                    const float lu = map_c(p.x, MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c(p.y, MP.mul_ly, MP.den_y, MP.rcp_y);   // cpu_undistort.rs:511-514
+                    const float lu = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(p.x, MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(p.y, MP.mul_ly, MP.den_y, MP.rcp_y);   // cpu_undistort.rs:511-514
                     if (A.ablate & 2) { if (lane == 99) A.pl[0].dst[0] = (uint8_t)(lu + lv); continue; }  // timing ablation only
                     if (I == 2) sample_store2<T, N0>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly);
                     else sample_store<T, N0, I>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly, s_lut);
                 }
                 if (A.nplanes > 1 && !(A.ablate & 4)) {
-                    const float cu = map_c(u0, MP.mul_cx, MP.den_x, MP.rcp_x), cv = map_c(v0, MP.mul_cy, MP.den_y, MP.rcp_y);
+                    const float cu = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(u0, MP.mul_cx, MP.den_x, MP.rcp_x), cv = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(v0, MP.mul_cy, MP.den_y, MP.rcp_y);
                     if (I == 2) {
                         if (INTERLEAVED_UV) sample_store2<T, 2>(cu, cv, ok0, A.pl[1], bg_c, lim_u, cx, cy);
                         else if (A.nplanes == 3) sample_store_uv2<T>(cu, cv, ok0, A.pl[1], A.pl[2], bg_c[0], bg_v, lim_u, lim_v, cx, cy);
@@ -732,6 +763,6 @@ static hipError_t launch_m(const GfwYuvArgs &A, int n0, int dw, int dh, bool int
 #define GFW_CAT(a, b) GFW_CAT2(a, b)
 #define GFW_FN GFW_CAT(GFW_CAT(gfw_launch_yuv_kind, GFW_FRAME_KIND), GFW_CAT(_taps, GFW_FRAME_TAPS))
 hipError_t GFW_FN(const GfwYuvArgs &A, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s) {
-    if (A.model == GFW_MODEL_OPENCV_FISHEYE) return launch_m<GFW_MODEL_OPENCV_FISHEYE>(A, n0, dw, dh, interleaved, fast1, s);
+    if (A.model == GFW_MODEL_OPENCV_FISHEYE && !A.extras) return launch_m<GFW_MODEL_OPENCV_FISHEYE>(A, n0, dw, dh, interleaved, fast1, s);
     return launch_m<-1>(A, n0, dw, dh, interleaved, false, s);
 }

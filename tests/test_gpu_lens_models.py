@@ -59,6 +59,8 @@ def test_digital_lenses(digital, lca):
                           base_overrides={"lens_correction_amount": lca, "digital_lens_params": DIGITAL[digital]})
     assert fr.planes[0]["params"].flags & abi.FLAG_HAS_DIGITAL_LENS
     run(fr)
+    if lca == 1.0:
+        assert warp.last_backend() == "yuv_fused"       # digital lenses run fused; the lens-correction blend does not
 
 
 def test_r_limit_and_stretch_and_input_rotation():
@@ -143,6 +145,9 @@ def test_ibis_ois_terms_in_matrices():
     fr.matrices[:, 13] = -0.4                           # oy
     ref = O.run_frame(fr)
     got = warp.run_frame(fr)
-    assert warp.last_backend() == "plane_generic"       # IBIS terms are outside the fused kernel's scope
-    for i, (a, b) in enumerate(zip(ref, got)):
-        assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "ibis plane %d" % i)
+    assert warp.last_backend() == "yuv_fused"           # served by the fused kernel's generic-model instantiation (exact first pass)
+    gen = warp.run_frame(fr, fused=False)
+    assert warp.last_backend() == "plane_generic"
+    for i, (a, b, g) in enumerate(zip(ref, got, gen)):
+        assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "ibis plane %d (fused)" % i)
+        assert_plane_equal(a, g, fr.planes[i]["pixel_type"], "ibis plane %d (generic)" % i)
