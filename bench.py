@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--profile-every", type=int, default=8,
                     help="bracket every N-th launch of the timed region with hipEvents for the roofline's kernel duration "
                          "(0 = none); the event pairs themselves cost GPU time between back-to-back kernels")
+    ap.add_argument("--digital", default="", help="digital lens on top of the physical one (gopro_superview, gopro_hyperview, ...): "
+                                                    "served by the fused kernel's generic-model instantiation")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--build-matrices", action="store_true",
@@ -90,7 +92,10 @@ def main():
     cquat = S.quat_from_euler_deg(5.0, 2.0, 3.0) if args.c1 else None
     fov = 0.82 if args.crop else args.fov
     ov = {"translation2d": (13.25, -7.5)} if args.crop else None
-    frames = [S.SyntheticFrame(args.fmt, W, H, seed=0x9F10 + rank * 1000 + i, timestamp_ms=1000.0 + 33.3 * (rank * 1000 + i),
+    lens = S.gopro_style_lens(W, H)
+    if args.digital:
+        lens["digital"] = args.digital
+    frames = [S.SyntheticFrame(args.fmt, W, H, seed=0x9F10 + rank * 1000 + i, timestamp_ms=1000.0 + 33.3 * (rank * 1000 + i), lens=dict(lens),
                                fov=fov, base_overrides=ov, interpolation=args.interp, readout_ms=readout, constant_quat=cquat)
               for i in range(N_DISTINCT)]
     nplanes = len(frames[0].planes)
