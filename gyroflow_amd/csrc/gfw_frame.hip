@@ -45,6 +45,9 @@
 #ifndef GFW_EXP_MIN
 #define GFW_EXP_MIN 1
 #endif
+#ifndef GFW_TAP_ROW_UNROLL
+#define GFW_TAP_ROW_UNROLL 2      // tap rows fetched together by the bicubic / Lanczos4 paths (registers vs loads in flight)
+#endif
 
 namespace {
 
@@ -211,22 +214,18 @@ __device__ __forceinline__ float min_limit(float v, float limit) {
 }
 
 // ---- LUT taps (cpu_undistort.rs:371-418): I = 2 bilinear, 4 bicubic, 8 Lanczos4 --------------------------------
-template <int I> struct Bins { int sx, sy; float cx[I], cy[I]; };
+// The I x-weights and I y-weights of a sample stay in the LDS copy of the table (32 phases x I floats per filter); a
+// Bins holds the two row pointers.  (Keeping 2*I weights per sample in registers cost the bicubic / Lanczos4 kernels
+// their occupancy: 148 VGPRs for I = 8.)
+template <int I> struct Bins { int sx, sy; const float *tx, *ty; };
 template <int I>
 __device__ __forceinline__ Bins<I> make_bins(float u, float v, const float *lut) {
     constexpr float OFFSET = (I == 2) ? 0.0f : (I == 4 ? 1.0f : 3.0f);       // :374
     const int sx0 = round_i32((u - OFFSET) * 32.0f), sy0 = round_i32((v - OFFSET) * 32.0f);
     Bins<I> b;
     b.sx = sx0 >> 5; b.sy = sy0 >> 5;
-    if (I == 2) {
-        b.cx[1] = (float)(sx0 & 31) * 0.03125f; b.cx[0] = 1.0f - b.cx[1];   // {1-k/32, k/32}: the LUT row (cpu_undistort.rs:14-19)
-        b.cy[1] = (float)(sy0 & 31) * 0.03125f; b.cy[0] = 1.0f - b.cy[1];
-    } else {
-        constexpr int IND = (I == 4) ? 64 : 192, SHIFT = (I >> 2) + 1;       // :373-375
-        const float *tx = lut + IND + ((sx0 & 31) << SHIFT), *ty = lut + IND + ((sy0 & 31) << SHIFT);
-        #pragma unroll
-        for (int i = 0; i < I; ++i) { b.cx[i] = tx[i]; b.cy[i] = ty[i]; }
-    }
+    constexpr int IND = (I == 2) ? 0 : (I == 4) ? 64 : 192, SHIFT = (I >> 2) + 1;       // :373-375
+    b.tx = lut + IND + ((sx0 & 31) << SHIFT); b.ty = lut + IND + ((sy0 & 31) << SHIFT);
     return b;
 }
 template <typename T> struct is_f32 { static constexpr bool value = false; };
@@ -238,26 +237,28 @@ __device__ __forceinline__ void taps_edge(const uint8_t *src, int stride, const 
     float sum[N];
     #pragma unroll
     for (int c = 0; c < N; ++c) sum[c] = 0.0f;
-    #pragma unroll          // (a rolled loop would index b.cy[] dynamically and push the whole Bins struct to scratch)
+    #pragma unroll 1        // the rare path: rolled, weights read from the table as they are needed
     for (int yp = 0; yp < I; ++yp) {
         const int yy = b.sy + yp;
+        const float wy = b.ty[yp];
         if (yy >= 0 && yy < h) {
             const T *row = reinterpret_cast<const T *>(src + (int64_t)yy * stride);
             float xs[N];
             #pragma unroll
             for (int c = 0; c < N; ++c) xs[c] = 0.0f;
-            #pragma unroll
+            #pragma unroll 1
             for (int xp = 0; xp < I; ++xp) {
                 const int xx = b.sx + xp;
                 const bool in = xx >= 0 && xx < w;
+                const float wx = b.tx[xp];
                 #pragma unroll
-                for (int c = 0; c < N; ++c) { const float px = in ? (float)row[(int64_t)xx * N + c] : bg[c]; xs[c] = xs[c] + px * b.cx[xp]; }
+                for (int c = 0; c < N; ++c) { const float px = in ? (float)row[(int64_t)xx * N + c] : bg[c]; xs[c] = xs[c] + px * wx; }
             }
             #pragma unroll
-            for (int c = 0; c < N; ++c) sum[c] = sum[c] + xs[c] * b.cy[yp];
+            for (int c = 0; c < N; ++c) sum[c] = sum[c] + xs[c] * wy;
         } else {
             #pragma unroll
-            for (int c = 0; c < N; ++c) sum[c] = sum[c] + bg[c] * b.cy[yp];
+            for (int c = 0; c < N; ++c) sum[c] = sum[c] + bg[c] * wy;
         }
     }
     #pragma unroll
@@ -268,15 +269,34 @@ __device__ __forceinline__ void taps_edge(const uint8_t *src, int stride, const 
 // pixels with -0 / negative values) they are kept so that signed zeros come out as the reference's.
 template <typename T, int N, int I>
 __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int stride, const Bins<I> &b, float limit, float *out) {
-    if (I == 2 && !is_f32<T>::value) {
-        const T *row0 = reinterpret_cast<const T *>(src + (int64_t)off0);
-        const T *row1 = reinterpret_cast<const T *>(src + (int64_t)(off0 + stride));
-        #pragma unroll
-        for (int c = 0; c < N; ++c) {
-            const float xs0 = (float)row0[c] * b.cx[0] + (float)row0[N + c] * b.cx[1];
-            const float xs1 = (float)row1[c] * b.cx[0] + (float)row1[N + c] * b.cx[1];
-            out[c] = fminf(xs0 * b.cy[0] + xs1 * b.cy[1], limit);
+    float cx[I];
+    #pragma unroll
+    for (int i = 0; i < I; ++i) cx[i] = b.tx[i];
+    if (N == 1 && !is_f32<T>::value && I > 2) {
+        // single-channel integer planes (Y, U, V): the I taps of a row are I*sizeof(T) contiguous bytes, fetched as dwords
+        // (two u16 / four u8 taps each) instead of element by element; same operation order as below
+        float s1 = 0.0f;
+        #pragma unroll GFW_TAP_ROW_UNROLL
+        for (int yp = 0; yp < I; ++yp) {
+            const uint8_t *rp = src + (int64_t)(off0 + yp * stride);
+            float xs = 0.0f;
+            #pragma unroll
+            for (int j = 0; j < (I * (int)sizeof(T)) / 4; ++j) {
+                uint32_t d;
+                __builtin_memcpy(&d, rp + 4 * j, 4);
+                if (sizeof(T) == 2) {
+                    xs = xs + (float)(d & 0xffffu) * cx[2 * j];
+                    xs = xs + (float)(d >> 16) * cx[2 * j + 1];
+                } else {
+                    xs = xs + (float)(d & 0xffu) * cx[4 * j];
+                    xs = xs + (float)((d >> 8) & 0xffu) * cx[4 * j + 1];
+                    xs = xs + (float)((d >> 16) & 0xffu) * cx[4 * j + 2];
+                    xs = xs + (float)(d >> 24) * cx[4 * j + 3];
+                }
+            }
+            s1 = s1 + xs * b.ty[yp];
         }
+        out[0] = fminf(s1, limit);
         return;
     }
     float sum[N];
@@ -291,10 +311,10 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
         #pragma unroll
         for (int xp = 0; xp < I; ++xp) {
             #pragma unroll
-            for (int c = 0; c < N; ++c) xs[c] = xs[c] + (float)row[xp * N + c] * b.cx[xp];
+            for (int c = 0; c < N; ++c) xs[c] = xs[c] + (float)row[xp * N + c] * cx[xp];
         }
         #pragma unroll
-        for (int c = 0; c < N; ++c) sum[c] = sum[c] + xs[c] * b.cy[yp];
+        for (int c = 0; c < N; ++c) sum[c] = sum[c] + xs[c] * b.ty[yp];
     }
     #pragma unroll
     for (int c = 0; c < N; ++c) out[c] = fminf(sum[c], limit);
@@ -333,9 +353,7 @@ template <typename T, int I>
 __device__ __forceinline__ void sample_store_shared(float u, float v, bool ok, const GfwYuvPlane *pl, int first, int last, int ox, int oy, const float *lut) {
     const GfwYuvPlane &P0 = pl[first];
     Bins<I> b;
-    b.sx = 0; b.sy = 0;
-    #pragma unroll
-    for (int i = 0; i < I; ++i) { b.cx[i] = 0.0f; b.cy[i] = 0.0f; }
+    b.sx = 0; b.sy = 0; b.tx = lut; b.ty = lut;
     bool inside = false;
     int off0 = 0;
     if (ok) {
