@@ -276,7 +276,7 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
         // single-channel integer planes (Y, U, V): the I taps of a row are I*sizeof(T) contiguous bytes, fetched as dwords
         // (two u16 / four u8 taps each) instead of element by element; same operation order as below
         float s1 = 0.0f;
-        #pragma unroll GFW_TAP_ROW_UNROLL
+        #pragma unroll (I >= 8 ? 1 : GFW_TAP_ROW_UNROLL)   // measured: Lanczos4 is fastest one row at a time (79 VGPRs), bicubic two
         for (int yp = 0; yp < I; ++yp) {
             const uint8_t *rp = src + (int64_t)(off0 + yp * stride);
             float xs = 0.0f;
