@@ -273,17 +273,27 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
     #pragma unroll
     for (int i = 0; i < I; ++i) cx[i] = b.tx[i];
     if (N == 1 && !is_f32<T>::value && I > 2) {
-        // single-channel integer planes (Y, U, V): the I taps of a row are I*sizeof(T) contiguous bytes, fetched as dwords
-        // (two u16 / four u8 taps each) instead of element by element; same operation order as below
+        // single-channel integer planes (Y, U, V): the I taps of a row are I*sizeof(T) contiguous bytes.  They are fetched as
+        // ALIGNED dwords and funnel-shifted into place: a row fetch whose address is not 4-byte aligned (every odd u16
+        // pixel) costs the texture-address unit 65 cycles instead of 18 (profiles/r01_membench_tap_row_fetch.txt), and that
+        // was what the Lanczos4 kernel waited for.  The extra dword is only read when the row is misaligned; the host-side
+        // `inside` test keeps TAP_MARGIN pixels clear of the row end so that it never leaves the plane.
         float s1 = 0.0f;
         #pragma unroll (I >= 8 ? 1 : GFW_TAP_ROW_UNROLL)   // measured: Lanczos4 is fastest one row at a time (79 VGPRs), bicubic two
         for (int yp = 0; yp < I; ++yp) {
             const uint8_t *rp = src + (int64_t)(off0 + yp * stride);
+            constexpr int ND = (I * (int)sizeof(T)) / 4;
+            const unsigned mis = (unsigned)(uintptr_t)rp & 3u;
+            const uint32_t *wp = reinterpret_cast<const uint32_t *>(rp - mis);
+            uint32_t w[ND + 1];
+            #pragma unroll
+            for (int j = 0; j < ND; ++j) w[j] = wp[j];
+            w[ND] = mis ? wp[ND] : 0u;
+            const unsigned sh = mis * 8u;
             float xs = 0.0f;
             #pragma unroll
-            for (int j = 0; j < (I * (int)sizeof(T)) / 4; ++j) {
-                uint32_t d;
-                __builtin_memcpy(&d, rp + 4 * j, 4);
+            for (int j = 0; j < ND; ++j) {
+                const uint32_t d = __builtin_amdgcn_alignbit(w[j + 1], w[j], sh);       // ({w[j+1], w[j]} >> sh)[31:0]
                 if (sizeof(T) == 2) {
                     xs = xs + (float)(d & 0xffffu) * cx[2 * j];
                     xs = xs + (float)(d >> 16) * cx[2 * j + 1];
@@ -319,9 +329,12 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
     #pragma unroll
     for (int c = 0; c < N; ++c) out[c] = fminf(sum[c], limit);
 }
-template <int I>
+// TAP_MARGIN: pixels kept clear of the row end by the aligned dword fetch of taps_inside (one dword may extend
+// 4/sizeof(T) - 1 pixels past the last tap); samples closer to the edge take the exact edge path.
+template <typename T, int N, int I>
 __device__ __forceinline__ bool bins_inside(const Bins<I> &b, int w, int h) {
-    return (unsigned)b.sx <= (unsigned)(w - I) && (unsigned)b.sy <= (unsigned)(h - I) && w >= I && h >= I;
+    constexpr int TAP_MARGIN = (N == 1 && !is_f32<T>::value && I > 2) ? (4 / (int)sizeof(T) - 1) : 0;
+    return w >= I + TAP_MARGIN && h >= I && (unsigned)b.sx <= (unsigned)(w - I - TAP_MARGIN) && (unsigned)b.sy <= (unsigned)(h - I);
 }
 template <typename T, int N>
 __device__ __forceinline__ void store_px(uint8_t *dst, int off, const float *v) {
@@ -340,7 +353,7 @@ __device__ __forceinline__ void sample_store(float u, float v, bool ok, const Gf
     for (int c = 0; c < N; ++c) out[c] = bg[c];
     if (ok) {
         const Bins<I> b = make_bins<I>(u, v, lut);
-        if (__builtin_expect(bins_inside<I>(b, P.w, P.h), 1))
+        if (__builtin_expect((bins_inside<T, N, I>(b, P.w, P.h)), 1))
             taps_inside<T, N, I>(P.src, b.sy * P.src_stride + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
         else
             taps_edge<T, N, I>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
@@ -358,7 +371,7 @@ __device__ __forceinline__ void sample_store_shared(float u, float v, bool ok, c
     int off0 = 0;
     if (ok) {
         b = make_bins<I>(u, v, lut);
-        inside = bins_inside<I>(b, P0.w, P0.h);
+        inside = bins_inside<T, 1, I>(b, P0.w, P0.h);
         off0 = b.sy * P0.src_stride + b.sx * (int)sizeof(T);
     }
     const int doff = oy * P0.dst_stride + ox * (int)sizeof(T);
