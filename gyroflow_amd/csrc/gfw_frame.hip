@@ -45,6 +45,9 @@
 #ifndef GFW_EXP_MIN
 #define GFW_EXP_MIN 1
 #endif
+#ifndef GFW_TAP_ROW_UNROLL8
+#define GFW_TAP_ROW_UNROLL8 1     // tap rows in flight in the Lanczos4 path (measured: 1 beats 2)
+#endif
 #ifndef GFW_TAP_ROW_UNROLL
 #define GFW_TAP_ROW_UNROLL 2      // tap rows fetched together by the bicubic / Lanczos4 paths (registers vs loads in flight)
 #endif
@@ -279,7 +282,7 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
         // was what the Lanczos4 kernel waited for.  The extra dword is only read when the row is misaligned; the host-side
         // `inside` test keeps TAP_MARGIN pixels clear of the row end so that it never leaves the plane.
         float s1 = 0.0f;
-        #pragma unroll (I >= 8 ? 1 : GFW_TAP_ROW_UNROLL)   // measured: Lanczos4 is fastest one row at a time (79 VGPRs), bicubic two
+        #pragma unroll (I >= 8 ? GFW_TAP_ROW_UNROLL8 : GFW_TAP_ROW_UNROLL)
         for (int yp = 0; yp < I; ++yp) {
             const uint8_t *rp = src + (int64_t)(off0 + yp * stride);
             constexpr int ND = (I * (int)sizeof(T)) / 4;
