@@ -281,18 +281,13 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
         // pixel) costs the texture-address unit 65 cycles instead of 18 (profiles/r01_membench_tap_row_fetch.txt), and that
         // was what the Lanczos4 kernel waited for.  The extra dword is only read when the row is misaligned; the host-side
         // `inside` test keeps TAP_MARGIN pixels clear of the row end so that it never leaves the plane.
+        constexpr int ND = (I * (int)sizeof(T)) / 4;
         float s1 = 0.0f;
-        #pragma unroll (I >= 8 ? GFW_TAP_ROW_UNROLL8 : GFW_TAP_ROW_UNROLL)
-        for (int yp = 0; yp < I; ++yp) {
-            const uint8_t *rp = src + (int64_t)(off0 + yp * stride);
-            constexpr int ND = (I * (int)sizeof(T)) / 4;
-            const unsigned mis = (unsigned)(uintptr_t)rp & 3u;
-            const uint32_t *wp = reinterpret_cast<const uint32_t *>(rp - mis);
+        auto row = [&](const uint32_t *wp, unsigned mis, unsigned sh, float wy) {
             uint32_t w[ND + 1];
             #pragma unroll
             for (int j = 0; j < ND; ++j) w[j] = wp[j];
             w[ND] = mis ? wp[ND] : 0u;
-            const unsigned sh = mis * 8u;
             float xs = 0.0f;
             #pragma unroll
             for (int j = 0; j < ND; ++j) {
@@ -307,7 +302,22 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
                     xs = xs + (float)(d >> 24) * cx[4 * j + 3];
                 }
             }
-            s1 = s1 + xs * b.ty[yp];
+            s1 = s1 + xs * wy;
+        };
+        if ((stride & 3) == 0) {
+            // the usual case (row pitch a multiple of 4 bytes): the misalignment is the same for every tap row of the sample
+            const uint8_t *rp0 = src + (int64_t)off0;
+            const unsigned mis = (unsigned)(uintptr_t)rp0 & 3u, sh = mis * 8u;
+            const uint8_t *ap = rp0 - mis;
+            #pragma unroll (I >= 8 ? GFW_TAP_ROW_UNROLL8 : GFW_TAP_ROW_UNROLL)
+            for (int yp = 0; yp < I; ++yp) row(reinterpret_cast<const uint32_t *>(ap + (int64_t)yp * stride), mis, sh, b.ty[yp]);
+        } else {
+            #pragma unroll 1
+            for (int yp = 0; yp < I; ++yp) {
+                const uint8_t *rp = src + (int64_t)(off0 + yp * stride);
+                const unsigned mis = (unsigned)(uintptr_t)rp & 3u;
+                row(reinterpret_cast<const uint32_t *>(rp - mis), mis, mis * 8u, b.ty[yp]);
+            }
         }
         out[0] = fminf(s1, limit);
         return;
