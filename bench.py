@@ -1,49 +1,66 @@
 #!/usr/bin/env python3
 """bench.py — Mpix/s of the gfwarp hot path on N MI355X (one process per GPU).
 
-A "step" is one pass of the hot path over one synthetic frame: all planes of a 4K (3840x2160) u16 4:2:2
-frame (BASELINE.json configs[1], "C2": planar YUV422P16LE = 3 x Luma16, GoPro-style opencv_fisheye lens,
-per-row rolling-shutter matrices) warped through libgfwarp's C ABI from buffers already resident in HBM.
-Frames shard across ranks (weak scaling: every rank warps its own K frames; no pixel crosses GPUs); the
-only collectives are a barrier and two tiny reductions (time max, checksum sum) over RCCL.
+    python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task statement), with
-  roofline     — algorithmic HBM bytes/launch (sum over planes of w*h*bpp read + written)
-                 over the kernel's mean launch duration, measured with hipEvents on the launch stream
-                 (GFW_OPT_PROFILE) during the timed region, against the 8 TB/s HBM3E peak;
-  cpu_baseline — the oracle (C restatement of the reference CPU path, OpenMP over all host cores) on a
-                 bounded sample of the same frames, rank 0 at N=1 only.
+A "step" is one pass of the hot path over one synthetic frame: all planes of a 4K (3840x2160) u16 4:2:2 frame
+(BASELINE.json configs[1], "C2": planar YUV422P16LE = 3 x Luma16, GoPro-style opencv_fisheye lens, per-row
+rolling-shutter matrices) warped through libgfwarp's C ABI from buffers already resident in HBM.
+
+Process model.  Started plainly, this file is a *launcher*: it spawns one worker process per GPU (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment, rendezvous on 127.0.0.1), relays rank 0's JSON line and exits with the
+workers' status; a worker set that dies abnormally is re-run (at most twice more) and the line says so under
+`launcher`.  Started by `torch.distributed.run` (RANK already in the environment) it is a worker itself.  N >= 2 ranks
+talk over RCCL (`nccl` backend); frames shard across ranks and no pixel ever crosses GPUs — the only collectives are a
+broadcast of the clip-invariant block, a barrier either side of the timed region, a MAX of the elapsed time and an
+all-gather of output checksums.
+
+Modes: default = weak scaling (every rank warps its own K frames of C2); `--c5` = BASELINE.json configs[4]: a
+10 000-frame clip whose frames are dealt round-robin to the ranks (strong scaling), each frame's per-row matrices built
+on the device from the clip's quaternion tracks, a 64-bit checksum per frame all-gathered at the end.
+
+Prints ONE JSON line (rank 0) with
+  roofline     — algorithmic HBM bytes/launch (sum over planes of w*h*bpp read + written) over the
+                 kernel's mean launch duration, measured with hipEvents on the launch stream (GFW_OPT_PROFILE) during
+                 the timed region, against the 8 TB/s HBM3E peak;
+  cpu_baseline — the oracle (C restatement of the reference CPU path, OpenMP over the host cores) timed on the same
+                 frames, rank 0 at N=1 only;
+  config.parity_vs_oracle — outputs of the LAST frames of the timed region itself, compared with the oracle.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
-from gyroflow_amd import abi, shard, synthetic as S, warp
-
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FMT, WIDTH, HEIGHT = "YUV422P16LE", 3840, 2160
-N_DISTINCT = 4                   # host-generated source frames (the oracle's parity spot check runs on these)
 N_RESIDENT = 64                  # distinct source frames + per-row matrix tables resident in HBM, cycled by the steps
-                                 # (SURVEY.md 8d "64 distinct resident source frames cycled": 4.2 GB, far beyond L2 + MALL)
+                                 # (SURVEY.md 8d "64 distinct resident source frames cycled": 2.1 GB, far beyond L2 + MALL)
 N_DST = 4                        # destination frame sets written round-robin
+N_CHECK = 3                      # frames of the timed region compared with the oracle afterwards
+TRAFFIC_FILE = os.path.join("profiles", "r02_c2_traffic.json")
 
 
-def main():
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N >= 2 (nccl = RCCL; gloo for the 1-GPU test of the N-rank path)")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (testing the N-rank path on a 1-GPU box; with --backend gloo)")
+    ap.add_argument("--no-retry", action="store_true", help="launcher: do not re-run a worker set that died")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the last timed frames")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--fmt", default=FMT)
@@ -53,38 +70,137 @@ def main():
     ap.add_argument("--resident", type=int, default=N_RESIDENT, help="distinct source frames / matrix tables kept in HBM and cycled")
     ap.add_argument("--c1", action="store_true", help="C1: 1920x1080 NV12 (u8), one constant quaternion, matrix_count = 1 "
                                                       "(BASELINE.json configs[0], the reference's own CPU-runnable case)")
+    ap.add_argument("--c5", action="store_true", help="C5: a --frames long 4K clip dealt round-robin to the ranks (strong scaling); per-row "
+                                                      "matrices built on the device per frame; per-frame checksums all-gathered")
+    ap.add_argument("--frames", type=int, default=10000, help="--c5: frames in the clip")
     ap.add_argument("--host-buffers", action="store_true",
                     help="PCIe-inclusive run: source and destination planes live in host memory (BufferSource::Cpu), every "
                          "call stages H2D, warps, copies D2H and synchronises — never the headline value")
     ap.add_argument("--profile-every", type=int, default=8,
                     help="bracket every N-th launch of the timed region with hipEvents for the roofline's kernel duration "
                          "(0 = none); the event pairs themselves cost GPU time between back-to-back kernels")
-    ap.add_argument("--digital", default="", help="digital lens on top of the physical one (gopro_superview, gopro_hyperview, ...): "
-                                                    "served by the fused kernel's generic-model instantiation")
+    ap.add_argument("--digital", default="", help="digital lens on top of the physical one (gopro_superview, gopro_hyperview, ...)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--build-matrices", action="store_true",
                     help="build every frame's per-row matrices on the device from quaternion tracks (gfw_build_matrices, "
                          "the 'next' row f-1) inside the timed region instead of using pre-packed resident tables")
-    ap.add_argument("--build-batch", type=int, default=16, help="with --build-matrices: frames per gfw_build_matrices_batch call (1 = one "
-                                                                 "gfw_build_matrices per frame on the auxiliary stream)")
+    ap.add_argument("--build-batch", type=int, default=16, help="frames per gfw_build_matrices_batch call (1 = one gfw_build_matrices per frame "
+                                                                 "on the auxiliary stream)")
     ap.add_argument("--upload-matrices", action="store_true",
                     help="upload the per-row matrices from host memory every frame (the reference's OpenCL backend does, "
                          "opencl.rs:406) instead of keeping the pre-packed tables of the clip resident in HBM")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------- launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launcher(args, argv):
+    """Spawn one worker per GPU, relay rank 0's JSON line.  A worker set that dies abnormally (GPU fault, signal) is
+    re-run — at most three attempts in all — and every failed attempt is reported in the line (`launcher.failures`)."""
+    n = max(1, args.gpus)
+    failures = []
+    attempts = 1 if args.no_retry else 3
+    for attempt in range(1, attempts + 1):
+        env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs, logs = [], []
+        for r in range(n):
+            e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+            logs.append((tempfile.TemporaryFile(mode="w+"), tempfile.TemporaryFile(mode="w+")))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ["--worker"], env=e,
+                                          stdout=logs[r][0], stderr=logs[r][1], text=True))
+        # wait for all; if one rank dies the others would wait on a collective for ever: give them 10 s, then kill them
+        dead_since = None
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                dead_since = dead_since or time.time()
+                if time.time() - dead_since > 10.0:
+                    for p in procs:
+                        if p.poll() is None:
+                            p.kill()
+            time.sleep(0.05)
+        rcs = [p.returncode for p in procs]
+        outs, errs = [], []
+        for fo, fe in logs:
+            fo.seek(0); fe.seek(0)
+            outs.append(fo.read()); errs.append(fe.read())
+            fo.close(); fe.close()
+        out0 = outs[0]
+        line = None
+        for ln in (out0 or "").splitlines():
+            if ln.startswith("{") and ln.rstrip().endswith("}"):
+                line = ln
+        if all(rc == 0 for rc in rcs) and line is not None:
+            out = json.loads(line)
+            out["launcher"] = {"ranks_spawned": n, "attempts": attempt, "failures": failures}
+            for e in errs:
+                if e:
+                    sys.stderr.write(e)
+            print(json.dumps(out), flush=True)
+            return 0
+        tail = " | ".join((e or "").strip().splitlines()[-1] if (e or "").strip() else "" for e in errs)
+        failures.append({"attempt": attempt, "rcs": rcs, "stderr_tail": tail[-400:]})
+        sys.stderr.write("[bench] attempt %d failed (rcs %s)\n" % (attempt, rcs))
+        for e in errs:
+            if e:
+                sys.stderr.write(e)
+        # only an abnormal death (signal, abort: GPU memory fault, runtime crash) is worth another attempt; an error the
+        # worker reported itself (exit status 1..127) would only repeat
+        if not any(rc < 0 or rc >= 128 for rc in rcs):
+            break
+    return 1
+
+
+# ---------------------------------------------------------------------------------------------- worker
+class _FrameView:
+    """What tests/_oracle.run_frame needs of a frame, with the pixels downloaded from the device."""
+
+    def __init__(self, frame, src_planes, matrices):
+        import numpy as np
+        self.model, self.digital, self.matrices = frame.model, frame.digital, matrices
+        self.planes = []
+        for pl, src in zip(frame.planes, src_planes):
+            q = dict(pl)
+            q["src"] = src
+            q["dst"] = np.full(pl["out_size"][2] * pl["out_size"][1], 0x5A, dtype=np.uint8)
+            self.planes.append(q)
+
+
+def worker(args):
+    import numpy as np
+    import torch
+    from gyroflow_amd import abi, shard, synthetic as S, warp
 
     rank, local_rank, world = shard.env_rank()
+    if world != max(1, args.gpus):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libgfwarp has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = shard.init("nccl", rank, world, dev)
+    dev_index = 0 if args.same_device else local_rank
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants cuda:%d but only %d device(s) are visible" % (rank, dev_index, torch.cuda.device_count()))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    dist = shard.init(args.backend, rank, world, dev)
+    if dist is not None:
+        assert dist.get_world_size() == world, (dist.get_world_size(), world)
+    cdev = dev if args.backend == "nccl" else "cpu"      # where the tiny control tensors of the collectives live
 
     lib = abi.load_library()
-    if lib.gfw_set_device(local_rank) != 0:
+    if lib.gfw_set_device(dev_index) != 0:
         raise SystemExit("gfw_set_device failed: %s" % lib.gfw_last_error().decode())
+    info = C.create_string_buffer(512)
+    lib.gfw_get_info(info, 512)
 
-    # ---- synthetic clip, resident in HBM ------------------------------------------------------------
+    # ---- synthetic clip, produced directly in HBM ---------------------------------------------------------
     if args.c1:
         args.width, args.height, args.fmt = 1920, 1080, "NV12"
     W, H = args.width, args.height
@@ -95,22 +211,35 @@ def main():
     lens = S.gopro_style_lens(W, H)
     if args.digital:
         lens["digital"] = args.digital
-    frames = [S.SyntheticFrame(args.fmt, W, H, seed=0x9F10 + rank * 1000 + i, timestamp_ms=1000.0 + 33.3 * (rank * 1000 + i), lens=dict(lens),
-                               fov=fov, base_overrides=ov, interpolation=args.interp, readout_ms=readout, constant_quat=cquat)
-              for i in range(N_DISTINCT)]
+    NR = 4 if args.host_buffers else max(1, args.resident)
+    device_built = args.build_matrices or args.c5
+    # frame j of this rank: seed and timestamp of its own (seed = 0x9F10 + frame index); the C5 clip's
+    # resident source frames are the clip's, the same on every rank
+    seed_base = 0 if args.c5 else rank * 1000
+    frames = [S.SyntheticFrame(args.fmt, W, H, seed=0x9F10 + seed_base + j, timestamp_ms=1000.0 + 33.3 * (seed_base + j), lens=dict(lens),
+                               fov=fov, base_overrides=ov, interpolation=args.interp, readout_ms=readout,
+                               constant_quat=cquat, pixels=args.host_buffers)
+              for j in range(NR)]
     nplanes = len(frames[0].planes)
-    NR = N_DISTINCT if args.host_buffers else max(N_DISTINCT, args.resident)
-    base_src = [[torch.from_numpy(pl["src"]).to(dev) for pl in fr.planes] for fr in frames]
-    # resident set j < 4 is host frame j itself; the others are byte-rotated copies (distinct content, same statistics)
-    d_src = [[base_src[j % N_DISTINCT][p] if j < N_DISTINCT else torch.roll(base_src[j % N_DISTINCT][p], 4098 * j)
-              for p in range(nplanes)] for j in range(NR)]
-    # destinations start from the same fill pattern as the host copies: stride padding is never written by the warp
-    d_dst = [[torch.from_numpy(pl["dst"]).to(dev) for pl in frames[0].planes] for _ in range(N_DST)]
     types = [pl["pixel_type"] for pl in frames[0].planes]
+    if args.host_buffers:
+        d_src = None
+        h_dst = [[pl["dst"].copy() for pl in frames[0].planes] for _ in range(N_DST)]
+    else:
+        d_src = [fr.device_planes(dev) for fr in frames]
+        h_dst = None
+    # destination sets: one contiguous allocation each (plane p at a 256-byte aligned offset), pre-filled like the host
+    # copies — stride padding is never written by the warp
+    sizes = [pl["out_size"][2] * pl["out_size"][1] for pl in frames[0].planes]
+    offs = [0]
+    for s in sizes:
+        offs.append(S.align(offs[-1] + s, 256))
+    dst_total = S.align(offs[-1], 256)
+    d_dstbuf = [torch.full((dst_total,), 0x5A, dtype=torch.uint8, device=dev) for _ in range(N_DST)]
+    d_dst = [[d_dstbuf[d][offs[p]:offs[p] + sizes[p]] for p in range(nplanes)] for d in range(N_DST)]
     bufsets = []                                      # bufsets[j * N_DST + d]: source set j -> destination set d
-    h_dst = [[pl["dst"].copy() for pl in frames[0].planes] for _ in range(N_DST)]
     for j in range(NR):
-        fr = frames[j % N_DISTINCT]
+        fr = frames[j]
         for d in range(N_DST):
             if args.host_buffers:
                 bufsets.append([warp.host_buffers(pl["src"], pl["size"], h_dst[d][p], pl["out_size"]) for p, pl in enumerate(fr.planes)])
@@ -119,11 +248,10 @@ def main():
                                                 d_dst[d][p].data_ptr(), d_dst[d][p].numel(), pl["out_size"])
                             for p, pl in enumerate(fr.planes)])
     # clip-invariant block (lens + per-plane KernelParams template): rank 0's copy is the one every rank uses
-    blob = shard.broadcast_bytes(dist, b"".join(bytes(pl["params"]) for pl in frames[0].planes), dev)
+    blob = shard.broadcast_bytes(dist, b"".join(bytes(pl["params"]) for pl in frames[0].planes), cdev)
     ksz = C.sizeof(abi.KernelParams)
     tmpl = [abi.KernelParams.from_buffer_copy(blob[k * ksz:(k + 1) * ksz]) for k in range(nplanes)]
-    params = [tmpl for _ in frames]
-    be = warp.Backend(params[0][0], types[0], frames[0].model, frames[0].digital, bufsets[0][0])
+    be = warp.Backend(tmpl[0], types[0], frames[0].model, frames[0].digital, bufsets[0][0])
     stream = torch.cuda.current_stream(dev)
     be.set_stream(stream.cuda_stream)
     be.set_option(abi.OPT_SYNCHRONOUS, 1 if args.host_buffers else 0)
@@ -131,68 +259,95 @@ def main():
         be.set_option(abi.OPT_KERNEL_VARIANT, args.variant)
     if args.grid:
         be.set_option(abi.OPT_TUNE_GRID, args.grid)
-
     rows_n = frames[0].matrices.shape[0]
+    nk = S.new_k(frames[0].lens, fov, W, H)
 
-    def matrix_sets():
-        """One per-row matrix table per resident frame: its own timestamp on the synthetic camera track."""
-        sets = [fr.matrices for fr in frames]
-        for j in range(N_DISTINCT, NR):
-            sets.append(S.row_matrices(frames[0].lens, fov, (W, H), (W, H), 1000.0 + 33.3 * (rank * 1000 + j), readout,
-                                       0x9F10 + rank * 1000 + j, constant_quat=cquat))
-        return sets
+    def timing_for(ts_ms, t=None):
+        t = t or abi.FrameTiming()
+        t.timestamp_ms, t.frame_readout_time_ms, t.rows, t.readout_dim = ts_ms, readout, rows_n, H
+        for i, v in enumerate(np.asarray(nk, dtype=np.float64).reshape(9)):
+            t.new_k[i] = v
+        return t
 
-    if args.build_matrices:
-        org = S.sampled_track(11 + rank, 0.0, 1000.0 + 33.4 * (args.steps + args.warmup + 2), 1000.0)
-        smo = S.sampled_track(12 + rank, 0.0, 1000.0 + 33.4 * (args.steps + args.warmup + 2), 200.0, scale=0.25)
+    BATCH = max(1, min(64, args.build_batch if not args.c5 else max(args.build_batch, 32)))
+    if args.c5:
+        total = max(1, args.frames)
+        own = list(shard.frames_for_rank(rank, world, total))           # global frame indices of this rank, in order
+        n_steps, n_warm = len(own), min(args.warmup, len(own))
+    else:
+        total, own = None, None
+        n_steps, n_warm = args.steps, args.warmup
+
+    def ts_of(f):                                      # clip time of global frame f (30 fps)
+        return 1000.0 + 33.3 * f
+
+    if device_built:
+        t_end = ts_of((total if args.c5 else (n_steps + n_warm + BATCH + 2)) + 2) + 100.0
+        org = S.sampled_track_fast(11, 0.0, t_end, 500.0)             # the clip's tracks: identical on every rank
+        smo = S.sampled_track_fast(12, 0.0, t_end, 100.0, scale=0.25)
         be.set_quaternion_tracks(org, smo)
         be.set_option(abi.OPT_MATRICES_ON_DEVICE, 2)
-        nk = S.new_k(frames[0].lens, fov, W, H)
-        table = be.build_matrices(nk, 1000.0, 16.0, H, H)          # context-owned table: same pointer every frame
+        table0 = be.build_matrices(nk, 1000.0, readout, rows_n, H)     # context-owned table: a valid pointer for the pre-marshalled calls
         be.synchronize()
-        calls = [warp.FrameCall(be, bufsets[j * N_DST + (j % N_DST)], params[j % N_DISTINCT], types, table, H) for j in range(NR)]
-        timing = abi.FrameTiming()
-        timing.frame_readout_time_ms, timing.rows, timing.readout_dim = 16.0, H, H
-        for i, v in enumerate(np.asarray(nk, dtype=np.float64).reshape(9)):
-            timing.new_k[i] = v
-        build_fn, ctxp, tref = be.lib.gfw_build_matrices, be.ctx, C.byref(timing)
-        tbl = C.c_void_p(0)
-        tblref = C.byref(tbl)
-        BATCH = args.build_batch
-        timings = (abi.FrameTiming * max(BATCH, 1))()
+        calls = [warp.FrameCall(be, bufsets[i], tmpl, types, table0, rows_n) for i in range(NR * N_DST)]
+        timings = (abi.FrameTiming * BATCH)()
         for t in timings:
-            t.frame_readout_time_ms, t.rows, t.readout_dim = 16.0, H, H
-            for i, v in enumerate(np.asarray(nk, dtype=np.float64).reshape(9)):
-                t.new_k[i] = v
-        tptrs = (C.c_void_p * max(BATCH, 1))()
-        batch_fn = be.lib.gfw_build_matrices_batch
+            timing_for(0.0, t)
+        tptrs = (C.c_void_p * BATCH)()
+        batch_fn, ctxp = be.lib.gfw_build_matrices_batch, be.ctx
+        one = timing_for(0.0)
+        one_ref, tbl = C.byref(one), C.c_void_p(0)
+        build_fn, tblref = be.lib.gfw_build_matrices, C.byref(tbl)
     elif args.upload_matrices:
-        mats = matrix_sets()
-        calls = [warp.FrameCall(be, bufsets[j * N_DST + (j % N_DST)], params[j % N_DISTINCT], types, mats[j]) for j in range(NR)]
+        calls = [warp.FrameCall(be, bufsets[j * N_DST + (j % N_DST)], tmpl, types, frames[j].matrices) for j in range(NR)]
     else:
-        d_mat = [torch.from_numpy(warp.pack_matrices(m)).to(dev) for m in matrix_sets()]
+        d_mat = [torch.from_numpy(warp.pack_matrices(fr.matrices)).to(dev) for fr in frames]
         be.set_option(abi.OPT_MATRICES_ON_DEVICE, 2)
-        calls = [warp.FrameCall(be, bufsets[j * N_DST + (j % N_DST)], params[j % N_DISTINCT], types, d_mat[j].data_ptr(), rows_n) for j in range(NR)]
+        calls = [warp.FrameCall(be, bufsets[j * N_DST + (j % N_DST)], tmpl, types, d_mat[j].data_ptr(), rows_n) for j in range(NR)]
+
+    # what step k of this rank reads and writes: (global frame, source set, destination set)
+    def plan(k):
+        f = own[k] if args.c5 else k
+        j = f % NR
+        return f, j, ((k if device_built else j) % N_DST)
+
+    if args.c5:
+        d_sums = torch.zeros(max(1, n_steps), dtype=torch.int64, device=dev)
+        sum_fn, sum_base = be.lib.gfw_checksum64, d_sums.data_ptr()
+        dst_ptrs = [b.data_ptr() for b in d_dstbuf]
 
     def step(k):
-        call = calls[k % NR]
-        if args.build_matrices and BATCH > 1:
-            # every BATCH frames: one launch builds the tables of the next BATCH frames, in order on the warp's stream
-            if k % BATCH == 0:
-                for i in range(BATCH):
-                    timings[i].timestamp_ms = 1000.0 + 33.3 * (k + i)
-                batch_fn(ctxp, timings, BATCH, tptrs)
-            call.mp = tptrs[k % BATCH]
-        elif args.build_matrices:
-            # the context builds this frame's table on its auxiliary stream (ring of tables) while the previous frame warps
-            timing.timestamp_ms = 1000.0 + 33.3 * k
-            build_fn(ctxp, tref, None, tblref)
-            call.mp = tbl.value
-        call()
+        f, j, d = plan(k)
+        if device_built:
+            call = calls[j * N_DST + d]
+            if BATCH > 1:
+                # every BATCH steps one launch builds the tables of the next BATCH frames, in order on the warp's stream
+                if k % BATCH == 0:
+                    for i in range(BATCH):
+                        kk = min(k + i, n_steps - 1)
+                        timings[i].timestamp_ms = ts_of(own[kk] if args.c5 else kk)
+                    rc = batch_fn(ctxp, timings, BATCH, tptrs)
+                    if rc != 0:
+                        be._check(rc)
+                call.mp = tptrs[k % BATCH]
+            else:
+                # the context builds this frame's table on its auxiliary stream (ring of tables) while the previous frame warps
+                one.timestamp_ms = ts_of(f)
+                rc = build_fn(ctxp, one_ref, None, tblref)
+                if rc != 0:
+                    be._check(rc)
+                call.mp = tbl.value
+            call()
+            if args.c5:
+                sum_fn(ctxp, dst_ptrs[d], dst_total, sum_base + 8 * k)           # the frame's checksum, in order on the same stream
+        else:
+            calls[j]()
 
-    for k in range(args.warmup):
+    for k in range(n_warm):
         step(k)
     torch.cuda.synchronize(dev)
+    if args.c5:
+        d_sums.zero_()                                # gfw_checksum64 accumulates
     pe = args.profile_every
     be.set_option(abi.OPT_PROFILE, 1 if pe == 1 else 0)
     be.get_profile(reset=True)
@@ -201,7 +356,7 @@ def main():
     t0 = time.perf_counter()
     if pe > 1:
         set_opt, ctxp2 = be.lib.gfw_set_option, be.ctx
-        for k in range(args.steps):
+        for k in range(n_steps):
             if k % pe == 0:
                 set_opt(ctxp2, abi.OPT_PROFILE, 1)
                 step(k)
@@ -209,86 +364,141 @@ def main():
             else:
                 step(k)
     else:
-        for k in range(args.steps):
+        for k in range(n_steps):
             step(k)
-    t_enq = time.perf_counter() - t0                 # host time to enqueue the K steps (GPU runs behind it)
+    t_enq = time.perf_counter() - t0                 # host time to enqueue the steps (the GPU runs behind it)
     torch.cuda.synchronize(dev)
     shard.barrier(dist)
     t1 = time.perf_counter()
     elapsed = t1 - t0
     kernel_ms, launches = be.get_profile(reset=True)
     be.set_option(abi.OPT_PROFILE, 0)
+    elapsed = shard.reduce_max(dist, elapsed, cdev)
 
-    # checksum of the last frame's planes (checksum of checksums across ranks)
-    crc = 0
-    last = ((args.steps - 1) % NR) % N_DST
-    for p in range(nplanes):
-        crc = zlib.crc32(h_dst[last][p].tobytes() if args.host_buffers else d_dst[last][p].cpu().numpy().tobytes(), crc)
-    elapsed = shard.reduce_max(dist, elapsed, dev)
-    rank_crcs = [g[0] for g in shard.gather_checksums(dist, [crc], dev)]
-    crc = shard.reduce_checksum(dist, crc, dev)
+    def dst_host(d, p):
+        return h_dst[d][p] if args.host_buffers else d_dst[d][p].cpu().numpy()
+
+    # ---- checksums ------------------------------------------------------------------------------------------
+    if args.c5:
+        mine = d_sums[:n_steps].cpu().numpy().astype(np.int64)
+        frame_sums, gathered = shard.assemble_frame_checksums(dist, [int(v) for v in mine], rank, world, total, cdev)
+        frame_sums = np.asarray(frame_sums, dtype=np.int64)
+        crc = zlib.crc32(frame_sums.tobytes())
+        rank_crcs = [zlib.crc32(np.asarray(g, dtype=np.int64).tobytes()) for g in gathered]
+    else:
+        crc = 0
+        last = plan(n_steps - 1)[2]
+        for p in range(nplanes):
+            crc = zlib.crc32(dst_host(last, p).tobytes(), crc)
+        rank_crcs = [g[0] for g in shard.gather_checksums(dist, [crc], cdev)]
+        crc = shard.reduce_checksum(dist, crc, cdev)
 
     luma_px = frames[0].luma_pixels()
     alg_bytes = frames[0].algorithmic_bytes()
-    value = luma_px * args.steps * world / elapsed / 1e6
+    frames_done = total if args.c5 else n_steps * world
+    value = luma_px * frames_done / elapsed / 1e6
+    cfg_name = ("C5" if args.c5 else "C1" if args.c1 else "C2" if (W, H, args.fmt, args.crop) == (3840, 2160, FMT, False) else
+                "C3" if (W, H, args.fmt) == (7680, 4320, FMT) else "C4" if args.crop else "custom")
+    how = (" — HOST buffers: H2D + warp + D2H + sync per frame (PCIe-inclusive)" if args.host_buffers else
+           " (matrices re-uploaded per frame)" if args.upload_matrices else
+           " (per-row matrices built on the device every frame from quaternion tracks, %d frames per build launch)" % BATCH if device_built else "")
+    workload = "%s: %dx%d %s, opencv_fisheye GoPro-style lens, rolling shutter matrix_count=%d, %s, %d distinct source frames%s resident in HBM%s" % (
+        cfg_name, W, H, args.fmt, rows_n, {2: "bilinear", 4: "bicubic", 8: "Lanczos4"}.get(args.interp, str(args.interp)), NR,
+        "" if device_built else " + per-row matrix tables", how)
+    if args.c5:
+        workload += "; %d-frame clip dealt round-robin to %d rank(s), one 64-bit checksum per frame" % (total, world)
     out = {
         "metric": "Mpix/s (4K u16 YUV, rolling-shutter warp)" if not args.c1 else "Mpix/s (1080p u8 NV12 warp)",
-        "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+        "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": n_steps, "warmup": n_warm,
+        "ms_per_step": round(elapsed / max(n_steps, 1) * 1e3, 5), "higher_is_better": True, "scaling": "strong" if args.c5 else "weak",
         "vs_baseline": None, "dtype": "f32 coordinates, %s pixels" % np.dtype(abi.PIXEL_TYPES[types[0]][1]).name, "data": "synthetic",
-        "config": {"workload": "%s: %dx%d %s, opencv_fisheye GoPro-style lens, rolling shutter matrix_count=%d, %s, "
-                               "%d frames + per-row matrix tables resident in HBM%s"
-                               % ("C1" if args.c1 else "C2" if (W, H, args.fmt) == (3840, 2160, FMT) else "C3" if (W, H, args.fmt) == (7680, 4320, FMT) else "C4" if args.crop else "custom",
-                                  W, H, args.fmt, frames[0].matrices.shape[0],
-                                  {2: "bilinear", 4: "bicubic", 8: "Lanczos4"}.get(args.interp, str(args.interp)), NR,
-                                  " — HOST buffers: H2D + warp + D2H + sync per frame (PCIe-inclusive)" if args.host_buffers else
-                                  " (matrices re-uploaded per frame)" if args.upload_matrices else
-                                  " (per-row matrices built on the device every frame from quaternion tracks)" if args.build_matrices else ""),
-                   "frames_per_rank": args.steps, "parallelism": "frame-sharded x%d" % world,
+        "config": {"workload": workload, "frames_per_rank": n_steps, "frames_total": frames_done, "parallelism": "frame-sharded x%d" % world,
                    "backend": warp.last_backend(), "checksum": crc, "rank_checksums": rank_crcs,
-                   "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 5)},
+                   "host_enqueue_ms_per_step": round(t_enq / max(n_steps, 1) * 1e3, 5),
+                   "device": info.value.decode(), "collectives": (args.backend if dist is not None else "none (1 rank)")},
     }
     if launches:
         per_launch_ms = kernel_ms / launches
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed PMC passes of this exact workload (rocprofv3 cannot run inside bench.py)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_c2_traffic.json")
-        if (W, H, args.fmt, args.interp, args.crop, args.variant, args.host_buffers) == (WIDTH, HEIGHT, FMT, 2, False, 0, False) and os.path.exists(tpath):
+        # HBM bytes per launch: rocprofv3 PMC passes cannot run inside bench.py; the stored figure of this exact workload is quoted
+        traffic, tsrc = None, None
+        tpath = os.path.join(ROOT, TRAFFIC_FILE)
+        if (W, H, args.fmt, args.interp, args.crop, args.variant, args.host_buffers, bool(args.digital)) == (WIDTH, HEIGHT, FMT, 2, False, 0, False, False) and os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic = int((tj["fetch_size_kib"] * tj["fetch_correction"] + tj["write_size_kib"]) * 1024)
+            tsrc = "%s (stored rocprofv3 PMC passes of this workload, not measured in this run)" % TRAFFIC_FILE
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                            "kernel": warp.last_backend(), "kernel_ms_per_launch": round(per_launch_ms, 5),
                            "algorithmic_bytes_per_launch": alg_bytes, "launches": launches}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+
+    # ---- parity of the timed region's own output, and the CPU baseline (rank 0) ---------------------------------
+    if rank == 0 and not (args.no_parity and (args.no_cpu_baseline or world > 1)):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import _oracle as O
-        cores = O.lib().gfw_oracle_num_threads()
-        O.run_frame(frames[0])                         # warm-up
-        n_cpu = 0
-        c0 = time.perf_counter()
-        while True:
-            ref = O.run_frame(frames[n_cpu % N_DISTINCT])
-            n_cpu += 1
-            if time.perf_counter() - c0 > 12.0 or n_cpu >= 256:
+        checks, seen_d = [], set()
+        for k in range(n_steps - 1, max(n_steps - 1 - min(N_CHECK, N_DST - 1), -1), -1):
+            f, j, d = plan(k)
+            if d in seen_d:                           # a later step overwrote this destination set
                 break
-        cpu_s = time.perf_counter() - c0
-        out["cpu_baseline"] = {"value": round(luma_px * n_cpu / cpu_s / 1e6, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
-                               "sample": "%d frames of the same workload through oracle/gfw_oracle.c (OpenMP rows, %d threads)" % (n_cpu, cores)}
-        # parity spot-check on the frame the oracle just produced
-        i = (n_cpu - 1) % N_DISTINCT
-        be.set_option(abi.OPT_SYNCHRONOUS, 1)
-        be.set_option(abi.OPT_MATRICES_ON_DEVICE, 0)
-        be.get_profile(reset=True)
-        be.undistort_frame(bufsets[i * N_DST], params[i], types, frames[i].matrices)
-        ok = all(np.array_equal(ref[p], h_dst[0][p] if args.host_buffers else d_dst[0][p].cpu().numpy()) for p in range(nplanes))
-        out["config"]["parity_vs_oracle"] = "bit-exact" if ok else "MISMATCH"
+            seen_d.add(d)
+            if device_built:
+                # the table this frame used: rebuilt from the same tracks / timestamp (the builder is deterministic)
+                tab = torch.empty(rows_n * 16, dtype=torch.float32, device=dev)
+                be.set_option(abi.OPT_SYNCHRONOUS, 1)
+                be.build_matrices(nk, ts_of(f), readout, rows_n, H, out_ptr=tab.data_ptr())
+                be.set_option(abi.OPT_SYNCHRONOUS, 0)
+                mats = np.ascontiguousarray(tab.cpu().numpy().reshape(rows_n, 16)[:, :14])
+            else:
+                mats = frames[j].matrices
+            src = [pl["src"] for pl in frames[j].planes] if args.host_buffers else [t.cpu().numpy() for t in d_src[j]]
+            checks.append((k, f, d, _FrameView(frames[j], src, mats)))
+        checks.reverse()
+        got = {d: [dst_host(d, p).copy() for p in range(nplanes)] for (_, _, d, _) in checks}
+        refs = {}
+        if not args.no_parity:
+            bad = []
+            for k, f, d, view in checks:
+                refs[k] = O.run_frame(view)
+                if not all(np.array_equal(refs[k][p], got[d][p]) for p in range(nplanes)):
+                    bad.append(k)
+                if args.c5:
+                    want = int(np.concatenate([np.pad(refs[k][p], (0, offs[p + 1] - offs[p] - sizes[p]), constant_values=0x5A) for p in range(nplanes)]
+                                              + [np.full(dst_total - offs[-1], 0x5A, np.uint8)]).view(np.int64).sum(dtype=np.int64))
+                    if want != int(mine[k]):
+                        bad.append(("checksum", k))
+            out["config"]["parity_vs_oracle"] = "bit-exact" if not bad else "MISMATCH at steps %s" % bad
+            out["config"]["parity_checked"] = "outputs of timed steps %s (frames %s) vs oracle/gfw_oracle.c, all planes" % (
+                [c[0] for c in checks], [c[1] for c in checks])
+        if world == 1 and not args.no_cpu_baseline:
+            cores = O.lib().gfw_oracle_num_threads()
+            views = [c[3] for c in checks]
+            for i in range(2):
+                O.run_frame(views[i % len(views)])                        # warm-up
+            times = []
+            c0 = time.perf_counter()
+            while len(times) < 5 or (time.perf_counter() - c0 < 10.0 and len(times) < 64):
+                a = time.perf_counter()
+                O.run_frame(views[len(times) % len(views)])
+                times.append(time.perf_counter() - a)
+            med = float(np.median(times))
+            out["cpu_baseline"] = {"value": round(luma_px / med / 1e6, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
+                                   "sample": "median of %d frames of the same workload (2 warm-ups) through oracle/gfw_oracle.c, OpenMP rows on %d threads "
+                                             "(nproc %d); mean %.3f Mpix/s" % (len(times), cores, os.cpu_count() or 0, luma_px * len(times) / sum(times) / 1e6)}
     be.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
     shard.finish(dist)
 
 
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.worker or "RANK" in os.environ:
+        worker(args)
+        return 0
+    return launcher(args, argv)
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -139,6 +139,7 @@ def bind(lib):
     lib.gfw_stmap_undistort.argtypes = [vp, C.POINTER(KernelParams), vp, i32, vp, sz, i32, i32, vp, i32]; lib.gfw_stmap_undistort.restype = i32
     lib.gfw_undistort_points.argtypes = [vp, C.POINTER(KernelParams), vp, sz, i32, vp, i32, vp, i32, vp, sz, vp, i32]; lib.gfw_undistort_points.restype = i32
     lib.gfw_pack_matrices.argtypes = [vp, i32, vp]; lib.gfw_pack_matrices.restype = i32
+    lib.gfw_checksum64.argtypes = [vp, vp, sz, vp]; lib.gfw_checksum64.restype = i32
     lib.gfw_get_audit.argtypes = [vp, C.POINTER(C.c_ulonglong * 8), i32]; lib.gfw_get_audit.restype = i32
     lib.gfw_debug_math.argtypes = [i32, vp, vp, vp, sz]; lib.gfw_debug_math.restype = i32
     lib.gfw_debug_selftest.argtypes = [i32, C.c_ulonglong, C.c_ulonglong]; lib.gfw_debug_selftest.restype = C.c_longlong
@@ -150,7 +151,7 @@ def bind(lib):
 
 EXPORTS = ["gfw_abi_version", "gfw_list_devices", "gfw_set_device", "gfw_get_info", "gfw_is_buffer_supported",
            "gfw_create", "gfw_destroy", "gfw_undistort_image", "gfw_undistort_frame", "gfw_set_option",
-           "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_last_backend", "gfw_get_profile", "gfw_last_error", "gfw_debug_math", "gfw_debug_selftest", "gfw_get_audit", "gfw_pack_matrices", "gfw_set_quaternion_tracks", "gfw_build_matrices", "gfw_build_matrices_batch", "gfw_stmap_undistort", "gfw_undistort_points",
+           "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_last_backend", "gfw_get_profile", "gfw_last_error", "gfw_debug_math", "gfw_debug_selftest", "gfw_get_audit", "gfw_pack_matrices", "gfw_checksum64", "gfw_set_quaternion_tracks", "gfw_build_matrices", "gfw_build_matrices_batch", "gfw_stmap_undistort", "gfw_undistort_points",
            "gfw_pixel_type_info"]
 
 

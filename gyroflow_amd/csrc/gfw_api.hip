@@ -442,6 +442,9 @@ static bool int_products_exact(int n_max, int n) {
 
 // s(rho) = theta_d(atan(r)) / r with r = sqrt(rho) (opencv_fisheye.rs:72-95), tabulated for the certified first pass.
 static double p1_s_of_rho(double rho, const float *k) {
+    // all four k zero: the reference skips the atan scaling altogether and returns (x/z, y/z) (opencv_fisheye.rs:75),
+    // which the exact path honours through k_all_zero — the table must describe the same map, s == 1
+    if (k[0] == 0.0f && k[1] == 0.0f && k[2] == 0.0f && k[3] == 0.0f) return 1.0;
     const double r = sqrt(rho);
     if (r == 0.0) return 1.0;
     const double t = atan(r), t2 = t * t;
@@ -617,13 +620,13 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     // luma output pixel -> output space identity: x*ow/ow = x
     if (!int_products_exact(p0.output_width, p0.output_width) || !int_products_exact(p0.output_height, p0.output_height)) return false;
     if (p0.output_width >= (1 << 23) || p0.output_height >= (1 << 23)) return false;
-    // IBIS/OIS terms (matrices[9..13]): host matrices are scanned, device matrices rely on the flag; packed device rows
-    // carry the host-evaluated cos/sin of the roll, raw device rows[14] do not (gfw_repack_matrices_kernel)
+    // IBIS/OIS terms (matrices[9..13]): host matrices are scanned, device matrices rely on the flag (get_kernel_flags sets
+    // it whenever the clip has IBIS/OIS data, mod.rs:226-251); packed device rows carry cos/sin of the roll from
+    // gfw_pack_matrices, raw device rows[14] get them from gfw_repack_matrices_kernel (the same libm routines, restated)
     if (h_matrices) {
         for (int r = 0; r < matrix_count && !(extras & 1); ++r) { const float *m = h_matrices + (size_t)r * 14;
             if (m[9] != 0.0f || m[10] != 0.0f || m[11] != 0.0f || m[12] != 0.0f || m[13] != 0.0f) extras |= 1; }
     } else if (p0.flags & GFW_FLAG_HAS_IBIS_DATA) {
-        if (c->matrices_on_device != 2) return false;
         extras |= 1;
     }
     // source_rect map constants: u * pw / W  (cpu_undistort.rs:511-514 with frame_size = (width, height))
@@ -804,6 +807,15 @@ long long gfw_debug_selftest(int test, unsigned long long n, unsigned long long 
     (void)hipFree(dbad);
     return (long long)bad;
 }
+}
+
+// Verification helper of the frame-sharded clip run ("8 B checksum per frame"): adds the sum of the
+// buffer's u64 words (mod 2^64) to *d_out, in order on the context's stream.  `bytes` must be a multiple of 8 and the
+// buffer 16-byte aligned; d_out is a device pointer the caller zeroed.
+extern "C" int gfw_checksum64(gfw_ctx *c, const void *d_buf, size_t bytes, unsigned long long *d_out) {
+    if (!c || !d_buf || !d_out || (bytes & 7) || ((uintptr_t)d_buf & 15)) { set_error("bad checksum arguments"); return GFW_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(gfw_launch_checksum64(d_buf, bytes, d_out, c->stream), GFW_ERR_HIP);
+    return GFW_OK;
 }
 
 extern "C" int gfw_pack_matrices(const float *rows14, int count, float *rows16) {

@@ -218,16 +218,49 @@ hipError_t gfw_launch_points(const gfw_kernel_params &P, const GfwCommon &C, con
 }
 
 // Row repack: [rows][14] f32 (FrameTransform.matrices) -> [rows][16] with cos(-m11), sin(-m11) slots.
-// Used only for device-resident matrices; the trig slots are 1 / 0 (no IBIS roll), see gfw_api.hip.
+// Used only for device-resident raw rows (GFW_OPT_MATRICES_ON_DEVICE = 1).  The roll terms are evaluated with
+// gfw_cosf / gfw_sinf — the host libm's routines restated (gfw_math.h), bit-identical to what cpu_undistort.rs:159-160
+// computes on the host — and, as on the host path (gfw_pack_matrices), only for rows that carry IBIS/OIS data.
 __global__ void gfw_repack_matrices_kernel(const float *in, float *out, int rows) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * GFW_MAT_STRIDE) return;
-    const int r = i >> 4, c = i & 15;
-    out[i] = c < 14 ? in[r * 14 + c] : (c == 14 ? 1.0f : 0.0f);
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float *m = in + (size_t)r * 14;
+    float *o = out + (size_t)r * GFW_MAT_STRIDE;
+    float v[14];
+    #pragma unroll
+    for (int c = 0; c < 14; ++c) { v[c] = m[c]; o[c] = v[c]; }
+    float cs = 1.0f, sn = 0.0f;
+    if (v[9] != 0.0f || v[10] != 0.0f || v[11] != 0.0f || v[12] != 0.0f || v[13] != 0.0f) { cs = gfw_cosf(-v[11]); sn = gfw_sinf(-v[11]); }
+    o[14] = cs; o[15] = sn;
 }
 hipError_t gfw_launch_repack(const float *in, float *out, int rows, hipStream_t s) {
-    const int n = rows * GFW_MAT_STRIDE;
-    hipLaunchKernelGGL(gfw_repack_matrices_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, rows);
+    hipLaunchKernelGGL(gfw_repack_matrices_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, in, out, rows);
+    return hipGetLastError();
+}
+
+// 64-bit additive checksum of a device buffer (gfw_checksum64): sum of its little-endian u64 words modulo 2^64, accumulated
+// into *out with one atomic per workgroup.  Order-independent, so ranks / launches agree bit for bit.
+__global__ __launch_bounds__(256) void gfw_checksum64_kernel(const uint64_t *p, size_t n, unsigned long long *out) {
+    __shared__ unsigned long long part[4];
+    unsigned long long acc = 0;
+    const size_t stride = (size_t)gridDim.x * 256u * 2u;
+    const ulonglong2 *p2 = reinterpret_cast<const ulonglong2 *>(p);
+    const size_t n2 = n >> 1;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n2; i += stride >> 1) { const ulonglong2 v = p2[i]; acc += v.x + v.y; }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc += p[n - 1];
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+hipError_t gfw_launch_checksum64(const void *buf, size_t bytes, unsigned long long *out, hipStream_t s) {
+    const size_t n = bytes / 8;
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n / 2 + 256 * 8 - 1) / (256 * 8);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gfw_checksum64_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint64_t *)buf, n, out);
     return hipGetLastError();
 }
 
@@ -249,6 +282,8 @@ __global__ void gfw_debug_math_kernel(int op, const float *a, const float *b, fl
     case 8: r = (float)gfw_f2u_sat(x, 65535.0f); break;
     case 9: r = gfw_round(x); break;
     case 10: r = (float)gfw_f2u_sat(x, 255.0f); break;
+    case 11: r = gfw_sinf(x); break;
+    case 12: r = gfw_cosf(x); break;
     }
     out[i] = r;
 }

@@ -166,3 +166,103 @@ GFW_HD float gfw_tanf(float x) {
     const int n = gfw_rem_pio2f(x, &y0, &y1);
     return gfw_kernel_tanf(y0, y1, 1 - ((n & 1) << 1));
 }
+
+
+// ---- sinf / cosf ----------------------------------------------------------------
+// glibc >= 2.28 (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, s_sincosf.h — Arm optimized-routines lineage): the
+// argument is reduced in double (the reduction gfw_rem_pio2f also restates) and a degree-7 / degree-8 double
+// polynomial is evaluated, the result rounded to float once.  On x86-64 the dynamic linker selects the `_fma` build of
+// these two routines on every FMA-capable CPU (sysdeps/x86_64/fpu/multiarch/s_sinf.c, s_cosf.c), in which the
+// compiler contracted every `a + b * c` of the source into one fused operation; the sequence below is that build's,
+// written with explicit fma() so that it does not depend on the contraction mode of THIS translation unit.
+// tests/test_math_host.py compares it with the host libm on all 2^32 inputs; tests/test_gpu_math.py re-checks the
+// device build.  Used for the IBIS/OIS roll angle (cpu_undistort.rs:159-160: cos(-m11), sin(-m11)) when the per-row
+// matrices never visit the host.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GFW_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#else
+#define GFW_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#endif
+GFW_HD double gfw_sincosf_reduce(float y, int *np, int *flip_table) {
+    // returns x*s (reduced argument with the quadrant sign applied); *np = quadrant; *flip_table = use the negated polynomial
+    const uint32_t xi0 = gfw_f2u(y);
+    const double sign4[4] = {1.0, -1.0, -1.0, 1.0};
+    double x = (double)y;
+    int n;
+    if (((xi0 >> 20) & 0x7ffu) < 0x42fu) {           // abstop12(y) < abstop12(120.0f): reduce_fast
+        const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+        const double r = x * hpi_inv;
+        n = ((int32_t)r + 0x800000) >> 24;
+        x = GFW_FMA(-(double)n, hpi, x);
+        *np = n;
+        *flip_table = (n & 2) != 0;
+        return x * sign4[n & 3];
+    }
+    // reduce_large
+    const uint32_t inv_pio4[24] = {
+        0x000000a2u, 0x0000a2f9u, 0x00a2f983u, 0xa2f9836eu, 0xf9836e4eu, 0x836e4e44u, 0x6e4e4415u, 0x4e441529u,
+        0x441529fcu, 0x1529fc27u, 0x29fc2757u, 0xfc2757d1u, 0x2757d1f5u, 0x57d1f534u, 0xd1f534ddu, 0xf534ddc0u,
+        0x34ddc0dbu, 0xddc0db62u, 0xc0db6295u, 0xdb629599u, 0x6295993cu, 0x95993c43u, 0x993c4390u, 0x3c439041u};
+    const double pi63 = 0x1.921FB54442D18p-62;
+    uint32_t xi = xi0;
+    const int sign = (int)(xi >> 31);
+    const uint32_t *arr = &inv_pio4[(xi >> 26) & 15];
+    const int shift = (int)((xi >> 23) & 7);
+    xi = (xi & 0xffffffu) | 0x800000u;
+    xi <<= shift;
+    uint64_t res0 = (uint64_t)(uint32_t)(xi * arr[0]);
+    const uint64_t res1 = (uint64_t)xi * arr[4];
+    const uint64_t res2 = (uint64_t)xi * arr[8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const uint64_t nn = (res0 + (1ULL << 61)) >> 62;
+    res0 -= nn << 62;
+    x = (double)(int64_t)res0 * pi63;
+    n = (int)nn;
+    *np = n;
+    *flip_table = ((n + sign) & 2) != 0;
+    return x * sign4[(n + sign) & 3];
+}
+// sinf_poly of s_sincosf.h: n even -> sine polynomial, n odd -> cosine polynomial; `neg` selects __sincosf_table[1]
+GFW_HD float gfw_sinf_poly(double x, double x2, int neg, int n) {
+    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    if ((n & 1) == 0) {
+        const double x3 = x * x2;
+        const double t1 = GFW_FMA(x2, s3, s2);
+        const double x7 = x3 * x2;
+        const double s = GFW_FMA(x3, s1, x);
+        return (float)GFW_FMA(x7, t1, s);
+    }
+    const double sg = neg ? -1.0 : 1.0;
+    const double x4 = x2 * x2;
+    const double d2 = GFW_FMA(x2, sg * c4, sg * c3);
+    const double d1 = GFW_FMA(x2, sg * c1, sg * c0);
+    const double x6 = x4 * x2;
+    const double c = GFW_FMA(x4, sg * c2, d1);
+    return (float)GFW_FMA(x6, d2, c);
+}
+GFW_HD float gfw_sinf(float y) {
+    const uint32_t top = (gfw_f2u(y) >> 20) & 0x7ffu;
+    if (top < 0x3f4u) {                                // abstop12(y) < abstop12(pio4 = 0x1.921FB6p-1f)
+        if (top < 0x398u) return y;                    // |y| < 2^-12
+        const double x = (double)y;
+        return gfw_sinf_poly(x, x * x, 0, 0);
+    }
+    if (top >= 0x7f8u) return y - y;                   // inf / NaN
+    int n, neg;
+    const double xs = gfw_sincosf_reduce(y, &n, &neg);
+    return gfw_sinf_poly(xs, xs * xs, neg, n);
+}
+GFW_HD float gfw_cosf(float y) {
+    const uint32_t top = (gfw_f2u(y) >> 20) & 0x7ffu;
+    if (top < 0x3f4u) {
+        if (top < 0x398u) return 1.0f;
+        const double x = (double)y;
+        return gfw_sinf_poly(x, x * x, 0, 1);
+    }
+    if (top >= 0x7f8u) return y - y;
+    int n, neg;
+    const double xs = gfw_sincosf_reduce(y, &n, &neg);
+    return gfw_sinf_poly(xs, xs * xs, neg, n ^ 1);
+}

@@ -76,6 +76,25 @@ def gather_checksums(dist, crcs, device="cpu"):
     return [[int(v) for v in o.cpu().tolist()] for o in outs]
 
 
+def assemble_frame_checksums(dist, mine, rank, world, total_frames, device="cpu"):
+    """Per-frame checksums of a round-robin sharded clip, back in clip order on every rank.
+
+    ``mine[i]`` is the checksum of the i-th frame this rank owns (``frames_for_rank(rank, world, total_frames)[i]``).
+    Ranks own ceil or floor(total/world) frames; the all-gather carries ceil(total/world) values per rank (8 B each,
+    80 KB for the 10 000-frame clip).  Returns (frame_sums: list of total_frames ints, per_rank: the gathered rows)."""
+    per_rank = (total_frames + world - 1) // world
+    own = frames_for_rank(rank, world, total_frames)
+    if len(mine) != len(own):
+        raise ValueError("rank %d owns %d frames but reported %d checksums" % (rank, len(own), len(mine)))
+    padded = [int(v) for v in mine] + [0] * (per_rank - len(mine))
+    gathered = gather_checksums(dist, padded, device)
+    frame_sums = [0] * total_frames
+    for r in range(world):
+        for i, f in enumerate(frames_for_rank(r, world, total_frames)):
+            frame_sums[f] = gathered[r][i]
+    return frame_sums, gathered
+
+
 def finish(dist):
     if dist is not None:
         dist.destroy_process_group()

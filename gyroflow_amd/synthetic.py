@@ -58,6 +58,72 @@ def plane_pattern(width, height, channels, dtype, seed, max_value=None):
     return out
 
 
+def _i64(c):
+    """A 64-bit constant as the two's-complement int64 torch uses (int64 arithmetic wraps, like uint64 does)."""
+    c &= 0xFFFFFFFFFFFFFFFF
+    return c - (1 << 64) if c >= (1 << 63) else c
+
+
+def plane_pattern_torch(width, height, channels, dtype, seed, max_value=None, device="cpu"):
+    """:func:`plane_pattern` evaluated with torch ops on ``device`` — bit-identical output (same integer hash in wrapping
+    int64, the same float64 operations one at a time), so a clip's source frames can be produced directly in HBM instead
+    of being generated on the host and uploaded.  Returns a torch tensor (height, width, channels) of ``dtype``."""
+    import torch
+    dt = np.dtype(dtype)
+    tdt = {"u1": torch.uint8, "<u2": torch.int32, "<f4": torch.float32, "<f2": torch.float16}[dt.str if dt.str != "|u1" else "u1"]
+    i64 = torch.int64
+
+    def lsr(x, s):                                   # logical shift right of the 64-bit pattern
+        return (x >> s) & ((1 << (64 - s)) - 1)
+
+    def splitmix(x):
+        x = x + _i64(0x9E3779B97F4A7C15)
+        x = (x ^ lsr(x, 30)) * _i64(0xBF58476D1CE4E5B9)
+        x = (x ^ lsr(x, 27)) * _i64(0x94D049BB133111EB)
+        return x ^ lsr(x, 31)
+
+    yy = torch.arange(height, dtype=i64, device=device).reshape(height, 1).expand(height, width)
+    xx = torch.arange(width, dtype=i64, device=device).reshape(1, width).expand(height, width)
+    planes = []
+    for ch in range(channels):
+        key = (_i64(int(seed) << 32) ^ _i64(ch << 56)) ^ (yy * 65537 + xx)
+        noise = lsr(splitmix(key), 40).to(torch.float64) / float(1 << 24)
+        grad = ((xx.to(torch.float64) / max(width - 1, 1)) + (yy.to(torch.float64) / max(height - 1, 1))) * 0.5
+        if ch % 2:
+            grad = 1.0 - grad
+        checker = ((lsr(xx, 4) + lsr(yy, 4)) & 1).to(torch.float64)
+        v = 0.5 * noise
+        v = v + 0.3 * grad
+        v = v + 0.2 * checker
+        if dt.kind == "u":
+            top = float(np.iinfo(dt).max if max_value is None else max_value)
+            planes.append(torch.minimum(torch.floor(v * (top + 1.0)), torch.tensor(top, dtype=torch.float64, device=device)).to(tdt))
+        else:
+            planes.append((v * float(1.0 if max_value is None else max_value)).to(tdt))
+    return torch.stack(planes, dim=2)
+
+
+def make_plane_buffer_torch(width, height, pixel_type, seed, max_value=None, stride_align=256, fill=0xA5, device="cpu"):
+    """:func:`make_plane_buffer` on ``device``: (1-D uint8 tensor of stride*height bytes, stride), byte-identical."""
+    import torch
+    _, dt, count, _ = abi.PIXEL_TYPES[pixel_type]
+    item = np.dtype(dt).itemsize
+    bpp = item * count
+    stride = align(width * bpp, stride_align)
+    pat = plane_pattern_torch(width, height, count, dt, seed, max_value, device).reshape(height, width * count)
+    if np.dtype(dt).kind == "u" and item == 2:
+        pat = torch.stack([pat & 0xFF, pat >> 8], dim=2).to(torch.uint8).reshape(height, width * bpp)      # little-endian u16
+    elif item == 1:
+        pat = pat.reshape(height, width * bpp)
+    else:
+        pat = pat.contiguous().view(torch.uint8).reshape(height, width * bpp)
+    if stride == width * bpp:
+        return pat.contiguous().reshape(-1), stride
+    buf = torch.full((height, stride), fill, dtype=torch.uint8, device=device)
+    buf[:, : width * bpp] = pat
+    return buf.reshape(-1), stride
+
+
 def align(n, a):
     return (n + a - 1) // a * a
 
@@ -277,7 +343,9 @@ class SyntheticFrame:
     def __init__(self, fmt, width, height, seed=0x9F10, fov=1.0, readout_ms=16.0, timestamp_ms=1000.0,
                  interpolation=2, constant_quat=None, out_size=None, lens=None, horizontal_rs=False,
                  stride_align=256, background_rgba=(0.0, 0.0, 0.0, 0.0), base_overrides=None, flags=0,
-                 limited_range=False):
+                 limited_range=False, pixels=True):
+        """pixels=False skips the host pixel buffers (``src``/``dst`` are None): geometry, params and matrices only — for
+        clips whose frames are produced on the device by :meth:`device_planes`."""
         self.fmt, self.width, self.height = fmt, width, height
         self.out_size = out_size or (width, height)
         self.lens = lens or gopro_style_lens(width, height)
@@ -295,17 +363,31 @@ class SyntheticFrame:
         for idx, (ptype, (dw, dh), yuvi, max_val) in enumerate(FRAME_FORMATS[fmt]):
             pw, ph = formats.plane_size(width, height, (dw, dh))
             ow, oh = formats.plane_size(self.out_size[0], self.out_size[1], (dw, dh))
-            src, stride = make_plane_buffer(pw, ph, ptype, seed + idx * 101, max_val, stride_align)
             _, dt, count, _ = abi.PIXEL_TYPES[ptype]
+            if pixels:
+                src, stride = make_plane_buffer(pw, ph, ptype, seed + idx * 101, max_val, stride_align)
+            else:
+                src, stride = None, align(pw * np.dtype(dt).itemsize * count, stride_align)
             ostride = align(ow * np.dtype(dt).itemsize * count, stride_align)
-            dst = np.full(ostride * oh, 0x5A, dtype=np.uint8)
+            dst = np.full(ostride * oh, 0x5A, dtype=np.uint8) if pixels else None
             kp = plane_kernel_params(base, ptype, (width, height), self.out_size,
                                      (pw, ph, stride, None, None), (ow, oh, ostride, None, None),
                                      interpolation=interpolation, flags=flags,
                                      background=formats.from_rgb_color(ptype, background_rgba, yuvi, limited_range),
                                      max_val=max_val, plane_index=idx)
             self.planes.append({"pixel_type": ptype, "size": (pw, ph, stride), "out_size": (ow, oh, ostride),
-                                "src": src, "dst": dst, "params": kp})
+                                "src": src, "dst": dst, "params": kp, "seed": seed + idx * 101, "max_val": max_val})
+        self.stride_align = stride_align
+
+    def device_planes(self, device):
+        """The frame's source planes generated directly on ``device`` (torch uint8 tensors, byte-identical to ``src``)."""
+        return [make_plane_buffer_torch(pl["size"][0], pl["size"][1], pl["pixel_type"], pl["seed"], pl["max_val"],
+                                        self.stride_align, device=device)[0] for pl in self.planes]
+
+    def device_outputs(self, device):
+        """Destination planes on ``device`` pre-filled like the host ``dst`` buffers (0x5A)."""
+        import torch
+        return [torch.full((pl["out_size"][2] * pl["out_size"][1],), 0x5A, dtype=torch.uint8, device=device) for pl in self.planes]
 
     def luma_pixels(self):
         return self.out_size[0] * self.out_size[1]
@@ -325,6 +407,47 @@ def sampled_track(seed, t0_ms, t1_ms, rate_hz=1000.0, scale=1.0):
     n = int((t1_ms - t0_ms) * rate_hz / 1000.0) + 1
     ts = (np.round((t0_ms + np.arange(n) * 1000.0 / rate_hz) * 1000.0)).astype(np.int64)
     q = np.stack([camera_quat_at(t / 1000.0, seed) for t in ts])
+    if scale != 1.0:
+        q[:, 1:] *= scale
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return ts, q
+
+
+def camera_quat_track(t_ms, seed):
+    """:func:`camera_quat_at` over an array of times (vectorised; numpy's sin/cos may differ from libm's in the last
+    place, which is irrelevant: tracks are inputs)."""
+    t_ms = np.asarray(t_ms, dtype=np.float64)
+    h = _splitmix64(np.arange(18, dtype=np.uint64) + (np.uint64(seed) << np.uint64(8)))
+    u = (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    ang = np.zeros((3, t_ms.shape[0]))
+    for axis in range(3):
+        for j in range(3):
+            freq = 0.5 + 2.5 * u[axis * 6 + j * 2]
+            phase = 2 * math.pi * u[axis * 6 + j * 2 + 1]
+            amp = (8.0 / 3.0) / (1.0 + j)
+            ang[axis] += amp * np.sin(2 * math.pi * freq * t_ms / 1000.0 + phase)
+
+    def axis_q(ax, deg):
+        hh = np.radians(deg) / 2.0
+        q = np.zeros((4, deg.shape[0]))
+        q[0] = np.cos(hh)
+        q[1 + ax] = np.sin(hh)
+        return q
+
+    def mul(a, b):
+        aw, ax, ay, az = a
+        bw, bx, by, bz = b
+        return np.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                         aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw])
+    q = mul(axis_q(2, ang[2] * 0.5), mul(axis_q(0, ang[1]), axis_q(1, ang[0])))
+    return np.ascontiguousarray(q.T)
+
+
+def sampled_track_fast(seed, t0_ms, t1_ms, rate_hz=1000.0, scale=1.0):
+    """:func:`sampled_track` built with :func:`camera_quat_track` (long clips: 10 000 frames = 333 s of track)."""
+    n = int((t1_ms - t0_ms) * rate_hz / 1000.0) + 1
+    ts = (np.round((t0_ms + np.arange(n) * 1000.0 / rate_hz) * 1000.0)).astype(np.int64)
+    q = camera_quat_track(ts / 1000.0, seed)
     if scale != 1.0:
         q[:, 1:] *= scale
     q /= np.linalg.norm(q, axis=1, keepdims=True)

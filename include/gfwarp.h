@@ -253,7 +253,10 @@ enum {
     GFW_OPT_MATRICES_ON_DEVICE = 2,  /* 0: host rows of [f32;14] (default, uploaded per call like opencl.rs:406);
                                         1: device pointer, rows of [f32;14]; 2: device pointer, rows of 16 floats as
                                         written by gfw_pack_matrices (no per-call work at all).  With 1 and 2 the
-                                        IBIS terms m[9..13] are honoured only if GFW_FLAG_HAS_IBIS_DATA is set. */
+                                        library cannot scan the rows, so the IBIS/OIS terms m[9..13] are honoured only if
+                                        GFW_FLAG_HAS_IBIS_DATA is set in params->flags (get_kernel_flags, mod.rs:226-251,
+                                        sets it for every clip that has such data); with 1 the roll's cos/sin are
+                                        evaluated on the device with the host libm's own routines (gfw_math.h). */
     GFW_OPT_KERNEL_VARIANT     = 3,  /* 0 auto; 1 generic per-plane kernel; 2 fused kernel with the exact first pass;
                                         3 fused kernel, certified first pass in audit mode (see gfw_get_audit) */
     GFW_OPT_PROFILE            = 4,  /* 1: bracket every warp-kernel launch with hipEvents on the context stream */
@@ -283,6 +286,11 @@ const char *gfw_last_error(void);
  * knows its FrameTransforms ahead of time packs them once, keeps them in HBM and passes the device pointer with
  * GFW_OPT_MATRICES_ON_DEVICE = 2. */
 int   gfw_pack_matrices(const float *rows14, int count, float *rows16);
+
+/* Verification helper for frame-sharded clip runs (no reference counterpart; SURVEY.md 8e: one 8-byte checksum per frame,
+ * all-gathered across ranks): adds the sum of the u64 words of a device buffer (mod 2^64) to *d_out, enqueued in order
+ * on the context's stream.  `bytes` a multiple of 8, `d_buf` 16-byte aligned, `d_out` a zero-initialised device word. */
+int   gfw_checksum64(gfw_ctx *ctx, const void *d_buf, size_t bytes, unsigned long long *d_out);
 
 /* ---- per-row matrices on the device ("next" row: FrameTransform::at_timestamp, frame_transform.rs:221-308) ----
  * gfw_set_quaternion_tracks uploads the clip's original and smoothed orientation tracks once

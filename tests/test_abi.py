@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_functions():
     txt = open(os.path.join(ROOT, "include", "gfwarp.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(gfw_[a-z_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(gfw_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_every_declared_symbol_is_exported():

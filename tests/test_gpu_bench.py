@@ -1,0 +1,76 @@
+"""bench.py under the driver's own command lines (subprocess, fresh process each): it must exit 0, print ONE JSON line
+carrying `roofline`, `cpu_baseline` and a bit-exact parity verdict on frames of the timed region — and the N-rank
+paths (self-spawned ranks, torchrun-style environment, the C5 clip) must agree with the 1-rank run."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(argv, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        e.pop(k, None)
+    e.update(env or {})
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=e, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    wall = time.time() - t0
+    assert r.returncode == 0, "bench.py %s -> rc %d\n%s\n%s" % (argv, r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0]), wall
+
+
+def test_driver_command_line():
+    out, wall = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5"])
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["warmup"] == 5
+    assert out["unit"] == "Mpix/s" and out["value"] > 0 and out["higher_is_better"] is True and out["scaling"] == "weak"
+    assert out["config"]["workload"].startswith("C2:")
+    assert out["config"]["parity_vs_oracle"] == "bit-exact", out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["launches"] >= 1
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["algorithmic_bytes_per_launch"] == 66355200
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert out["ms_per_step"] * out["steps"] / 1e3 < wall
+    assert out["launcher"]["attempts"] == 1 and out["launcher"]["failures"] == []
+    # the value is consistent with the step time
+    assert abs(out["value"] - 3840 * 2160 / (out["ms_per_step"] * 1e-3) / 1e6) / out["value"] < 1e-3
+
+
+def test_torchrun_style_environment_single_rank():
+    out, _ = run_bench(["--gpus", "1", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"],
+                       env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29547"})
+    assert out["n_gpus"] == 1 and "launcher" not in out
+    assert out["config"]["parity_vs_oracle"] == "bit-exact"
+
+
+def test_two_self_spawned_ranks_on_one_gpu():
+    # the N-rank control path on real hardware: both ranks share cuda:0, collectives over gloo (RCCL refuses two ranks on one device)
+    one, _ = run_bench(["--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--resident", "8"])
+    two, _ = run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--resident", "8", "--backend", "gloo", "--same-device"])
+    assert two["n_gpus"] == 2 and two["launcher"]["ranks_spawned"] == 2
+    assert two["config"]["frames_total"] == 12 and len(two["config"]["rank_checksums"]) == 2
+    assert two["config"]["parity_vs_oracle"] == "bit-exact"
+    # rank 0 of the 2-rank run warps the same frames as the 1-rank run
+    assert two["config"]["rank_checksums"][0] == one["config"]["rank_checksums"][0]
+    assert two["config"]["rank_checksums"][1] != two["config"]["rank_checksums"][0]
+
+
+def test_c5_clip_checksums_do_not_depend_on_the_rank_count():
+    base = ["--c5", "--frames", "70", "--resident", "8", "--warmup", "3", "--no-cpu-baseline"]
+    one, _ = run_bench(base + ["--gpus", "1"])
+    two, _ = run_bench(base + ["--gpus", "2", "--backend", "gloo", "--same-device"])
+    for o in (one, two):
+        assert o["scaling"] == "strong" and o["config"]["workload"].startswith("C5:") and o["config"]["frames_total"] == 70
+        assert o["config"]["parity_vs_oracle"] == "bit-exact", o["config"]
+    assert one["steps"] == 70 and two["steps"] == 35
+    assert one["config"]["checksum"] == two["config"]["checksum"]

@@ -151,3 +151,39 @@ def test_ibis_ois_terms_in_matrices():
     for i, (a, b, g) in enumerate(zip(ref, got, gen)):
         assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "ibis plane %d (fused)" % i)
         assert_plane_equal(a, g, fr.planes[i]["pixel_type"], "ibis plane %d (generic)" % i)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_ibis_terms_with_device_resident_matrices(mode):
+    """Raw rows[14] (mode 1: cos/sin of the roll evaluated on the device with the restated libm routines) and packed
+    rows[16] (mode 2) resident in HBM, GFW_FLAG_HAS_IBIS_DATA set as get_kernel_flags does (mod.rs:226-251)."""
+    import torch
+    w, h = 256, 160
+    fr = S.SyntheticFrame("YUV422P16LE", w, h, seed=59, fov=1.2, flags=abi.FLAG_HAS_IBIS_DATA)
+    y = np.arange(fr.matrices.shape[0], dtype=np.float32)
+    fr.matrices[:, 9] = 1.25 * np.sin(y * 0.05)
+    fr.matrices[:, 10] = -0.7 * np.cos(y * 0.03)
+    fr.matrices[:, 11] = 0.05 * np.sin(y * 0.02) + 0.01     # roll angle (radians), large enough to matter
+    fr.matrices[:, 12] = 0.5
+    fr.matrices[:, 13] = -0.25
+    fr.matrices[::7, 9:14] = 0.0                             # some rows without IBIS data: cos/sin slots must be 1/0 there
+    ref = O.run_frame(fr)
+    dev = torch.device("cuda", 0)
+    host = fr.matrices if mode == 1 else warp.pack_matrices(fr.matrices)
+    d_mat = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
+    for variant in (0, 1):                                   # fused (generic-model instantiation) and per-plane kernels
+        outs = [pl["dst"].copy() for pl in fr.planes]
+        bufs = [warp.host_buffers(pl["src"], pl["size"], o, pl["out_size"]) for pl, o in zip(fr.planes, outs)]
+        params = [pl["params"] for pl in fr.planes]
+        types = [pl["pixel_type"] for pl in fr.planes]
+        be = warp.Backend(params[0], types[0], fr.model, fr.digital, bufs[0])
+        try:
+            be.set_option(abi.OPT_MATRICES_ON_DEVICE, mode)
+            if variant:
+                be.set_option(abi.OPT_KERNEL_VARIANT, variant)
+            be.undistort_frame(bufs, params, types, d_mat.data_ptr(), matrix_count=fr.matrices.shape[0])
+            assert warp.last_backend() == ("plane_generic" if variant else "yuv_fused")
+        finally:
+            be.close()
+        for i, (a, b) in enumerate(zip(ref, outs)):
+            assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "ibis mode %d variant %d plane %d" % (mode, variant, i))

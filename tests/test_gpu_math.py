@@ -95,3 +95,16 @@ def test_lean_primitives_equal_generic_on_a_billion_operands():
     # the one-correction divide over significand pairs: 16384 denominators x every 64th numerator here (1.5e9 quotients);
     # tools/prove_div.py runs all 7.04e13 pairs (profiles/r01_div_one_correction_proof.txt)
     assert lib.gfw_debug_selftest(3, 1 << 14, (6 << 32) | 0x2a5f13) == 0, "refined reciprocal + one correction"
+
+
+def test_device_sinf_cosf_equal_libm():
+    for seed, lo, hi in ((11, -30, 8), (12, -4, 40)):
+        x = sample_floats(1 << 21, seed, lo, hi)
+        assert same_bits(dev(11, x), libm(2, x))
+        assert same_bits(dev(12, x), libm(3, x))
+    x = np.linspace(-7.0, 7.0, 1 << 22, dtype=np.float32)
+    assert same_bits(dev(11, x), libm(2, x))
+    assert same_bits(dev(12, x), libm(3, x))
+    x = np.linspace(100.0, 3e7, 1 << 20, dtype=np.float32)          # reduce_large path
+    assert same_bits(dev(11, x), libm(2, x))
+    assert same_bits(dev(12, x), libm(3, x))

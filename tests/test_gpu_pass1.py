@@ -73,3 +73,22 @@ def test_horizontal_rs_and_zoomed_out_audit():
     ref = O.run_frame(fr)
     for a, b in zip(ref, outs):
         assert np.array_equal(a, b)
+
+
+def test_all_zero_k_with_rolling_shutter_keeps_the_certified_pass_exact():
+    # opencv_fisheye with k[0..3] == 0 (no lens profile / rectilinear): the reference returns (x/z, y/z) without the atan
+    # scaling (opencv_fisheye.rs:75); the first-pass table must describe that very map or rows are picked tens of pixels off
+    lens = S.gopro_style_lens(960, 540)
+    lens["k"] = [0.0] * 12
+    for fmt, seed in (("YUV422P16LE", 31), ("NV12", 32)):
+        fr = S.SyntheticFrame(fmt, 960, 540, seed=seed, lens=dict(lens), readout_ms=20.0)
+        assert fr.matrices.shape[0] == 540
+        (certified, wrong, queued, overflow, gap), outs = audit(fr)
+        assert wrong == 0 and certified > 0.8 * 960 * 540
+        ref = O.run_frame(fr)
+        for a, b in zip(ref, outs):
+            assert np.array_equal(a, b)
+        got = warp.run_frame(fr)
+        assert warp.last_backend() == "yuv_fused_p1"
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b)

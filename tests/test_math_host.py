@@ -69,3 +69,35 @@ def test_branch_free_round_half_away_matches_roundf_on_all_inputs(tmp_path):
     exe = tmp_path / "r"
     subprocess.check_call(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fno-fast-math", str(c), "-o", str(exe), "-lm"])
     assert subprocess.check_output([str(exe)], timeout=900).decode().split() == ["0"]
+
+
+SINCOS_SRC = r"""
+#include <math.h>
+#include <stdio.h>
+#include <stdint.h>
+#include "%s/gyroflow_amd/csrc/gfw_math.h"
+int main(void) {
+    long bad_s = 0, bad_c = 0;
+    #pragma omp parallel for reduction(+:bad_s,bad_c) schedule(static)
+    for (long i = 0; i < (1L << 32); ++i) {
+        const uint32_t u = (uint32_t)i; const float x = gfw_u2f(u);
+        const float a = sinf(x), b = gfw_sinf(x);
+        if (gfw_f2u(a) != gfw_f2u(b) && !(a != a && b != b)) bad_s++;
+        const float c = cosf(x), d = gfw_cosf(x);
+        if (gfw_f2u(c) != gfw_f2u(d) && !(c != c && d != d)) bad_c++;
+    }
+    printf("%%ld %%ld\n", bad_s, bad_c);
+    return 0;
+}
+"""
+
+
+def test_sinf_cosf_bit_identical_to_libm_on_all_inputs(tmp_path):
+    """gfw_sinf / gfw_cosf (IBIS/OIS roll terms for device-resident matrices) vs this box's libm, all 2^32 floats.  glibc picks
+    its FMA build of sinf/cosf on FMA-capable x86-64 CPUs; on a CPU without FMA this test would tell."""
+    c = tmp_path / "sc.c"
+    c.write_text(SINCOS_SRC % ROOT)
+    exe = tmp_path / "sc"
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fno-fast-math", str(c), "-o", str(exe), "-lm"])
+    out = subprocess.check_output([str(exe)], timeout=900).decode().split()
+    assert out == ["0", "0"], "mismatches vs libm: sinf %s, cosf %s" % tuple(out)

@@ -33,6 +33,17 @@ WORKER = textwrap.dedent("""
     g = shard.gather_checksums(dist, [crc, rank + 7])
     assert len(g) == world and g[rank] == [crc, rank + 7] and g[1 - rank][1] == (1 - rank) + 7
     assert sum(x[0] for x in g) == c
+    # the C5 clip's per-frame checksums come back in clip order on every rank (bench.py --c5 uses this very function);
+    # 7 frames over 2 ranks: rank 0 owns 4, rank 1 owns 3 (ragged)
+    own = list(shard.frames_for_rank(rank, world, 7))
+    sums, rows = shard.assemble_frame_checksums(dist, [1000 + f * f for f in own], rank, world, 7)
+    assert sums == [1000 + f * f for f in range(7)], sums
+    assert len(rows) == world and len(rows[0]) == 4
+    try:
+        shard.assemble_frame_checksums(dist, [1], rank, world, 7)
+        raise SystemExit("ragged input accepted")
+    except ValueError:
+        pass
     print("RESULT", rank, mine, t, c, flush=True)
     shard.finish(dist)
 """) % (ROOT, ROOT)
