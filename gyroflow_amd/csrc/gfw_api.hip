@@ -335,6 +335,36 @@ static int validate_plane(const gfw_buffers *b, const gfw_kernel_params *p, int 
     return GFW_OK;
 }
 
+// Header of the Sony mesh / focal-plane-distortion block (gyro_source/splines.rs:88-177, sony.rs:557-563): the kernels use
+// mesh[0] as the offset of the FPD block and mesh[1], mesh[2] as loop bounds over 9-element arrays.  The reference
+// asserts / bounds-checks these (BivariateSpline::new, slice indexing); a malformed block must not reach the device.
+template <typename MT>
+static int validate_mesh(const MT *mesh, size_t mesh_len) {
+    if (!mesh || mesh_len == 0) return GFW_OK;
+    if (mesh_len < 9) { set_error("mesh data: %zu values, header needs 9", mesh_len); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
+    const double md0 = (double)mesh[0];
+    if (!(md0 == md0)) { set_error("mesh data: NaN header"); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
+    if (md0 > 10.0) {
+        const double nxd = (double)mesh[1], nyd = (double)mesh[2];
+        if (!(nxd >= 2.0 && nxd <= 9.0 && nyd >= 2.0 && nyd <= 9.0)) { set_error("mesh data: grid %g x %g outside 2..9", nxd, nyd); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
+        const size_t nx = (size_t)nxd, ny = (size_t)nyd;
+        if (9 + nx * ny * 2 + 2 * ny * 36 > mesh_len) { set_error("mesh data: %zu values, a %zux%zu grid needs %zu", mesh_len, nx, ny, 9 + nx * ny * 2 + 2 * ny * 36); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
+    }
+    if (md0 > 0.0) {
+        if (md0 >= (double)mesh_len) { set_error("mesh data: focal-plane block offset %g beyond %zu values", md0, mesh_len); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
+        const size_t o = (size_t)md0;
+        if ((double)mesh[o] > 0.0 && o + 4 + 16 > mesh_len) { set_error("mesh data: focal-plane block at %zu needs 20 values, %zu left", o, mesh_len - o); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
+    }
+    return GFW_OK;
+}
+
+// hipSetDevice only when the calling thread's current device is another one (hipGetDevice reads a thread-local)
+static hipError_t select_device(int device) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == device) return hipSuccess;
+    return hipSetDevice(device);
+}
+
 static int upload_matrices(gfw_ctx *c, const float *matrices, int matrix_count, const float **d_out) {
     if (!matrices) { set_error("null matrices"); return GFW_ERR_NO_STABILIZATION_DATA; }
     if (matrix_count > c->max_matrix_rows) {
@@ -641,6 +671,8 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
         P.w = planes[i].input.width; P.h = planes[i].input.height;
         for (int ch = 0; ch < 4; ++ch) P.bg[ch] = params[i].background[ch] * params[i].max_pixel_value;
         P.limit = params[i].pixel_value_limit;
+        P.src_len = (int32_t)(planes[i].input.len < 0x7fffffffull ? planes[i].input.len : 0x7fffffffull);
+        P.dst_len = (int32_t)(planes[i].output.len < 0x7fffffffull ? planes[i].output.len : 0x7fffffffull);
     }
     Y.nplanes = nplanes;
     Y.width = p0.width; Y.height = p0.height;
@@ -676,16 +708,14 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
                       const float *matrices, int matrix_count, const float *mesh, size_t mesh_len) {
     if (!c) { set_error("null context"); return GFW_ERR_INVALID_ARGUMENT; }
     if (nplanes < 1 || nplanes > 8) { set_error("nplanes %d", nplanes); return GFW_ERR_INVALID_ARGUMENT; }
-    {   // hipSetDevice is not free; contexts are thread-affine, so remember what this thread last selected
-        static thread_local int tl_device = -1;
-        if (tl_device != c->device) { HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP); tl_device = c->device; }
-    }
+    HIP_TRY(select_device(c->device), GFW_ERR_HIP);
     for (int i = 0; i < nplanes; ++i) {
         const int rc = validate_plane(&planes[i], &params[i], pixel_types[i]);
         if (rc != GFW_OK) return rc;
         if (params[i].matrix_count != matrix_count) { set_error("plane %d: matrix_count %d != %d", i, params[i].matrix_count, matrix_count); return GFW_ERR_INVALID_ARGUMENT; }
     }
     if (mesh_len > GFW_MESH_MAX) { set_error("Buffer size mismatch buf_mesh_data! %d vs %zu", GFW_MESH_MAX, mesh_len); return GFW_ERR_BUFFER_SIZE_MISMATCH; }  // opencl.rs:352
+    { const int mrc = validate_mesh(mesh, mesh_len); if (mrc != GFW_OK) return mrc; }
     const float *d_mat = nullptr;
     int rc = upload_matrices(c, matrices, matrix_count, &d_mat);
     if (rc != GFW_OK) return rc;
@@ -927,6 +957,7 @@ extern "C" int gfw_undistort_points(gfw_ctx *c, const gfw_kernel_params *p, cons
     if (!c || !p || !rotations || !out || rotation_count < 1 || index_mode < 0 || index_mode > 3) { set_error("bad undistort_points arguments"); return GFW_ERR_INVALID_ARGUMENT; }
     if (!points && grid_width < 1) { set_error("grid_width must be >= 1 when points is NULL"); return GFW_ERR_INVALID_ARGUMENT; }
     if (mesh_len > GFW_MESH_MAX) { set_error("mesh too large"); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
+    { const int mrc = validate_mesh(mesh, mesh_len); if (mrc != GFW_OK) return mrc; }
     if (n == 0) return GFW_OK;                                               // :637 `if distorted.is_empty() { return Vec::new(); }`
     HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
     GfwPointsArgs A;
@@ -979,6 +1010,7 @@ extern "C" int gfw_stmap_undistort(gfw_ctx *c, const gfw_kernel_params *p, const
     if (!c || !p || !coords || width < 1 || height < 1) { set_error("bad stmap arguments"); return GFW_ERR_INVALID_ARGUMENT; }
     if (p->matrix_count != matrix_count || matrix_count < 1) { set_error("matrix_count %d != %d", p->matrix_count, matrix_count); return GFW_ERR_INVALID_ARGUMENT; }
     if (mesh_len > GFW_MESH_MAX) { set_error("mesh too large"); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
+    { const int mrc = validate_mesh(mesh, mesh_len); if (mrc != GFW_OK) return mrc; }
     HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
     const float *d_mat = nullptr;
     int rc = upload_matrices(c, matrices, matrix_count, &d_mat);

@@ -11,7 +11,8 @@ struct GfwYuvPlane {
     int32_t w, h;                     // source plane size (= source_rect w,h)
     float bg[4];                      // background[c] * max_pixel_value
     float limit;                      // pixel_value_limit
-    int32_t pad_[3];
+    int32_t src_len, dst_len;         // bytes the caller declared for the two buffers (< 2 GiB on this path): audit mode range-checks against them
+    int32_t pad_;
 };
 
 #define GFW_P1_TABLE_N 2048      // intervals of the first-pass s(rho) table
@@ -46,7 +47,8 @@ struct GfwYuvArgs {
     float p1_rho_max, p1_rho_scale;   // scale = N / rho_max
     float p1_eps;                     // E: bound on |approx - exact| of the projected row/column coordinate, pixels
     float p1_f, p1_c;                 // f[1], c[1] (f[0], c[0] for horizontal rolling shutter)
-    unsigned long long *audit;        // nullptr, or 8 words: certified, certified-but-wrong, queued, queue-overflow, max |approx-exact| (f32 bits)
+    unsigned long long *audit;        // nullptr, or 8 words: certified, certified-but-wrong, queued, queue-overflow, max |approx-exact| (f32 bits),
+                                      // [5] global addresses outside their buffer (audit mode range-checks every tap, store, matrix row and table entry)
     gfw_kernel_params kp;             // plane-0 params, for the non-specialised lens models
     GfwCommon common;
 };

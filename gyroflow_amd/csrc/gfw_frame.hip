@@ -461,19 +461,31 @@ __device__ __forceinline__ void taps_inside2(const uint8_t *src, int off0, int s
     }
 }
 // One plane.  32-bit byte offsets from the uniform plane base (planes are < 2 GiB, checked on the host).
+// Audit mode (aud != nullptr, a compile-time constant after inlining): every byte range about to be touched is checked
+// against the length the caller declared for the buffer; violations are counted in aud[5] and the access is skipped.
+__device__ __forceinline__ bool range_ok(unsigned long long *aud, int64_t off, int64_t bytes, int len) {
+    if (!aud) return true;
+    if (off >= 0 && off + bytes <= (int64_t)len) return true;
+    atomicAdd(&aud[5], 1ull);
+    return false;
+}
 template <typename T, int N>
-__device__ __forceinline__ void sample_store2(float u, float v, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy) {
+__device__ __forceinline__ void sample_store2(float u, float v, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy,
+                                              unsigned long long *aud = nullptr) {
     float out[N];
     #pragma unroll
     for (int c = 0; c < N; ++c) out[c] = bg[c];
     if (ok) {
         const Bins2 b = make_bins2(u, v);
-        if (__builtin_expect((unsigned)b.sx < (unsigned)(P.w - 1) && (unsigned)b.sy < (unsigned)(P.h - 1), 1))
-            taps_inside2<T, N>(P.src, b.sy * P.src_stride + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
-        else
+        if (__builtin_expect((unsigned)b.sx < (unsigned)(P.w - 1) && (unsigned)b.sy < (unsigned)(P.h - 1), 1)) {
+            const int off0 = b.sy * P.src_stride + b.sx * (int)(N * sizeof(T));
+            if (range_ok(aud, off0, 2 * N * sizeof(T), P.src_len) && range_ok(aud, (int64_t)off0 + P.src_stride, 2 * N * sizeof(T), P.src_len))
+                taps_inside2<T, N>(P.src, off0, P.src_stride, b, limit, out);
+        } else
             taps_edge2<T, N>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
     }
-    store_px<T, N>(P.dst, oy * P.dst_stride + ox * (int)(N * sizeof(T)), out);
+    const int doff = oy * P.dst_stride + ox * (int)(N * sizeof(T));
+    if (range_ok(aud, doff, N * sizeof(T), P.dst_len)) store_px<T, N>(P.dst, doff, out);
 }
 // Planar planes of identical geometry (U and V; or G,B,R,A of a planar float frame): one set of bins / weights /
 // offsets, one gather pair per plane.
@@ -504,20 +516,24 @@ __device__ __forceinline__ void sample_store_shared2(float u, float v, bool ok, 
 // two gathers, no loop over a plane index (which would index the kernel-argument plane array dynamically).
 template <typename T>
 __device__ __forceinline__ void sample_store_uv2(float u, float v, bool ok, const GfwYuvPlane &PU, const GfwYuvPlane &PV,
-                                                 float bg_u, float bg_v, float lim_u, float lim_v, int ox, int oy) {
+                                                 float bg_u, float bg_v, float lim_u, float lim_v, int ox, int oy, unsigned long long *aud = nullptr) {
     float ou = bg_u, ov = bg_v;
     if (ok) {
         const Bins2 b = make_bins2(u, v);
         if (__builtin_expect((unsigned)b.sx < (unsigned)(PU.w - 1) && (unsigned)b.sy < (unsigned)(PU.h - 1), 1)) {
             const int off0 = b.sy * PU.src_stride + b.sx * (int)sizeof(T);
-            taps_inside2<T, 1>(PU.src, off0, PU.src_stride, b, lim_u, &ou);
-            taps_inside2<T, 1>(PV.src, off0, PU.src_stride, b, lim_v, &ov);
+            const int top = PU.src_len < PV.src_len ? PU.src_len : PV.src_len;
+            if (range_ok(aud, off0, 2 * sizeof(T), top) && range_ok(aud, (int64_t)off0 + PU.src_stride, 2 * sizeof(T), top)) {
+                taps_inside2<T, 1>(PU.src, off0, PU.src_stride, b, lim_u, &ou);
+                taps_inside2<T, 1>(PV.src, off0, PU.src_stride, b, lim_v, &ov);
+            }
         } else {
             taps_edge2<T, 1>(PU.src, PU.src_stride, b, PU.w, PU.h, &bg_u, lim_u, &ou);
             taps_edge2<T, 1>(PV.src, PU.src_stride, b, PU.w, PU.h, &bg_v, lim_v, &ov);
         }
     }
     const int doff = oy * PU.dst_stride + ox * (int)sizeof(T);
+    if (!range_ok(aud, doff, sizeof(T), PU.dst_len < PV.dst_len ? PU.dst_len : PV.dst_len)) return;
     store_px<T, 1>(PU.dst, doff, &ou);
     store_px<T, 1>(PV.dst, doff, &ov);
 }
@@ -549,7 +565,7 @@ __device__ __forceinline__ int pass1_exact(float ox, float oy, const Mid &M, con
 // approximate + certificate; returns false when the exact path must decide.
 // (ax, ay, aw) = ox*m0+m2, ox*m3+m5, ox*m6+m8 are per-lane constants of the pixel column.
 __device__ __forceinline__ bool pass1_fast(float ax, float ay, float aw, float oy, const Mid &M, const P1 &Q, const float2 *tab,
-                                           bool hrs, float rl2, int &sy, float &v_out) {
+                                           bool hrs, float rl2, int &sy, float &v_out, unsigned long long *aud = nullptr) {
     const float X = __builtin_fmaf(oy, M.m1, ax);
     const float Y = __builtin_fmaf(oy, M.m4, ay);
     const float W = __builtin_fmaf(oy, M.m7, aw);
@@ -564,6 +580,7 @@ __device__ __forceinline__ bool pass1_fast(float ax, float ay, float aw, float o
     }
     const float tpos = fminf(fmaxf(rho, 0.0f), Q.rho_max) * Q.rho_scale;   // clamped: a rejected lane still indexes the table
     const float ti = floorf(tpos);
+    if (aud && !((int)ti >= 0 && (int)ti <= GFW_P1_TABLE_N)) atomicAdd(&aud[5], 1ull);
     const float2 e = tab[(int)ti];
     const float s = __builtin_fmaf(tpos - ti, e.y, e.x);
     const float v = __builtin_fmaf((hrs ? a : b) * s, Q.f, Q.c);
@@ -652,7 +669,7 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
                         if (FAST1) {
                             float v_fast;
                             const float ax = __builtin_fmaf(ox, M.m0, M.m2), ay = __builtin_fmaf(ox, M.m3, M.m5), aw = __builtin_fmaf(ox, M.m6, M.m8);
-                            if (!pass1_fast(ax, ay, aw, oy, M, Q, A.p1_table, hrs, L.rl2, sy, v_fast)) {
+                            if (!pass1_fast(ax, ay, aw, oy, M, Q, A.p1_table, hrs, L.rl2, sy, v_fast, AUDIT ? A.audit : nullptr)) {
                                 const unsigned slot = atomicAdd(&q_n[wave], 1u);      // < QCAP: flushed below before it can fill
                                 q_x[wave][slot] = ox; q_y[wave][slot] = oy;
                                 q_dst[wave][slot] = (unsigned short)((lane << 6) | (r * NPX + k));
@@ -704,7 +721,11 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
                     const int sy = two_pass ? s_rows[r * NPX + k][tid] : default_row<MODEL>(ox, oy, A);
                     GfwPt p;
                     if (A.ablate & 8) { p.x = ox * 0.5f; p.y = oy * 0.5f; p.ok = true; }              // timing ablation only
-                    else p = rd_row<MODEL>(ox, oy, min(sy, A.matrix_count - 1), L, A);
+                    else {
+                        const int row = min(sy, A.matrix_count - 1);
+                        if (AUDIT && (unsigned)row >= (unsigned)A.matrix_count) atomicAdd(&A.audit[5], 1ull);
+                        p = rd_row<MODEL>(ox, oy, row, L, A);
+                    }
                     if (A.background_mode != 0 && p.ok) {                      // cpu_undistort.rs:495-509 (edge repeat / edge mirror)
                         const float width_f = (float)A.width, height_f = (float)A.height;
                         if (A.background_mode == 1) {
@@ -722,14 +743,14 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
                     if (k == 0) { u0 = p.x; v0 = p.y; ok0 = p.ok; }
                     const float lu = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(p.x, MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(p.y, MP.mul_ly, MP.den_y, MP.rcp_y);   // cpu_undistort.rs:511-514
                     if (A.ablate & 2) { if (lane == 99) A.pl[0].dst[0] = (uint8_t)(lu + lv); continue; }  // timing ablation only
-                    if (I == 2) sample_store2<T, N0>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly);
+                    if (I == 2) sample_store2<T, N0>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly, AUDIT ? A.audit : nullptr);
                     else sample_store<T, N0, I>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly, s_lut);
                 }
                 if (A.nplanes > 1 && !(A.ablate & 4)) {
                     const float cu = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(u0, MP.mul_cx, MP.den_x, MP.rcp_x), cv = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(v0, MP.mul_cy, MP.den_y, MP.rcp_y);
                     if (I == 2) {
-                        if (INTERLEAVED_UV) sample_store2<T, 2>(cu, cv, ok0, A.pl[1], bg_c, lim_u, cx, cy);
-                        else if (A.nplanes == 3) sample_store_uv2<T>(cu, cv, ok0, A.pl[1], A.pl[2], bg_c[0], bg_v, lim_u, lim_v, cx, cy);
+                        if (INTERLEAVED_UV) sample_store2<T, 2>(cu, cv, ok0, A.pl[1], bg_c, lim_u, cx, cy, AUDIT ? A.audit : nullptr);
+                        else if (A.nplanes == 3) sample_store_uv2<T>(cu, cv, ok0, A.pl[1], A.pl[2], bg_c[0], bg_v, lim_u, lim_v, cx, cy, AUDIT ? A.audit : nullptr);
                         else sample_store_shared2<T>(cu, cv, ok0, A.pl, 1, A.nplanes - 1, cx, cy);
                     } else {
                         if (INTERLEAVED_UV) sample_store<T, 2, I>(cu, cv, ok0, A.pl[1], bg_c, lim_u, cx, cy, s_lut);

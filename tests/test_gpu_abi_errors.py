@@ -99,3 +99,34 @@ def test_asynchronous_mode_with_many_frames_in_flight():
             w_bytes = pl["out_size"][0] * pl["params"].bytes_per_pixel
             got = d.cpu().numpy().reshape(h, stride)[:, :w_bytes]
             assert np.array_equal(r.reshape(h, stride)[:, :w_bytes], got)
+
+
+def test_malformed_mesh_header_is_rejected_before_launch():
+    """mesh[0] (offset of the focal-plane block) and mesh[1], mesh[2] (grid size) index device memory and private arrays;
+    the reference asserts on them (BivariateSpline::new, slice bounds).  A bad header is an error code, not a device fault."""
+    fr, pl, dst, b, be = setup()
+    try:
+        def mesh(n=839):
+            m = np.zeros(n, dtype=np.float32)
+            for i, v in ((1, 9), (2, 9), (3, 128), (4, 64), (7, 128), (8, 64)):
+                if i < n:
+                    m[i] = v
+            return m
+        bad = []
+        m = mesh(); m[0] = 500.0; m[1] = 12.0; bad.append(m)            # 12 x 9 grid: over the 9-element spline arrays
+        m = mesh(); m[0] = 500.0; m[2] = 1.0; bad.append(m)             # fewer than 2 rows
+        m = mesh(200); m[0] = 150.0; bad.append(m)                      # 9x9 grid needs 819 values
+        m = mesh(); m[0] = 5000.0; bad.append(m)                        # focal-plane block offset beyond the buffer
+        m = mesh(); m[0] = 830.0; m[1] = 2; m[2] = 2; m[830] = 1.0; bad.append(m)   # focal-plane block runs off the end
+        m = mesh(5); bad.append(m)                                      # shorter than the header
+        m = mesh(); m[0] = np.nan; bad.append(m)
+        for m in bad:
+            with pytest.raises(warp.GfwError) as e:
+                be.undistort_image(b, pl["params"], fr.matrices, m)
+            assert e.value.name == "BufferSizeMismatch" and "mesh" in str(e.value)
+            assert np.all(dst == 0x5A)
+        ok = mesh(); ok[0] = 0.0                                         # header says: no mesh, no focal-plane data
+        be.undistort_image(b, pl["params"], fr.matrices, ok)
+        assert not np.all(dst == 0x5A)
+    finally:
+        be.close()

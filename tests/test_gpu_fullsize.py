@@ -29,7 +29,7 @@ class _View:
             self.planes.append(q)
 
 
-def run_device_path(frames, stream_kind="torch"):
+def run_device_path(frames, stream_kind="torch", variant=0, audit_out=None):
     """Warp every frame the way bench.py does; returns [(frame, [src planes on host], [dst planes on host])]."""
     import torch
     dev = torch.device("cuda", 0)
@@ -50,12 +50,19 @@ def run_device_path(frames, stream_kind="torch"):
         be.set_stream(stream.cuda_stream)
         be.set_option(abi.OPT_SYNCHRONOUS, 0)
         be.set_option(abi.OPT_MATRICES_ON_DEVICE, 2)
+        if variant:
+            be.set_option(abi.OPT_KERNEL_VARIANT, variant)
+            be.get_audit(reset=True)
         calls = [warp.FrameCall(be, bufs[j], params[j], types, d_mat[j].data_ptr(), frames[j].matrices.shape[0]) for j in range(len(frames))]
         for rep in range(2):                              # twice: steady state, all frames in flight back to back
             for c in calls:
                 c()
         be.synchronize()
         backend = warp.last_backend()
+        if audit_out is not None:
+            arr = (C.c_ulonglong * 8)()
+            assert be.lib.gfw_get_audit(be.ctx, C.byref(arr), 0) == 0
+            audit_out.extend(int(v) for v in arr)
     finally:
         be.close()
     torch.cuda.synchronize(dev)
@@ -110,3 +117,20 @@ def test_c1_1080p_nv12_device_path():
     q = S.quat_from_euler_deg(5.0, 2.0, 3.0)
     frames = [S.SyntheticFrame("NV12", 1920, 1080, seed=0x9F10 + j, readout_ms=0.0, constant_quat=q, pixels=False) for j in range(2)]
     check(frames, "yuv_fused")
+
+
+def test_c2_full_size_address_audit():
+    """The audit instantiation of the fused kernel range-checks every tap, store, matrix-row and table address against the
+    buffer lengths the caller declared (and re-checks every first-pass certificate): nothing may fall outside on the
+    bench workload's geometry — 4K planes that end exactly on a page boundary, device-resident matrices."""
+    frames = [S.SyntheticFrame("YUV422P16LE", 3840, 2160, seed=0x9F10 + j, timestamp_ms=1000.0 + 33.3 * j, pixels=False) for j in (0, 17, 63)]
+    counters = []
+    backend, res = run_device_path(frames, variant=3, audit_out=counters)
+    assert backend == "yuv_fused_p1"
+    certified, wrong, queued, overflow, _, out_of_range = counters[:6]
+    assert certified + queued == 2 * len(frames) * 3840 * 2160 and wrong == 0 and overflow == 0
+    assert out_of_range == 0
+    for fr, src, dst in res:
+        ref = O.run_frame(_View(fr, src))
+        for p, (a, b) in enumerate(zip(ref, dst)):
+            assert_plane_equal(a, b, fr.planes[p]["pixel_type"], "audit plane %d" % p)

@@ -6,7 +6,8 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python bench.py --steps 60 --warmup 5 --no-cpu-baseline"
+export RANK=0 LOCAL_RANK=0 WORLD_SIZE=1   # bench.py as a worker itself (no launcher process between rocprofv3 and the kernels)
+CMD="python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-parity ${BENCH_EXTRA:-}"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o trace -- $CMD > $OUT/bench_trace.log 2>&1
 rocprofv3 -f csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc1 -o pmc1 -- $CMD > $OUT/bench_pmc1.log 2>&1
 rocprofv3 -f csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS -d $OUT/pmc2 -o pmc2 -- $CMD > $OUT/bench_pmc2.log 2>&1
@@ -15,3 +16,6 @@ rocprofv3 -f csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc4 -o pmc4 
 find $OUT -name "*.csv" | head -50
 python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+# keep the summary and the kernel-stats table; the raw per-dispatch CSVs (hundreds of MB with torch's set-up kernels) stay on the box
+mkdir -p $OUT/keep; find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/keep/ \;
+rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4
