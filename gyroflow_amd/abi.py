@@ -80,7 +80,14 @@ class FrameTiming(C.Structure):
     """``gfw_frame_timing``: inputs of the device-side per-row matrix builder."""
     _fields_ = [("timestamp_ms", C.c_double), ("per_frame_time_offset_ms", C.c_double), ("frame_readout_time_ms", C.c_double),
                 ("new_k", C.c_double * 9), ("video_rotation_deg", C.c_double), ("rows", C.c_int32), ("readout_dim", C.c_int32),
-                ("framebuffer_inverted", C.c_int32), ("pad_", C.c_int32)]
+                ("framebuffer_inverted", C.c_int32), ("suppress_rotation", C.c_int32)]
+
+
+class FrameStab(C.Structure):
+    """``gfw_frame_stab``: file_metadata.camera_stab_data[frame] (IBIS/OIS splines) for the device matrix builder."""
+    _fields_ = [("offset", C.c_double), ("sensor_size", C.c_double * 2), ("crop_area", C.c_double * 4), ("pixel_pitch", C.c_double * 2),
+                ("width", C.c_double), ("height", C.c_double), ("ibis_count", C.c_int32), ("ois_count", C.c_int32),
+                ("ibis", C.c_void_p), ("ois", C.c_void_p)]
 
 
 class BufferDesc(C.Structure):
@@ -135,6 +142,8 @@ def bind(lib):
     lib.gfw_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]; lib.gfw_get_profile.restype = i32
     lib.gfw_set_quaternion_tracks.argtypes = [vp, vp, vp, i32, vp, vp, i32]; lib.gfw_set_quaternion_tracks.restype = i32
     lib.gfw_build_matrices.argtypes = [vp, C.POINTER(FrameTiming), vp, C.POINTER(vp)]; lib.gfw_build_matrices.restype = i32
+    lib.gfw_build_matrices_stab.argtypes = [vp, C.POINTER(FrameTiming), C.POINTER(FrameStab), vp, C.POINTER(vp)]; lib.gfw_build_matrices_stab.restype = i32
+    lib.gfw_set_sync_offsets.argtypes = [vp, C.c_double, vp, vp, i32]; lib.gfw_set_sync_offsets.restype = i32
     lib.gfw_build_matrices_batch.argtypes = [vp, C.POINTER(FrameTiming), i32, C.POINTER(vp)]; lib.gfw_build_matrices_batch.restype = i32
     lib.gfw_stmap_undistort.argtypes = [vp, C.POINTER(KernelParams), vp, i32, vp, sz, i32, i32, vp, i32]; lib.gfw_stmap_undistort.restype = i32
     lib.gfw_undistort_points.argtypes = [vp, C.POINTER(KernelParams), vp, sz, i32, vp, i32, vp, i32, vp, sz, vp, i32]; lib.gfw_undistort_points.restype = i32
@@ -151,7 +160,7 @@ def bind(lib):
 
 EXPORTS = ["gfw_abi_version", "gfw_list_devices", "gfw_set_device", "gfw_get_info", "gfw_is_buffer_supported",
            "gfw_create", "gfw_destroy", "gfw_undistort_image", "gfw_undistort_frame", "gfw_set_option",
-           "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_last_backend", "gfw_get_profile", "gfw_last_error", "gfw_debug_math", "gfw_debug_selftest", "gfw_get_audit", "gfw_pack_matrices", "gfw_checksum64", "gfw_set_quaternion_tracks", "gfw_build_matrices", "gfw_build_matrices_batch", "gfw_stmap_undistort", "gfw_undistort_points",
+           "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_last_backend", "gfw_get_profile", "gfw_last_error", "gfw_debug_math", "gfw_debug_selftest", "gfw_get_audit", "gfw_pack_matrices", "gfw_checksum64", "gfw_set_quaternion_tracks", "gfw_build_matrices", "gfw_build_matrices_stab", "gfw_set_sync_offsets", "gfw_build_matrices_batch", "gfw_stmap_undistort", "gfw_undistort_points",
            "gfw_pixel_type_info"]
 
 

@@ -399,12 +399,65 @@ __device__ __forceinline__ void sample_store_shared(float u, float v, bool ok, c
     }
 }
 
+// ---- integer-dot taps for 8/16-bit planes ---------------------------------------------------------------------------------
+// A bilinear sample of an integer plane is sum = RN(RN(xs0*cy0) + RN(xs1*cy1)) with xs = p0*(1-k/32) + p1*k/32 exact
+// (cpu_undistort.rs:392-411).  xs*32 = p0*(32-k) + p1*k is ONE integer dot instruction on the raw loaded word
+// (v_dot2_u32_u16 / v_dot4_u32_u8), converted exactly (< 2^22), multiplied by the integer y weight and scaled by 2^-10 at the
+// end — power-of-two scaling commutes with round-to-nearest, so the two roundings are the reference's.
+typedef float gfw_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned short gfw_us2 __attribute__((ext_vector_type(2)));
+
+template <typename T, bool UV> struct HotTap;
+template <> struct HotTap<uint16_t, false> {                 // two u16 taps = one dword at a 2-byte aligned address
+    static constexpr int BYTES = 4, PX = 2;
+    typedef uint32_t u32u __attribute__((aligned(2)));
+    static __device__ __forceinline__ uint32_t load(const uint8_t *src, uint32_t off) { return *reinterpret_cast<const u32u *>(src + off); }
+    static __device__ __forceinline__ uint32_t wpack(uint32_t k) { return (32u - k) | (k << 16); }
+    static __device__ __forceinline__ uint32_t dot(uint32_t raw, uint32_t w) { return __builtin_amdgcn_udot2(__builtin_bit_cast(gfw_us2, raw), __builtin_bit_cast(gfw_us2, w), 0u, false); }
+};
+template <> struct HotTap<uint8_t, false> {                  // two u8 taps = one 16-bit word at any address
+    static constexpr int BYTES = 2, PX = 1;
+    typedef uint16_t u16u __attribute__((aligned(1)));
+    static __device__ __forceinline__ uint32_t load(const uint8_t *src, uint32_t off) { return *reinterpret_cast<const u16u *>(src + off); }
+    static __device__ __forceinline__ uint32_t wpack(uint32_t k) { return (32u - k) | (k << 8); }
+    static __device__ __forceinline__ uint32_t dot(uint32_t raw, uint32_t w) { return __builtin_amdgcn_udot4(raw, w, 0u, false); }
+};
+// interleaved chroma: (U0 V0 U1 V1)
+template <> struct HotTap<uint8_t, true> {                   // four bytes at a 2-byte aligned address
+    static constexpr int BYTES = 4, PX = 2;
+    typedef uint32_t u32u __attribute__((aligned(2)));
+    static __device__ __forceinline__ uint32_t load(const uint8_t *src, uint32_t off) { return *reinterpret_cast<const u32u *>(src + off); }
+    static __device__ __forceinline__ uint32_t wpack(uint32_t k) { return (32u - k) | (k << 16); }          // bytes 0 and 2 (U); << 8 for V
+    static __device__ __forceinline__ void dot(uint32_t raw, uint32_t w, uint32_t &u, uint32_t &v) {
+        u = __builtin_amdgcn_udot4(raw, w, 0u, false); v = __builtin_amdgcn_udot4(raw, w << 8, 0u, false);
+    }
+};
+template <> struct HotTap<uint16_t, true> {                  // eight bytes at a 4-byte aligned address
+    static constexpr int BYTES = 8, PX = 4;
+    typedef uint2 uint2a __attribute__((aligned(2)));
+    static __device__ __forceinline__ uint2 load(const uint8_t *src, uint32_t off) { return *reinterpret_cast<const uint2a *>(src + off); }
+    static __device__ __forceinline__ uint32_t wpack(uint32_t k) { return (32u - k) | (k << 16); }
+    static __device__ __forceinline__ void dot(uint2 raw, uint32_t w, uint32_t &u, uint32_t &v) {
+        const uint32_t uu = __builtin_amdgcn_perm(raw.y, raw.x, 0x05040100u);      // (U0, U1)
+        const uint32_t vv = __builtin_amdgcn_perm(raw.y, raw.x, 0x07060302u);      // (V0, V1)
+        u = __builtin_amdgcn_udot2(__builtin_bit_cast(gfw_us2, uu), __builtin_bit_cast(gfw_us2, w), 0u, false);
+        v = __builtin_amdgcn_udot2(__builtin_bit_cast(gfw_us2, vv), __builtin_bit_cast(gfw_us2, w), 0u, false);
+    }
+};
+__device__ __forceinline__ uint32_t hot_f2u(float v) { uint32_t r; asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(v)); return r; }
+// RN(RN(xs0*cy0) + RN(xs1*cy1)) from the two integer row sums (see the header comment), clamped by pixel_value_limit
+__device__ __forceinline__ uint32_t hot_blend(uint32_t i0, uint32_t i1, uint32_t ky, float limit) {
+    const float s = ((float)i0 * (float)(32u - ky) + (float)i1 * (float)ky) * 0.0009765625f;
+    return hot_f2u(min_limit(s, limit));
+}
+
 // ---- bilinear specialisation (I = 2): named weights, two-compare interior test — the hot configuration ---------------------------------------------------
-struct Bins2 { int sx, sy; float cx0, cx1, cy0, cy1; };
+struct Bins2 { int sx, sy; float cx0, cx1, cy0, cy1; uint32_t kx, ky; };
 __device__ __forceinline__ Bins2 make_bins2(float u, float v) {
     const int sx0 = round_i32(u * 32.0f), sy0 = round_i32(v * 32.0f);
     Bins2 b;
     b.sx = sx0 >> 5; b.sy = sy0 >> 5;
+    b.kx = (uint32_t)sx0 & 31u; b.ky = (uint32_t)sy0 & 31u;
     b.cx1 = (float)(sx0 & 31) * 0.03125f; b.cx0 = 1.0f - b.cx1;     // {1-k/32, k/32}: the LUT row (cpu_undistort.rs:14-19)
     b.cy1 = (float)(sy0 & 31) * 0.03125f; b.cy0 = 1.0f - b.cy1;
     return b;
@@ -479,8 +532,31 @@ __device__ __forceinline__ void sample_store2(float u, float v, bool ok, const G
         const Bins2 b = make_bins2(u, v);
         if (__builtin_expect((unsigned)b.sx < (unsigned)(P.w - 1) && (unsigned)b.sy < (unsigned)(P.h - 1), 1)) {
             const int off0 = b.sy * P.src_stride + b.sx * (int)(N * sizeof(T));
-            if (range_ok(aud, off0, 2 * N * sizeof(T), P.src_len) && range_ok(aud, (int64_t)off0 + P.src_stride, 2 * N * sizeof(T), P.src_len))
-                taps_inside2<T, N>(P.src, off0, P.src_stride, b, limit, out);
+            if (range_ok(aud, off0, 2 * N * sizeof(T), P.src_len) && range_ok(aud, (int64_t)off0 + P.src_stride, 2 * N * sizeof(T), P.src_len)) {
+                if constexpr (!is_f32<T>::value && (N == 1 || N == 2)) {
+                    // integer-dot taps: the pixel value comes out as an integer; store it and leave
+                    const uint32_t doff = (uint32_t)oy * (uint32_t)P.dst_stride + (uint32_t)ox * (uint32_t)(N * sizeof(T));
+                    if (!range_ok(aud, doff, N * sizeof(T), P.dst_len)) return;
+                    if constexpr (N == 1) {
+                        typedef HotTap<T, false> Tap;
+                        const uint32_t r0 = Tap::load(P.src, (uint32_t)off0), r1 = Tap::load(P.src, (uint32_t)off0 + (uint32_t)P.src_stride);
+                        const uint32_t w = Tap::wpack(b.kx);
+                        *reinterpret_cast<T *>(P.dst + doff) = (T)hot_blend(Tap::dot(r0, w), Tap::dot(r1, w), b.ky, limit);
+                    } else {
+                        typedef HotTap<T, true> Tap;
+                        const auto r0 = Tap::load(P.src, (uint32_t)off0), r1 = Tap::load(P.src, (uint32_t)off0 + (uint32_t)P.src_stride);
+                        const uint32_t w = Tap::wpack(b.kx);
+                        uint32_t u0, v0, u1, v1;
+                        Tap::dot(r0, w, u0, v0); Tap::dot(r1, w, u1, v1);
+                        const uint32_t ou = hot_blend(u0, u1, b.ky, limit), ov = hot_blend(v0, v1, b.ky, limit);
+                        T *d = reinterpret_cast<T *>(P.dst + doff);
+                        d[0] = (T)ou; d[1] = (T)ov;
+                    }
+                    return;
+                } else {
+                    taps_inside2<T, N>(P.src, off0, P.src_stride, b, limit, out);
+                }
+            }
         } else
             taps_edge2<T, N>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
     }
@@ -492,7 +568,7 @@ __device__ __forceinline__ void sample_store2(float u, float v, bool ok, const G
 template <typename T>
 __device__ __forceinline__ void sample_store_shared2(float u, float v, bool ok, const GfwYuvPlane *pl, int first, int last, int ox, int oy) {
     const GfwYuvPlane &P0 = pl[first];
-    Bins2 b = {0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
+    Bins2 b = {0, 0, 0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u};
     bool inside = false;
     int off0 = 0;
     if (ok) {
@@ -524,8 +600,20 @@ __device__ __forceinline__ void sample_store_uv2(float u, float v, bool ok, cons
             const int off0 = b.sy * PU.src_stride + b.sx * (int)sizeof(T);
             const int top = PU.src_len < PV.src_len ? PU.src_len : PV.src_len;
             if (range_ok(aud, off0, 2 * sizeof(T), top) && range_ok(aud, (int64_t)off0 + PU.src_stride, 2 * sizeof(T), top)) {
-                taps_inside2<T, 1>(PU.src, off0, PU.src_stride, b, lim_u, &ou);
-                taps_inside2<T, 1>(PV.src, off0, PU.src_stride, b, lim_v, &ov);
+                if constexpr (!is_f32<T>::value) {
+                    typedef HotTap<T, false> Tap;
+                    const uint32_t doff = (uint32_t)oy * (uint32_t)PU.dst_stride + (uint32_t)ox * (uint32_t)sizeof(T);
+                    if (!range_ok(aud, doff, sizeof(T), PU.dst_len < PV.dst_len ? PU.dst_len : PV.dst_len)) return;
+                    const uint32_t a0 = Tap::load(PU.src, (uint32_t)off0), a1 = Tap::load(PU.src, (uint32_t)off0 + (uint32_t)PU.src_stride);
+                    const uint32_t b0 = Tap::load(PV.src, (uint32_t)off0), b1 = Tap::load(PV.src, (uint32_t)off0 + (uint32_t)PU.src_stride);
+                    const uint32_t w = Tap::wpack(b.kx);
+                    *reinterpret_cast<T *>(PU.dst + doff) = (T)hot_blend(Tap::dot(a0, w), Tap::dot(a1, w), b.ky, lim_u);
+                    *reinterpret_cast<T *>(PV.dst + doff) = (T)hot_blend(Tap::dot(b0, w), Tap::dot(b1, w), b.ky, lim_v);
+                    return;
+                } else {
+                    taps_inside2<T, 1>(PU.src, off0, PU.src_stride, b, lim_u, &ou);
+                    taps_inside2<T, 1>(PV.src, off0, PU.src_stride, b, lim_v, &ov);
+                }
             }
         } else {
             taps_edge2<T, 1>(PU.src, PU.src_stride, b, PU.w, PU.h, &bg_u, lim_u, &ou);
@@ -763,6 +851,552 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
     }
 }
 
+
+// =====================================================================================================================
+// gfw_hot_kernel — the production configuration (opencv_fisheye, bilinear, 8/16-bit planar or semi-planar 4:2:2 / 4:2:0,
+// solid background) with a CERTIFIED SECOND PASS and integer-dot-product taps.
+//
+// Second pass.  The head of rotate_and_distort is evaluated exactly as the reference does (X, Y, W and the two correctly
+// rounded divisions: cpu_undistort.rs:134-137, opencv_fisheye.rs:73), so a = X/W and b = Y/W are the reference's bits.  The
+// expensive middle — r = sqrt(a^2+b^2), theta = atanf(r), the theta_d polynomial and the division theta_d/r
+// (opencv_fisheye.rs:77-93), two thirds of the exact projection's instructions — is replaced by s~ = S(rho~), rho~ = a^2+b^2,
+// read from the first pass's table, together with a RELATIVE bound kappa on |s~ - s_ref| (derivation in DESIGN.md section 2b:
+// every rounding of the reference's chain and of this one is accounted for; atanf's error constant is measured over all
+// positive floats, tests/test_math_host.py).  The rest of the chain — a*s, *f, +c, the source_rect map, *32, round — is made of
+// monotone non-decreasing steps (round-to-nearest is monotone, f > 0, mul > 0), so the 1/32-pixel bin is a monotone step
+// function of s: it is evaluated at s_lo = s~(1-kappa) and s_hi = s~(1+kappa) with the reference's own operations (packed,
+// two values per instruction), and if both ends land in the same bin — for x and y, and for the chroma site's bins when the
+// pixel carries one — that bin IS the reference's.  No error analysis of the tail is involved.  Pixels whose ends disagree
+// (a few percent) are queued per wave and resolved densely by the exact projection, like the first pass's rejects.
+// The audit instantiation recomputes the exact bins of EVERY accepted pixel and counts disagreements (there must be none).
+//
+// Taps.  A bilinear sample of an integer plane is sum = RN(RN(xs0*cy0) + RN(xs1*cy1)) with xs = p0*(1-k/32) + p1*k/32 exact
+// (cpu_undistort.rs:392-411).  Here xs*32 = p0*(32-k) + p1*k is ONE integer dot instruction on the raw loaded word
+// (v_dot2_u32_u16 / v_dot4_u32_u8), converted exactly (< 2^22), multiplied by the integer y weight and scaled by 2^-10 at the
+// end — power-of-two scaling commutes with round-to-nearest, so the two roundings are the reference's.
+// =====================================================================================================================
+#if GFW_FRAME_TAPS == 2 && GFW_FRAME_KIND != 4
+__device__ __forceinline__ Bins2 hot_bins2(int bx, int by) {
+    Bins2 b;
+    b.sx = bx >> 5; b.sy = by >> 5;
+    b.kx = (uint32_t)bx & 31u; b.ky = (uint32_t)by & 31u;
+    b.cx1 = (float)(bx & 31) * 0.03125f; b.cx0 = 1.0f - b.cx1;
+    b.cy1 = (float)(by & 31) * 0.03125f; b.cy0 = 1.0f - b.cy1;
+    return b;
+}
+// One single-channel sample from its 1/32-pixel bins (bx, by) = (round(u*32), round(v*32)): the pixel value as an integer.
+template <typename T>
+__device__ __forceinline__ uint32_t hot_sample(const GfwYuvPlane &P, int bx, int by, float bg, float limit, unsigned long long *aud) {
+    typedef HotTap<T, false> Tap;
+    const int sx = bx >> 5, sy = by >> 5;
+    if (__builtin_expect((unsigned)sx < (unsigned)(P.w - 1) && (unsigned)sy < (unsigned)(P.h - 1), 1)) {
+        const uint32_t off = (uint32_t)sy * (uint32_t)P.src_stride + (uint32_t)sx * (uint32_t)sizeof(T);
+        if (!range_ok(aud, off, Tap::BYTES, P.src_len) || !range_ok(aud, (int64_t)off + P.src_stride, Tap::BYTES, P.src_len)) return 0u;
+        const uint32_t r0 = Tap::load(P.src, off), r1 = Tap::load(P.src, off + (uint32_t)P.src_stride);
+        const uint32_t w = Tap::wpack((uint32_t)bx & 31u);
+        return hot_blend(Tap::dot(r0, w), Tap::dot(r1, w), (uint32_t)by & 31u, limit);
+    }
+    float o;
+    taps_edge2<T, 1>(P.src, P.src_stride, hot_bins2(bx, by), P.w, P.h, &bg, limit, &o);
+    return gfw_f2u_sat(o, sizeof(T) == 1 ? 255.0f : 65535.0f);
+}
+// The chroma site: two planar planes of identical geometry (U, V) sharing bins, or one interleaved UV plane.
+template <typename T, bool INTERLEAVED_UV>
+__device__ __forceinline__ void hot_sample_uv(const GfwYuvPlane &PU, const GfwYuvPlane &PV, int bx, int by, float bg_u, float bg_v, float lim_u, float lim_v,
+                                              uint32_t &ou, uint32_t &ov, unsigned long long *aud) {
+    const int sx = bx >> 5, sy = by >> 5;
+    const bool inside = (unsigned)sx < (unsigned)(PU.w - 1) && (unsigned)sy < (unsigned)(PU.h - 1);
+    ou = 0u; ov = 0u;
+    if (INTERLEAVED_UV) {
+        typedef HotTap<T, true> Tap;
+        if (__builtin_expect(inside, 1)) {
+            const uint32_t off = (uint32_t)sy * (uint32_t)PU.src_stride + (uint32_t)sx * (uint32_t)(2 * sizeof(T));
+            if (!range_ok(aud, off, Tap::BYTES, PU.src_len) || !range_ok(aud, (int64_t)off + PU.src_stride, Tap::BYTES, PU.src_len)) return;
+            const auto r0 = Tap::load(PU.src, off), r1 = Tap::load(PU.src, off + (uint32_t)PU.src_stride);
+            const uint32_t w = Tap::wpack((uint32_t)bx & 31u);
+            uint32_t u0, v0, u1, v1;
+            Tap::dot(r0, w, u0, v0); Tap::dot(r1, w, u1, v1);
+            ou = hot_blend(u0, u1, (uint32_t)by & 31u, lim_u);
+            ov = hot_blend(v0, v1, (uint32_t)by & 31u, lim_u);
+        } else {
+            float bg[2] = {bg_u, bg_v}, o[2];
+            taps_edge2<T, 2>(PU.src, PU.src_stride, hot_bins2(bx, by), PU.w, PU.h, bg, lim_u, o);
+            ou = gfw_f2u_sat(o[0], sizeof(T) == 1 ? 255.0f : 65535.0f); ov = gfw_f2u_sat(o[1], sizeof(T) == 1 ? 255.0f : 65535.0f);
+        }
+    } else {
+        typedef HotTap<T, false> Tap;
+        if (__builtin_expect(inside, 1)) {
+            const uint32_t off = (uint32_t)sy * (uint32_t)PU.src_stride + (uint32_t)sx * (uint32_t)sizeof(T);
+            const int top = PU.src_len < PV.src_len ? PU.src_len : PV.src_len;
+            if (!range_ok(aud, off, Tap::BYTES, top) || !range_ok(aud, (int64_t)off + PU.src_stride, Tap::BYTES, top)) return;
+            const uint32_t a0 = Tap::load(PU.src, off), a1 = Tap::load(PU.src, off + (uint32_t)PU.src_stride);
+            const uint32_t b0 = Tap::load(PV.src, off), b1 = Tap::load(PV.src, off + (uint32_t)PU.src_stride);
+            const uint32_t w = Tap::wpack((uint32_t)bx & 31u);
+            ou = hot_blend(Tap::dot(a0, w), Tap::dot(a1, w), (uint32_t)by & 31u, lim_u);
+            ov = hot_blend(Tap::dot(b0, w), Tap::dot(b1, w), (uint32_t)by & 31u, lim_v);
+        } else {
+            float o;
+            const Bins2 b = hot_bins2(bx, by);
+            taps_edge2<T, 1>(PU.src, PU.src_stride, b, PU.w, PU.h, &bg_u, lim_u, &o); ou = gfw_f2u_sat(o, sizeof(T) == 1 ? 255.0f : 65535.0f);
+            taps_edge2<T, 1>(PV.src, PU.src_stride, b, PU.w, PU.h, &bg_v, lim_v, &o); ov = gfw_f2u_sat(o, sizeof(T) == 1 ? 255.0f : 65535.0f);
+        }
+    }
+}
+template <typename T, bool INTERLEAVED_UV>
+__device__ __forceinline__ void hot_store_uv(const GfwYuvPlane &PU, const GfwYuvPlane &PV, int cx, int cy, uint32_t ou, uint32_t ov, unsigned long long *aud) {
+    if (INTERLEAVED_UV) {
+        const uint32_t doff = (uint32_t)cy * (uint32_t)PU.dst_stride + (uint32_t)cx * (uint32_t)(2 * sizeof(T));
+        if (!range_ok(aud, doff, 2 * sizeof(T), PU.dst_len)) return;
+        if (sizeof(T) == 2) *reinterpret_cast<uint32_t *>(PU.dst + doff) = ou | (ov << 16);
+        else *reinterpret_cast<uint16_t *>(PU.dst + doff) = (uint16_t)(ou | (ov << 8));
+    } else {
+        const uint32_t doff = (uint32_t)cy * (uint32_t)PU.dst_stride + (uint32_t)cx * (uint32_t)sizeof(T);
+        if (!range_ok(aud, doff, sizeof(T), PU.dst_len < PV.dst_len ? PU.dst_len : PV.dst_len)) return;
+        *reinterpret_cast<T *>(PU.dst + doff) = (T)ou;
+        *reinterpret_cast<T *>(PV.dst + doff) = (T)ov;
+    }
+}
+
+struct HotQ { float rho_max, rho_scale, kappa; };
+// Uniform constants of the tail, as (x, y) pairs: the packed instructions take them as natural 64-bit scalar operands.
+struct HotC { gfw_f2 f, c, mul_l, mul_c, nden, rcp; };
+__device__ __forceinline__ gfw_f2 hot_map2(gfw_f2 x, gfw_f2 mul, gfw_f2 nden, gfw_f2 rcp) {      // map_c on (x, y)
+    const gfw_f2 a = x * mul;
+    const gfw_f2 q0 = a * rcp;
+    const gfw_f2 r0 = __builtin_elementwise_fma(nden, q0, a);
+    return __builtin_elementwise_fma(r0, rcp, q0);
+}
+__device__ __forceinline__ void hot_bins(gfw_f2 xy, int &bx, int &by) {                           // round(x*32), round(y*32)
+    const gfw_f2 g = xy * 32.0f;
+    bx = round_i32(g.x); by = round_i32(g.y);
+}
+// Byte-offset addressing from a uniform base: a 32-bit lane offset on top of a scalar base register pair.
+template <typename V>
+__device__ __forceinline__ V hot_ld(const void *base, uint32_t byte_off) { return *reinterpret_cast<const V *>(reinterpret_cast<const uint8_t *>(base) + byte_off); }
+
+// Second pass of one pixel with the matrix row at byte offset `moff`: exact head, certified middle, exact two-point tail.
+//   ok  : the reference's validity (w > 0, r_limit) — exact
+//   acc : every bin below is certified; otherwise the exact path must decide
+__device__ __forceinline__ void hot_project(float ox, float oy, const float *matrices, uint32_t moff, float rl2, const HotC &K, const HotQ &Q, const float2 *tab,
+                                            bool with_chroma, bool &ok, bool &acc, int &bx, int &by, int &cbx, int &cby, unsigned long long *aud, int ablate = 0) {
+    const float4 ma = hot_ld<float4>(matrices, moff), mb = hot_ld<float4>(matrices, moff + 16u);
+    const float m8 = hot_ld<float>(matrices, moff + 32u);
+    const float X = (ox * ma.x) + (oy * ma.y) + ma.z;                  // cpu_undistort.rs:134-136 (translation3d == 0)
+    const float Y = (ox * ma.w) + (oy * mb.x) + mb.y;
+    const float W = (ox * mb.z) + (oy * mb.w) + m8;
+    ok = W > 0.0f;
+    if (rl2 > 0.0f && (X * X + Y * Y) > rl2 * W) ok = false;           // :139
+    const float mag = fmaxf(fmaxf(fabsf(X), fabsf(Y)), W);
+    const bool lean = (mag <= 524288.0f) && (W >= 9.5367431640625e-07f);      // proven operand range of the lean divide
+    gfw_f2 ab;
+    { float a, b; LeanOps::div2(X, Y, W, a, b); ab.x = a; ab.y = b; }  // opencv_fisheye.rs:73 — the reference's a, b
+    const float rho = __builtin_fmaf(ab.x, ab.x, ab.y * ab.y);
+    const float tpos = fminf(rho, Q.rho_max) * Q.rho_scale;            // a NaN / oversized rho still indexes the table; `acc` rejects it
+    const float ti = floorf(tpos);
+    if (aud && !((int)ti >= 0 && (int)ti <= GFW_P1_TABLE_N)) atomicAdd(&aud[5], 1ull);
+    float2 e = float2{1.0f, 0.0f};
+    if (!(ablate & 16)) e = hot_ld<float2>(tab, (uint32_t)(int)ti * 8u);
+    const float s = __builtin_fmaf(tpos - ti, e.y, e.x);
+    const float s_lo = __builtin_fmaf(-s, Q.kappa, s), s_hi = __builtin_fmaf(s, Q.kappa, s);
+    const gfw_f2 p_lo = ((ab * s_lo) * K.f) + K.c;                     // opencv_fisheye.rs:94, cpu_undistort.rs:155,167 at s_lo
+    const gfw_f2 p_hi = ((ab * s_hi) * K.f) + K.c;                     // ... and at s_hi
+    int bx2, by2;
+    hot_bins(hot_map2(p_lo, K.mul_l, K.nden, K.rcp), bx, by);          // :511-514, :380-381
+    hot_bins(hot_map2(p_hi, K.mul_l, K.nden, K.rcp), bx2, by2);
+    acc = lean & (rho < Q.rho_max) & (bx == bx2) & (by == by2);
+    cbx = 0; cby = 0;
+    if (with_chroma) {
+        hot_bins(hot_map2(p_lo, K.mul_c, K.nden, K.rcp), cbx, cby);
+        hot_bins(hot_map2(p_hi, K.mul_c, K.nden, K.rcp), bx2, by2);
+        acc &= (cbx == bx2) & (cby == by2);
+    }
+}
+// ---- the lane's two horizontally adjacent pixels at once: loads of both pixels are in flight together and the head runs
+// packed across the pair (same operations, same order, per element) --------------------------------------------------------
+struct HotPair { bool ok[2], acc[2]; int bx[2], by[2], cbx, cby; };
+__device__ __forceinline__ void hot_project_pair(gfw_f2 ox, float oy, const float *matrices, uint32_t moff0, uint32_t moff1, float rl2, const HotC &K,
+                                                 const HotQ &Q, const float2 *tab, bool with_chroma, HotPair &R, unsigned long long *aud) {
+    const float4 ma0 = hot_ld<float4>(matrices, moff0), mb0 = hot_ld<float4>(matrices, moff0 + 16u);
+    const float4 ma1 = hot_ld<float4>(matrices, moff1), mb1 = hot_ld<float4>(matrices, moff1 + 16u);
+    const float m80 = hot_ld<float>(matrices, moff0 + 32u), m81 = hot_ld<float>(matrices, moff1 + 32u);
+    const gfw_f2 oyv = {oy, oy};
+    const gfw_f2 X = ((ox * gfw_f2{ma0.x, ma1.x}) + (oyv * gfw_f2{ma0.y, ma1.y})) + gfw_f2{ma0.z, ma1.z};      // cpu_undistort.rs:134-136
+    const gfw_f2 Y = ((ox * gfw_f2{ma0.w, ma1.w}) + (oyv * gfw_f2{mb0.x, mb1.x})) + gfw_f2{mb0.y, mb1.y};
+    const gfw_f2 W = ((ox * gfw_f2{mb0.z, mb1.z}) + (oyv * gfw_f2{mb0.w, mb1.w})) + gfw_f2{m80, m81};
+    R.ok[0] = W.x > 0.0f; R.ok[1] = W.y > 0.0f;
+    if (rl2 > 0.0f) {                                                                                           // :139
+        const gfw_f2 lhs = (X * X) + (Y * Y), rhs = W * rl2;
+        R.ok[0] = R.ok[0] && !(lhs.x > rhs.x); R.ok[1] = R.ok[1] && !(lhs.y > rhs.y);
+    }
+    const bool lean0 = (fmaxf(fmaxf(fabsf(X.x), fabsf(Y.x)), W.x) <= 524288.0f) && (W.x >= 9.5367431640625e-07f);
+    const bool lean1 = (fmaxf(fmaxf(fabsf(X.y), fabsf(Y.y)), W.y) <= 524288.0f) && (W.y >= 9.5367431640625e-07f);
+    // gfw_rcp_prepare + gfw_div_prepared (gfw_fastmath.h), element-wise: the correctly rounded X/W and Y/W inside the lean range
+    const gfw_f2 r0 = {gfw_hw_rcp(W.x), gfw_hw_rcp(W.y)};
+    const gfw_f2 one = {1.0f, 1.0f};
+    const gfw_f2 rr = __builtin_elementwise_fma(__builtin_elementwise_fma(-W, r0, one), r0, r0);
+    const gfw_f2 qa = X * rr, qb = Y * rr;
+    const gfw_f2 a = __builtin_elementwise_fma(__builtin_elementwise_fma(-W, qa, X), rr, qa);
+    const gfw_f2 b = __builtin_elementwise_fma(__builtin_elementwise_fma(-W, qb, Y), rr, qb);
+    const gfw_f2 rho = __builtin_elementwise_fma(a, a, b * b);
+    const gfw_f2 tpos = gfw_f2{fminf(rho.x, Q.rho_max), fminf(rho.y, Q.rho_max)} * Q.rho_scale;   // NaN / oversized rho still index the table; acc rejects
+    const gfw_f2 ti = {floorf(tpos.x), floorf(tpos.y)};
+    if (aud && !((int)ti.x >= 0 && (int)ti.x <= GFW_P1_TABLE_N && (int)ti.y >= 0 && (int)ti.y <= GFW_P1_TABLE_N)) atomicAdd(&aud[5], 1ull);
+    const float2 e0 = hot_ld<float2>(tab, (uint32_t)(int)ti.x * 8u), e1 = hot_ld<float2>(tab, (uint32_t)(int)ti.y * 8u);
+    const gfw_f2 s = __builtin_elementwise_fma(tpos - ti, gfw_f2{e0.y, e1.y}, gfw_f2{e0.x, e1.x});
+    const gfw_f2 kap = {Q.kappa, Q.kappa};
+    const gfw_f2 s_lo = __builtin_elementwise_fma(-s, kap, s), s_hi = __builtin_elementwise_fma(s, kap, s);
+    R.cbx = 0; R.cby = 0;
+    #pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const gfw_f2 ab = {i ? a.y : a.x, i ? b.y : b.x};
+        const float lo = i ? s_lo.y : s_lo.x, hi = i ? s_hi.y : s_hi.x;
+        const gfw_f2 p_lo = ((ab * lo) * K.f) + K.c;                   // opencv_fisheye.rs:94, cpu_undistort.rs:155,167 at s_lo
+        const gfw_f2 p_hi = ((ab * hi) * K.f) + K.c;                   // ... and at s_hi
+        int bx2, by2;
+        hot_bins(hot_map2(p_lo, K.mul_l, K.nden, K.rcp), R.bx[i], R.by[i]);          // :511-514, :380-381
+        hot_bins(hot_map2(p_hi, K.mul_l, K.nden, K.rcp), bx2, by2);
+        R.acc[i] = (i ? lean1 : lean0) & ((i ? rho.y : rho.x) < Q.rho_max) & (R.bx[i] == bx2) & (R.by[i] == by2);
+        if (i == 0 && with_chroma) {
+            hot_bins(hot_map2(p_lo, K.mul_c, K.nden, K.rcp), R.cbx, R.cby);
+            hot_bins(hot_map2(p_hi, K.mul_c, K.nden, K.rcp), bx2, by2);
+            R.acc[0] &= (R.cbx == bx2) & (R.cby == by2);
+        }
+    }
+}
+// Branch-free interior sample: the loads are issued whatever the lane's state (offset 0 when the taps are not all inside)
+// so that every sample of the pair is in flight together; `inside` tells the caller whether the value is the real one.
+template <typename T>
+__device__ __forceinline__ uint32_t hot_sample_free(const GfwYuvPlane &P, int pw, int ph, int bx, int by, float limit, bool &inside, unsigned long long *aud) {
+    typedef HotTap<T, false> Tap;
+    const int sx = bx >> 5, sy = by >> 5;
+    inside = (unsigned)sx < (unsigned)(pw - 1) && (unsigned)sy < (unsigned)(ph - 1);
+    uint32_t off = inside ? (uint32_t)sy * (uint32_t)P.src_stride + (uint32_t)sx * (uint32_t)sizeof(T) : 0u;
+    if (!range_ok(aud, off, Tap::BYTES, P.src_len) || !range_ok(aud, (int64_t)off + P.src_stride, Tap::BYTES, P.src_len)) off = 0u;
+    const uint32_t r0 = Tap::load(P.src, off), r1 = Tap::load(P.src, off + (uint32_t)P.src_stride);
+    const uint32_t w = Tap::wpack((uint32_t)bx & 31u);
+    return hot_blend(Tap::dot(r0, w), Tap::dot(r1, w), (uint32_t)by & 31u, limit);
+}
+template <typename T, bool INTERLEAVED_UV>
+__device__ __forceinline__ void hot_sample_uv_free(const GfwYuvPlane &PU, const GfwYuvPlane &PV, int bx, int by, float lim_u, float lim_v,
+                                                   uint32_t &ou, uint32_t &ov, bool &inside, unsigned long long *aud) {
+    const int sx = bx >> 5, sy = by >> 5;
+    inside = (unsigned)sx < (unsigned)(PU.w - 1) && (unsigned)sy < (unsigned)(PU.h - 1);
+    if (INTERLEAVED_UV) {
+        typedef HotTap<T, true> Tap;
+        uint32_t off = inside ? (uint32_t)sy * (uint32_t)PU.src_stride + (uint32_t)sx * (uint32_t)(2 * sizeof(T)) : 0u;
+        if (!range_ok(aud, off, Tap::BYTES, PU.src_len) || !range_ok(aud, (int64_t)off + PU.src_stride, Tap::BYTES, PU.src_len)) off = 0u;
+        const auto r0 = Tap::load(PU.src, off), r1 = Tap::load(PU.src, off + (uint32_t)PU.src_stride);
+        const uint32_t w = Tap::wpack((uint32_t)bx & 31u);
+        uint32_t u0, v0, u1, v1;
+        Tap::dot(r0, w, u0, v0); Tap::dot(r1, w, u1, v1);
+        ou = hot_blend(u0, u1, (uint32_t)by & 31u, lim_u);
+        ov = hot_blend(v0, v1, (uint32_t)by & 31u, lim_u);
+    } else {
+        typedef HotTap<T, false> Tap;
+        uint32_t off = inside ? (uint32_t)sy * (uint32_t)PU.src_stride + (uint32_t)sx * (uint32_t)sizeof(T) : 0u;
+        const int top = PU.src_len < PV.src_len ? PU.src_len : PV.src_len;
+        if (!range_ok(aud, off, Tap::BYTES, top) || !range_ok(aud, (int64_t)off + PU.src_stride, Tap::BYTES, top)) off = 0u;
+        const uint32_t a0 = Tap::load(PU.src, off), a1 = Tap::load(PU.src, off + (uint32_t)PU.src_stride);
+        const uint32_t b0 = Tap::load(PV.src, off), b1 = Tap::load(PV.src, off + (uint32_t)PU.src_stride);
+        const uint32_t w = Tap::wpack((uint32_t)bx & 31u);
+        ou = hot_blend(Tap::dot(a0, w), Tap::dot(a1, w), (uint32_t)by & 31u, lim_u);
+        ov = hot_blend(Tap::dot(b0, w), Tap::dot(b1, w), (uint32_t)by & 31u, lim_v);
+    }
+}
+
+// First pass of the lane's two horizontally adjacent pixels at once (packed): the certified table-driven row pick of
+// pass1_fast, element-wise.  good[i] false -> the exact path decides that pixel's row.
+__device__ __forceinline__ void hot_pass1_pair(gfw_f2 ox, float oy, const Mid &M, const P1 &Q, const float2 *tab, bool hrs, float rl2,
+                                               int &sy0, int &sy1, bool &good0, bool &good1, gfw_f2 &v_out, unsigned long long *aud) {
+    const gfw_f2 oyv = {oy, oy};
+    const gfw_f2 X = __builtin_elementwise_fma(oyv, gfw_f2{M.m1, M.m1}, __builtin_elementwise_fma(ox, gfw_f2{M.m0, M.m0}, gfw_f2{M.m2, M.m2}));
+    const gfw_f2 Y = __builtin_elementwise_fma(oyv, gfw_f2{M.m4, M.m4}, __builtin_elementwise_fma(ox, gfw_f2{M.m3, M.m3}, gfw_f2{M.m5, M.m5}));
+    const gfw_f2 W = __builtin_elementwise_fma(oyv, gfw_f2{M.m7, M.m7}, __builtin_elementwise_fma(ox, gfw_f2{M.m6, M.m6}, gfw_f2{M.m8, M.m8}));
+    const gfw_f2 rw = {gfw_hw_rcp(W.x), gfw_hw_rcp(W.y)};
+    const gfw_f2 a = X * rw, b = Y * rw;
+    const gfw_f2 rho = __builtin_elementwise_fma(a, a, b * b);
+    bool g0 = (W.x > 0.0009765625f) & (rho.x < Q.rho_max), g1 = (W.y > 0.0009765625f) & (rho.y < Q.rho_max);
+    if (rl2 > 0.0f) {                                              // :139 — decide only when clear of the boundary
+        const gfw_f2 lhs = __builtin_elementwise_fma(X, X, Y * Y), rhs = W * (rl2 * 0.9999f);
+        g0 &= lhs.x < rhs.x; g1 &= lhs.y < rhs.y;
+    }
+    const gfw_f2 tpos = gfw_f2{fminf(fmaxf(rho.x, 0.0f), Q.rho_max), fminf(fmaxf(rho.y, 0.0f), Q.rho_max)} * Q.rho_scale;
+    const gfw_f2 ti = {floorf(tpos.x), floorf(tpos.y)};
+    if (aud && !((int)ti.x >= 0 && (int)ti.x <= GFW_P1_TABLE_N && (int)ti.y >= 0 && (int)ti.y <= GFW_P1_TABLE_N)) atomicAdd(&aud[5], 1ull);
+    const float2 e0 = hot_ld<float2>(tab, (uint32_t)(int)ti.x * 8u), e1 = hot_ld<float2>(tab, (uint32_t)(int)ti.y * 8u);
+    const gfw_f2 s = __builtin_elementwise_fma(tpos - ti, gfw_f2{e0.y, e1.y}, gfw_f2{e0.x, e1.x});
+    const gfw_f2 v = __builtin_elementwise_fma((hrs ? a : b) * s, gfw_f2{Q.f, Q.f}, gfw_f2{Q.c, Q.c});
+    v_out = v;
+    const gfw_f2 g = v - 0.5f;
+    const gfw_f2 d = g - gfw_f2{rintf(g.x), rintf(g.y)};           // distance of v to the nearest half-integer
+    const bool out0 = !(v.x > -0.25f) | !(v.x < Q.lim + 0.25f), out1 = !(v.y > -0.25f) | !(v.y < Q.lim + 0.25f);   // there the clamp decides
+    good0 = g0 & (out0 | (fabsf(d.x) > Q.eps)) & (v.x == v.x);
+    good1 = g1 & (out1 | (fabsf(d.y) > Q.eps)) & (v.y == v.y);
+    sy0 = max(min(gfw_f2i(rintf(v.x)), (int)Q.lim), 0);
+    sy1 = max(min(gfw_f2i(rintf(v.y)), (int)Q.lim), 0);
+}
+
+// The kernel-argument segment as scalar-addressable constant memory: rare paths read their uniforms from here at the point
+// of use instead of keeping them in (scarce) scalar registers across the pixel loop.
+#ifndef GFW_HOT_ABLATE
+#define GFW_HOT_ABLATE 0          // timing experiments only (wrong output): 1 no first pass, 2 no taps, 4 no exact resolve, 8 accept everything, 64 no luma store
+#endif
+typedef const GfwYuvArgs __attribute__((address_space(4))) *HotKArgs;
+#define GFW_OPAQUE(p) asm volatile("" : "+s"(p))
+
+template <typename T, int DH, bool INTERLEAVED_UV, bool AUDIT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void gfw_hot_kernel(const GfwYuvArgs A) {
+    constexpr int MODEL = GFW_MODEL_OPENCV_FISHEYE, DW = 2, RB = GFW_YUV_RB_FAST;
+    constexpr int NPX = DW * DH;
+    constexpr unsigned QCAP = 256;                 // ring of deferred pixels per wave: <= 63 pending + <= 128 new per step
+    static_assert(RB * NPX <= 64, "slot index must fit 6 bits");
+    __shared__ unsigned q_id[4][QCAP];             // (tile << 12) | (lane << 6) | (r * NPX + k)
+    __shared__ unsigned short q_sy[4][QCAP];       // certified rolling-shutter row, or 0xFFFF: the exact first pass decides
+    __shared__ unsigned q_tail[4];
+    __shared__ unsigned short s_sy[RB * DH][2][256];   // phase 1 -> phase 2: certified row of each pixel, 0xFFFF = not certified (lane-private slots)
+    const int wave = threadIdx.y, lane = threadIdx.x, tid = wave * 64 + lane;
+    const bool two_pass = A.matrix_count > 1;
+    const bool hrs = A.hrs != 0;
+    unsigned long long *const aud = AUDIT ? A.audit : nullptr;
+    HotKArgs Ak = (HotKArgs)__builtin_amdgcn_kernarg_segment_ptr();
+
+    const float t2x = A.t2[0], t2y = A.t2[1], rl2 = A.r_limit_sq;
+    const float bg_y = A.pl[0].bg[0], lim_y = A.pl[0].limit;
+    const float bg_u = A.pl[1].bg[0], lim_u = A.pl[1].limit;
+    const float bg_v = INTERLEAVED_UV ? A.pl[1].bg[1] : A.pl[2].bg[0], lim_v = INTERLEAVED_UV ? A.pl[1].limit : A.pl[2].limit;
+    const GfwYuvPlane &PY = A.pl[0], &PU = A.pl[1], &PV = A.pl[INTERLEAVED_UV ? 1 : 2];
+    const HotQ Q2{A.p1_rho_max, A.p1_rho_scale, A.p2_kappa};
+    const HotC K{gfw_f2{A.f[0], A.f[1]}, gfw_f2{A.c[0], A.c[1]}, gfw_f2{A.map_lx.mul, A.map_ly.mul}, gfw_f2{A.map_cx.mul, A.map_cy.mul},
+                 gfw_f2{-A.map_lx.den, -A.map_ly.den}, gfw_f2{A.map_lx.rcp, A.map_ly.rcp}};
+    constexpr float top_f = sizeof(T) == 1 ? 255.0f : 65535.0f;
+    const int row_lim = hrs ? A.width : A.height;
+    Mid M{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    P1 Q1{0, 0, 0, 0, 0, 0};
+    if (two_pass) {
+        const float *mid = A.matrices + (size_t)(A.matrix_count >> 1) * GFW_MAT_STRIDE;       // wave-uniform -> scalar loads
+        M = Mid{mid[0], mid[1], mid[2], mid[3], mid[4], mid[5], mid[6], mid[7], mid[8]};
+        Q1 = P1{A.p1_rho_max, A.p1_rho_scale, A.p1_eps, A.p1_f, A.p1_c, (float)row_lim};
+    }
+
+    // ---- the exact path: `n` deferred pixels starting at ring position `head`, one per lane ------------------------------
+    auto resolve = [&](unsigned head, unsigned n) {
+        if ((unsigned)lane >= n) return;
+        const unsigned idx = (head + (unsigned)lane) & (QCAP - 1u);
+        const unsigned id = q_id[wave][idx];
+        int sy = (int)q_sy[wave][idx];
+        HotKArgs P = Ak;
+        GFW_OPAQUE(P);                                           // uniforms of this path are read here, not carried through the pixel loop
+        const int t = (int)(id >> 12), ql = (int)((id >> 6) & 63u), slot = (int)(id & 63u);
+        const int r = slot / NPX, k = slot - r * NPX, i = k % DW, j = k / DW;
+        const int tiles_x = P->tiles_x;
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int cx = tx * 64 + ql, cy = (ty * 4 + wave) * RB + r;
+        const int lx = cx * DW + i, ly = cy * DH + j;
+        const float ox = (float)lx + t2x, oy = (float)ly + t2y;
+        Lens L;
+        L.f0 = P->f[0]; L.f1 = P->f[1]; L.c0 = P->c[0]; L.c1 = P->c[1];
+        L.k0 = P->k[0]; L.k1 = P->k[1]; L.k2 = P->k[2]; L.k3 = P->k[3];
+        L.t2x = t2x; L.t2y = t2y; L.rl2 = rl2;
+        const float *matrices = P->matrices;
+        const int mc = P->matrix_count;
+        if (sy == 0xFFFF) {                                      // the first pass was not certified either: cpu_undistort.rs:465-479
+            const float *mid = matrices + (size_t)(mc >> 1) * GFW_MAT_STRIDE;
+            const Mid M{mid[0], mid[1], mid[2], mid[3], mid[4], mid[5], mid[6], mid[7], mid[8]};
+            sy = max(min(round_i32(hrs ? ox : oy), row_lim), 0);
+            const float X = (ox * M.m0) + (oy * M.m1) + M.m2, Y = (ox * M.m3) + (oy * M.m4) + M.m5, W = (ox * M.m6) + (oy * M.m7) + M.m8;
+            if (W > 0.0f && !(rl2 > 0.0f && (X * X + Y * Y) > rl2 * W)) {
+                float u, v;
+                const float mag = fmaxf(fmaxf(fabsf(X), fabsf(Y)), W);
+                if (__builtin_expect((mag <= 524288.0f) && (W >= 9.5367431640625e-07f), 1)) fisheye_project<LeanOps>(X, Y, W, L, false, u, v);
+                else fisheye_project<IeeeOps>(X, Y, W, L, false, u, v);
+                sy = max(min(round_i32(hrs ? u : v), row_lim), 0);
+            }
+        }
+        const float *m = matrices + (size_t)min(sy, mc - 1) * GFW_MAT_STRIDE;
+        const float4 ma = *reinterpret_cast<const float4 *>(m), mb = *reinterpret_cast<const float4 *>(m + 4);
+        const float X = (ox * ma.x) + (oy * ma.y) + ma.z, Y = (ox * ma.w) + (oy * mb.x) + mb.y, W = (ox * mb.z) + (oy * mb.w) + m[8];
+        bool ok = W > 0.0f;
+        if (rl2 > 0.0f && (X * X + Y * Y) > rl2 * W) ok = false;
+        float u = 0.0f, v = 0.0f;
+        if (ok) {
+            const float mag = fmaxf(fmaxf(fabsf(X), fabsf(Y)), W);
+            if (__builtin_expect((mag <= 524288.0f) && (W >= 9.5367431640625e-07f), 1)) fisheye_project<LeanOps>(X, Y, W, L, false, u, v);
+            else fisheye_project<IeeeOps>(X, Y, W, L, false, u, v);
+        }
+        const gfw_f2 uv = {u, v};
+        int bx, by;
+        hot_bins(hot_map2(uv, K.mul_l, K.nden, K.rcp), bx, by);
+        const uint32_t val = ok ? hot_sample<T>(PY, bx, by, bg_y, lim_y, aud) : gfw_f2u_sat(bg_y, top_f);
+        const uint32_t doff = (uint32_t)ly * (uint32_t)PY.dst_stride + (uint32_t)lx * (uint32_t)sizeof(T);
+        if (range_ok(aud, doff, sizeof(T), PY.dst_len)) *reinterpret_cast<T *>(PY.dst + doff) = (T)val;
+        if (k == 0) {
+            uint32_t ou = gfw_f2u_sat(bg_u, top_f), ov = gfw_f2u_sat(bg_v, top_f);
+            if (ok) {
+                int cbx, cby;
+                hot_bins(hot_map2(uv, K.mul_c, K.nden, K.rcp), cbx, cby);
+                hot_sample_uv<T, INTERLEAVED_UV>(PU, PV, cbx, cby, bg_u, bg_v, lim_u, lim_v, ou, ov, aud);
+            }
+            hot_store_uv<T, INTERLEAVED_UV>(PU, PV, cx, cy, ou, ov, aud);
+        }
+    };
+
+    if (lane == 0) q_tail[wave] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    unsigned head = 0;                                           // wave-uniform: entries [head, tail) of the ring are pending
+
+    const int n_tiles = A.tiles_x * A.tiles_y;
+    const int per_xcd = (n_tiles + 7) >> 3;
+    const int wg_per_xcd = (int)gridDim.x >> 3;
+    const int xcd = (int)blockIdx.x & 7;
+    for (int tb = (int)blockIdx.x >> 3; tb < per_xcd; tb += wg_per_xcd) {
+        const int t = xcd * per_xcd + tb;
+        if (t >= n_tiles) break;
+        const int ty = t / A.tiles_x, tx = t - ty * A.tiles_x;
+        const int cx = tx * 64 + lane;
+        const int cy0 = (ty * 4 + wave) * RB;
+        const bool lane_ok = cx < A.cw;
+        const int lx0 = cx * DW;
+        const gfw_f2 oxp = {(float)lx0 + t2x, (float)(lx0 + 1) + t2x};
+
+        // ---- phase 1: certified rolling-shutter rows of the lane's RB x DH pixel pairs, straight-line: the table lookups of all
+        // rows are in flight together.  Rows outside the frame are computed too (harmless) and never used.
+        if (two_pass && !(GFW_HOT_ABLATE & 1)) {
+            #pragma unroll
+            for (int rj = 0; rj < RB * DH; ++rj) {
+                const int ly = cy0 * DH + rj;
+                const float oy = (float)ly + t2y;
+                int sy0, sy1; bool g0, g1; gfw_f2 v_fast;
+                hot_pass1_pair(oxp, oy, M, Q1, A.p1_table, hrs, rl2, sy0, sy1, g0, g1, v_fast, aud);
+                s_sy[rj][0][tid] = g0 ? (unsigned short)sy0 : (unsigned short)0xFFFF;
+                s_sy[rj][1][tid] = g1 ? (unsigned short)sy1 : (unsigned short)0xFFFF;
+                if (AUDIT && lane_ok && ly < A.out_h) {
+                    Lens L;
+                    L.f0 = A.f[0]; L.f1 = A.f[1]; L.c0 = A.c[0]; L.c1 = A.c[1]; L.k0 = A.k[0]; L.k1 = A.k[1]; L.k2 = A.k[2]; L.k3 = A.k[3];
+                    L.t2x = t2x; L.t2y = t2y; L.rl2 = rl2;
+                    #pragma unroll
+                    for (int i = 0; i < DW; ++i) {
+                        if (lx0 + i >= A.out_w) continue;
+                        if (!(i ? g1 : g0)) { atomicAdd(&A.audit[2], 1ull); continue; }
+                        atomicAdd(&A.audit[0], 1ull);
+                        const float oxi = i ? oxp.y : oxp.x;
+                        if (pass1_exact<MODEL>(oxi, oy, M, L, A) != (i ? sy1 : sy0)) atomicAdd(&A.audit[1], 1ull);
+                        const GfwPt ex = rd<MODEL>(oxi, oy, float4{M.m0, M.m1, M.m2, M.m3}, float4{M.m4, M.m5, M.m6, M.m7}, M.m8, A.matrices + (size_t)(A.matrix_count / 2) * GFW_MAT_STRIDE + 8, L, A);
+                        if (ex.ok) atomicMax(&A.audit[4], (unsigned long long)gfw_f2u(fabsf((hrs ? ex.x : ex.y) - (i ? v_fast.y : v_fast.x))));
+                    }
+                }
+            }
+        }
+
+        #pragma unroll 1
+        for (int rj = 0; rj < RB * DH; ++rj) {
+            const int r = rj / DH, j = rj - r * DH;
+            const int cy = cy0 + r, ly = cy * DH + j;
+            if (lane_ok && cy < A.ch && ly < A.out_h) {
+                const float oy = (float)ly + t2y;
+                int sy[2]; bool good[2] = {true, true};
+                if (two_pass && !(GFW_HOT_ABLATE & 1)) {
+                    sy[0] = (int)s_sy[rj][0][tid]; sy[1] = (int)s_sy[rj][1][tid];
+                    good[0] = sy[0] != 0xFFFF; good[1] = sy[1] != 0xFFFF;
+                } else {
+                    sy[0] = max(min(round_i32(hrs ? oxp.x : oy), row_lim), 0);
+                    sy[1] = max(min(round_i32(hrs ? oxp.y : oy), row_lim), 0);
+                }
+                // ---- second pass + taps of the two pixels together; what is not certified is deferred to the exact path ----------
+                const bool with_chroma = (j == 0);
+                const bool px1 = lx0 + 1 < A.out_w;                  // odd output widths: the pair's second pixel may not exist
+                const int row0 = min(sy[0], A.matrix_count - 1), row1 = min(sy[1], A.matrix_count - 1);
+                if (AUDIT && ((unsigned)row0 >= (unsigned)A.matrix_count || (unsigned)row1 >= (unsigned)A.matrix_count)) atomicAdd(&A.audit[5], 1ull);
+                HotPair R;
+                hot_project_pair(oxp, oy, A.matrices, (uint32_t)row0 * (uint32_t)(GFW_MAT_STRIDE * sizeof(float)),
+                                 (uint32_t)row1 * (uint32_t)(GFW_MAT_STRIDE * sizeof(float)), rl2, K, Q2, A.p1_table, with_chroma, R, aud);
+                if (GFW_HOT_ABLATE & 8) { R.acc[0] = true; R.acc[1] = true; }
+                // settled now: certified (or invalid: background colour, an exact decision); otherwise the exact path takes the pixel
+                const bool done0 = good[0] & (R.acc[0] | !R.ok[0]);
+                const bool done1 = px1 & good[1] & (R.acc[1] | !R.ok[1]);
+                if (AUDIT) {                                         // audit: the certified bins against the exact projection's
+                    Lens L;
+                    L.f0 = A.f[0]; L.f1 = A.f[1]; L.c0 = A.c[0]; L.c1 = A.c[1]; L.k0 = A.k[0]; L.k1 = A.k[1]; L.k2 = A.k[2]; L.k3 = A.k[3];
+                    L.t2x = t2x; L.t2y = t2y; L.rl2 = rl2;
+                    #pragma unroll
+                    for (int i = 0; i < DW; ++i) {
+                        if (!(i ? done1 : done0) || !R.ok[i]) continue;
+                        atomicAdd(&A.audit[6], 1ull);
+                        const GfwPt p = rd_row<MODEL>(i ? oxp.y : oxp.x, oy, i ? row1 : row0, L, A);
+                        int ex, ey;
+                        hot_bins(hot_map2(gfw_f2{p.x, p.y}, K.mul_l, K.nden, K.rcp), ex, ey);
+                        bool same = p.ok && ex == R.bx[i] && ey == R.by[i];
+                        if (i == 0 && with_chroma) { hot_bins(hot_map2(gfw_f2{p.x, p.y}, K.mul_c, K.nden, K.rcp), ex, ey); same = same && ex == R.cbx && ey == R.cby; }
+                        if (!same) atomicAdd(&A.audit[7], 1ull);
+                    }
+                }
+                uint32_t val0, val1, ou = 0u, ov = 0u;
+                bool in0, in1, inc = true;
+                if (GFW_HOT_ABLATE & 2) { val0 = (uint32_t)(R.bx[0] + R.by[0] + R.cbx); val1 = (uint32_t)(R.bx[1] + R.by[1] + R.cby); in0 = in1 = true; }   // timing ablation only
+                else {
+                    val0 = hot_sample_free<T>(PY, A.width, A.height, R.bx[0], R.by[0], lim_y, in0, aud);
+                    val1 = hot_sample_free<T>(PY, A.width, A.height, R.bx[1], R.by[1], lim_y, in1, aud);
+                    if (with_chroma) hot_sample_uv_free<T, INTERLEAVED_UV>(PU, PV, R.cbx, R.cby, lim_u, lim_v, ou, ov, inc, aud);
+                }
+                // rare: taps that straddle the source rect (cpu_undistort.rs:392-409), for the lanes that need them
+                if (__builtin_expect((done0 & R.ok[0] & !in0) | (done1 & R.ok[1] & !in1) | (with_chroma & done0 & R.ok[0] & !inc), 0)) {
+                    if (done0 & R.ok[0] & !in0) val0 = hot_sample<T>(PY, R.bx[0], R.by[0], bg_y, lim_y, aud);
+                    if (done1 & R.ok[1] & !in1) val1 = hot_sample<T>(PY, R.bx[1], R.by[1], bg_y, lim_y, aud);
+                    if (with_chroma & done0 & R.ok[0] & !inc) hot_sample_uv<T, INTERLEAVED_UV>(PU, PV, R.cbx, R.cby, bg_u, bg_v, lim_u, lim_v, ou, ov, aud);
+                }
+                if (!R.ok[0]) { val0 = gfw_f2u_sat(bg_y, top_f); ou = gfw_f2u_sat(bg_u, top_f); ov = gfw_f2u_sat(bg_v, top_f); }
+                if (!R.ok[1]) val1 = gfw_f2u_sat(bg_y, top_f);
+                if (with_chroma & done0) hot_store_uv<T, INTERLEAVED_UV>(PU, PV, cx, cy, ou, ov, aud);
+                // the lane's two horizontally adjacent luma pixels: one store when both are settled
+                const uint32_t doff = (uint32_t)ly * (uint32_t)PY.dst_stride + (uint32_t)lx0 * (uint32_t)sizeof(T);
+                if ((GFW_HOT_ABLATE & 64) && val0 + val1 != 0x12345u) { }
+                else if (done0 & done1) {
+                    if (range_ok(aud, doff, 2 * sizeof(T), PY.dst_len)) {
+                        if (sizeof(T) == 2) *reinterpret_cast<uint32_t *>(PY.dst + doff) = val0 | (val1 << 16);
+                        else *reinterpret_cast<uint16_t *>(PY.dst + doff) = (uint16_t)(val0 | (val1 << 8));
+                    }
+                } else {
+                    if (done0 && range_ok(aud, doff, sizeof(T), PY.dst_len)) *reinterpret_cast<T *>(PY.dst + doff) = (T)val0;
+                    if (done1 && range_ok(aud, (int64_t)doff + sizeof(T), sizeof(T), PY.dst_len)) *reinterpret_cast<T *>(PY.dst + doff + sizeof(T)) = (T)val1;
+                }
+                if (!done0 | (px1 & !done1)) {                       // the exact path decides (and samples) these pixels
+                    #pragma unroll
+                    for (int i = 0; i < DW; ++i) {
+                        if (i ? (!px1 | done1) : done0) continue;
+                        const unsigned slot = atomicAdd(&q_tail[wave], 1u) & (QCAP - 1u);
+                        q_id[wave][slot] = ((unsigned)t << 12) | ((unsigned)lane << 6) | (unsigned)(r * NPX + j * DW + i);
+                        q_sy[wave][slot] = good[i] ? (unsigned short)sy[i] : (unsigned short)0xFFFF;
+                    }
+                }
+            }
+            // drain the ring in full chunks of 64: the exact path always runs with every lane busy
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const unsigned tail = q_tail[wave];
+            while (tail - head >= 64u) { if (!(GFW_HOT_ABLATE & 4)) resolve(head, 64u); head += 64u; }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const unsigned tail = q_tail[wave];
+    if (tail != head) resolve(head, tail - head);
+}
+
+template <typename T, bool AUDIT>
+hipError_t launch_hot(const GfwYuvArgs &A, int dh, bool interleaved, hipStream_t s) {
+    const int n_tiles = A.tiles_x * A.tiles_y;
+    if (n_tiles <= 0) return hipSuccess;
+    int grid = A.grid_limit > 0 ? A.grid_limit : 256 * 6;
+    const int per_xcd = (n_tiles + 7) >> 3;
+    if (grid > per_xcd * 8) grid = per_xcd * 8;
+    grid = (grid + 7) & ~7;
+    dim3 block(64, 4);
+    if (dh == 1 && !interleaved) hipLaunchKernelGGL((gfw_hot_kernel<T, 1, false, AUDIT>), dim3(grid), block, 0, s, A);
+    else if (dh == 1 && interleaved) hipLaunchKernelGGL((gfw_hot_kernel<T, 1, true, AUDIT>), dim3(grid), block, 0, s, A);
+    else if (dh == 2 && !interleaved) hipLaunchKernelGGL((gfw_hot_kernel<T, 2, false, AUDIT>), dim3(grid), block, 0, s, A);
+    else if (dh == 2 && interleaved) hipLaunchKernelGGL((gfw_hot_kernel<T, 2, true, AUDIT>), dim3(grid), block, 0, s, A);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+#endif   // hot kernel
+
 template <int MODEL, typename T, int N0, int I, int RB, bool FAST1, bool AUDIT>
 hipError_t launch_mt(const GfwYuvArgs &A, int dw, int dh, bool interleaved, hipStream_t s) {
     const int n_tiles = A.tiles_x * A.tiles_y;
@@ -774,7 +1408,7 @@ hipError_t launch_mt(const GfwYuvArgs &A, int dw, int dh, bool interleaved, hipS
     grid = (grid + 7) & ~7;
     dim3 block(64, 4);
 #define GFW_YUV_LAUNCH(DW, DH, IL) hipLaunchKernelGGL((gfw_yuv_kernel<MODEL, T, N0, I, DW, DH, IL, RB, FAST1, AUDIT>), dim3(grid), block, 0, s, A)
-    if (N0 > 1 || is_f32<T>::value) {                    // packed single plane, or planar f32 planes: full resolution only
+    if constexpr (N0 > 1 || is_f32<T>::value) {          // packed single plane, or planar f32 planes: full resolution only
         if (dw == 1 && dh == 1 && !interleaved) GFW_YUV_LAUNCH(1, 1, false);
         else return hipErrorInvalidValue;
     } else {
@@ -828,6 +1462,16 @@ static hipError_t launch_m(const GfwYuvArgs &A, int n0, int dw, int dh, bool int
 #define GFW_CAT(a, b) GFW_CAT2(a, b)
 #define GFW_FN GFW_CAT(GFW_CAT(gfw_launch_yuv_kind, GFW_FRAME_KIND), GFW_CAT(_taps, GFW_FRAME_TAPS))
 hipError_t GFW_FN(const GfwYuvArgs &A, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s) {
+#if GFW_FRAME_TAPS == 2 && GFW_FRAME_KIND != 4
+    if (A.hot) {
+        if (n0 != 1 || dw != 2 || A.model != GFW_MODEL_OPENCV_FISHEYE || A.extras) return hipErrorInvalidValue;
+#if GFW_FRAME_KIND == 1
+        return A.audit ? launch_hot<uint8_t, true>(A, dh, interleaved, s) : launch_hot<uint8_t, false>(A, dh, interleaved, s);
+#else
+        return A.audit ? launch_hot<uint16_t, true>(A, dh, interleaved, s) : launch_hot<uint16_t, false>(A, dh, interleaved, s);
+#endif
+    }
+#endif
     if (A.model == GFW_MODEL_OPENCV_FISHEYE && !A.extras) return launch_m<GFW_MODEL_OPENCV_FISHEYE>(A, n0, dw, dh, interleaved, fast1, s);
     return launch_m<-1>(A, n0, dw, dh, interleaved, false, s);
 }

@@ -452,53 +452,3 @@ def sampled_track_fast(seed, t0_ms, t1_ms, rate_hz=1000.0, scale=1.0):
         q[:, 1:] *= scale
     q /= np.linalg.norm(q, axis=1, keepdims=True)
     return ts, q
-
-
-def slerp(a, b, t):
-    """nalgebra UnitQuaternion::slerp (shorter arc)."""
-    c = float(np.dot(a, b))
-    if c < 0.0:
-        b, c = -b, -c
-    if abs(c) >= 1.0:
-        return a.copy()
-    hang = math.acos(c)
-    s = math.sqrt(1.0 - c * c)
-    if s == 0.0:
-        return a.copy()
-    return a * (math.sin((1.0 - t) * hang) / s) + b * (math.sin(t * hang) / s)
-
-
-def quat_at(ts_us, quats, timestamp_ms):
-    """GyroSource::quat_at_timestamp (gyro_source/mod.rs:857-882)."""
-    if len(ts_us) < 2:
-        return np.array([1.0, 0.0, 0.0, 0.0])
-    lookup = int(min(max(int(np.floor(timestamp_ms * 1000.0 + 0.5)) if timestamp_ms >= 0 else int(np.ceil(timestamp_ms * 1000.0 - 0.5)), int(ts_us[0])), int(ts_us[-1])))
-    i = int(np.searchsorted(ts_us, lookup, side="right")) - 1
-    if ts_us[i] == lookup or i + 1 >= len(ts_us):
-        return quats[i].copy()
-    fract = float(lookup - ts_us[i]) / float(ts_us[i + 1] - ts_us[i])
-    return slerp(quats[i], quats[i + 1], fract)
-
-
-def row_matrices_from_tracks(org, smoothed, nk, timestamp_ms, frame_readout_time_ms, rows, readout_dim,
-                             video_rotation_deg=0.0, framebuffer_inverted=False, per_frame_offset_ms=0.0):
-    """Float64 host statement of frame_transform.rs:221-308 over sampled tracks; returns [rows][14] f32."""
-    ts = timestamp_ms + per_frame_offset_ms
-    start_ts = ts - frame_readout_time_ms / 2.0
-    row_t = frame_readout_time_ms / readout_dim
-    q1 = quat_at(org[0], org[1], ts)
-    q1 = np.array([q1[0], -q1[1], -q1[2], -q1[3]]) / np.dot(q1, q1)
-    sm = quat_at(smoothed[0], smoothed[1], ts)
-    a = math.radians(video_rotation_deg)
-    rot = np.array([[math.cos(a), -math.sin(a), 0.0], [math.sin(a), math.cos(a), 0.0], [0.0, 0.0, 1.0]])
-    out = np.zeros((rows, 14), dtype=np.float32)
-    for y in range(rows):
-        qt = start_ts + row_t * y if abs(frame_readout_time_ms) > 0.0 else start_ts
-        q = quat_mul(sm, quat_mul(q1, quat_at(org[0], org[1], qt)))
-        r = rot @ quat_to_matrix(q)
-        if framebuffer_inverted:
-            r[0, 2] *= -1.0; r[1, 2] *= -1.0; r[2, 0] *= -1.0; r[2, 1] *= -1.0
-        else:
-            r[0, 1] *= -1.0; r[0, 2] *= -1.0; r[1, 0] *= -1.0; r[2, 0] *= -1.0
-        out[y, :9] = np.linalg.pinv(nk @ r, rcond=1e-6).reshape(9).astype(np.float32)
-    return out

@@ -95,23 +95,54 @@ class Backend:
         gap = float(np.array([int(arr[4]) & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0])
         return int(arr[0]), int(arr[1]), int(arr[2]), int(arr[3]), gap
 
+    def get_audit_full(self, reset=False):
+        """All audit words by name (first pass + certified second pass + address audit)."""
+        arr = (C.c_ulonglong * 8)()
+        self._check(self.lib.gfw_get_audit(self.ctx, C.byref(arr), 1 if reset else 0))
+        gap = float(np.array([int(arr[4]) & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0])
+        return {"certified1": int(arr[0]), "certified1_wrong": int(arr[1]), "queued1": int(arr[2]), "queue_overflow": int(arr[3]),
+                "pass1_gap_px": gap, "out_of_range": int(arr[5]), "certified2": int(arr[6]), "certified2_wrong": int(arr[7])}
+
     def set_quaternion_tracks(self, org, smoothed):
         """Upload (timestamps_us int64, quaternions f64[n,4]) tracks once per clip (device matrix builder)."""
         ot, oq = np.ascontiguousarray(org[0], dtype=np.int64), np.ascontiguousarray(org[1], dtype=np.float64)
         st, sq = np.ascontiguousarray(smoothed[0], dtype=np.int64), np.ascontiguousarray(smoothed[1], dtype=np.float64)
         self._check(self.lib.gfw_set_quaternion_tracks(self.ctx, ot.ctypes.data, oq.ctypes.data, len(ot), st.ctypes.data, sq.ctypes.data, len(st)))
 
+    def set_sync_offsets(self, duration_ms, timestamps_us=(), offsets_ms=()):
+        """The clip's gyro/video sync offsets (GyroSource.offsets_adjusted) and duration (gyro_source/mod.rs:857-860)."""
+        ts = np.ascontiguousarray(timestamps_us, dtype=np.int64)
+        ov = np.ascontiguousarray(offsets_ms, dtype=np.float64)
+        assert ts.shape == ov.shape
+        self._check(self.lib.gfw_set_sync_offsets(self.ctx, float(duration_ms), ts.ctypes.data if len(ts) else None, ov.ctypes.data if len(ts) else None, len(ts)))
+
     def build_matrices(self, nk, timestamp_ms, frame_readout_time_ms, rows, readout_dim, video_rotation_deg=0.0,
-                       framebuffer_inverted=False, per_frame_offset_ms=0.0, out_ptr=None):
-        """Build one frame's packed rows on the device; returns the device pointer (context-owned unless out_ptr given)."""
+                       framebuffer_inverted=False, per_frame_offset_ms=0.0, out_ptr=None, suppress_rotation=0, stab=None):
+        """Build one frame's packed rows on the device; returns the device pointer (context-owned unless out_ptr given).
+        stab: None or dict(offset, sensor_size, crop_area, pixel_pitch, width, height, ibis=[n][4], ois=[n][4])."""
         t = abi.FrameTiming()
         t.timestamp_ms, t.per_frame_time_offset_ms, t.frame_readout_time_ms = timestamp_ms, per_frame_offset_ms, frame_readout_time_ms
         for i, v in enumerate(np.asarray(nk, dtype=np.float64).reshape(9)):
             t.new_k[i] = v
         t.video_rotation_deg, t.rows, t.readout_dim = video_rotation_deg, rows, readout_dim
         t.framebuffer_inverted = 1 if framebuffer_inverted else 0
+        t.suppress_rotation = int(suppress_rotation)
         ptr = C.c_void_p(0)
-        self._check(self.lib.gfw_build_matrices(self.ctx, C.byref(t), out_ptr, C.byref(ptr)))
+        if stab is None:
+            self._check(self.lib.gfw_build_matrices(self.ctx, C.byref(t), out_ptr, C.byref(ptr)))
+            return ptr.value
+        st = abi.FrameStab()
+        st.offset = stab["offset"]
+        st.sensor_size[0], st.sensor_size[1] = stab["sensor_size"]
+        for i in range(4):
+            st.crop_area[i] = stab["crop_area"][i]
+        st.pixel_pitch[0], st.pixel_pitch[1] = stab["pixel_pitch"]
+        st.width, st.height = stab["width"], stab["height"]
+        ibis = np.ascontiguousarray(stab["ibis"], dtype=np.float64).reshape(-1, 4)
+        ois = np.ascontiguousarray(stab["ois"], dtype=np.float64).reshape(-1, 4)
+        st.ibis_count, st.ois_count = ibis.shape[0], ois.shape[0]
+        st.ibis, st.ois = ibis.ctypes.data, ois.ctypes.data
+        self._check(self.lib.gfw_build_matrices_stab(self.ctx, C.byref(t), C.byref(st), out_ptr, C.byref(ptr)))
         return ptr.value
 
     def build_matrices_batch(self, nk, timestamps_ms, frame_readout_time_ms, rows, readout_dim, video_rotation_deg=0.0,

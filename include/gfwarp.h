@@ -258,7 +258,9 @@ enum {
                                         sets it for every clip that has such data); with 1 the roll's cos/sin are
                                         evaluated on the device with the host libm's own routines (gfw_math.h). */
     GFW_OPT_KERNEL_VARIANT     = 3,  /* 0 auto; 1 generic per-plane kernel; 2 fused kernel with the exact first pass;
-                                        3 fused kernel, certified first pass in audit mode (see gfw_get_audit) */
+                                        3 fused kernel, certified first pass in audit mode (see gfw_get_audit);
+                                        5 experimental gfw_hot_kernel (certified SECOND pass): bit-exact,
+                                        fewer instructions, measured slower than the default on MI355X; 6 = 5 in audit mode */
     GFW_OPT_PROFILE            = 4,  /* 1: bracket every warp-kernel launch with hipEvents on the context stream */
     GFW_OPT_TUNE_ROWS          = 5,  /* reserved (ignored) */
     GFW_OPT_TUNE_GRID          = 6   /* tuning: persistent workgroups of the fused kernel (0 = 6 per CU) */
@@ -297,8 +299,10 @@ int   gfw_checksum64(gfw_ctx *ctx, const void *d_buf, size_t bytes, unsigned lon
  * (GyroSource.quaternions / smoothed_quaternions: BTreeMap<i64 timestamp_us, Quat64>, gyro_source/mod.rs:857-882);
  * gfw_build_matrices then produces the packed rows of one frame directly in HBM (device pointer `rows16_out`, or a
  * context-owned table when NULL; its address is returned through `*out_ptr`) to be passed to
- * gfw_undistort_image/frame with GFW_OPT_MATRICES_ON_DEVICE = 2.  IBIS/OIS spline terms are not covered (rows get
- * zeros there).  Results equal the host f64 statement to ~1 ULP of f32 (SVD vs closed-form inverse). */
+ * gfw_undistort_image/frame with GFW_OPT_MATRICES_ON_DEVICE = 2.  Results equal the host f64 statement to ~1 ULP of f32
+ * (SVD vs closed-form inverse).  gfw_set_sync_offsets adds the clip's gyro/video sync offsets, gfw_build_matrices_stab the
+ * IBIS/OIS terms, gfw_frame_timing.suppress_rotation the `suppress_rotation` switch: with them FrameTransform::at_timestamp's
+ * matrix loop (frame_transform.rs:249-308) is covered in full. */
 typedef struct gfw_frame_timing {
     double timestamp_ms;               /* frame centre */
     double per_frame_time_offset_ms;   /* file_metadata.per_frame_time_offsets[frame] */
@@ -308,11 +312,33 @@ typedef struct gfw_frame_timing {
     int32_t rows;                      /* matrix_count: H, W (horizontal readout) or 1 */
     int32_t readout_dim;               /* divisor of the row readout time: height, or width for horizontal readout */
     int32_t framebuffer_inverted;
-    int32_t pad_;
+    int32_t suppress_rotation;         /* 0; 1 = params.suppress_rotation (R = identity, frame_transform.rs:291-296);
+                                          2 = the same with params.frame_readout_time == 0.0 (the IBIS/OIS terms are zeroed too) */
 } gfw_frame_timing;
+/* file_metadata.camera_stab_data[frame] (gyro_source/file_metadata.rs:41-48): in-body / optical stabiliser positions along the
+ * sensor readout, as two Catmull-Rom splines of the sensor row.  frame_transform.rs:234-241 and :270-289 turn them into
+ * the per-row terms m[9..13] = (sx, sy, roll angle, ox, oy); gfw_build_matrices_stab evaluates them per row on the device
+ * (f64, the reference's operation order) and fills the roll's cos/sin slots with the host libm's routines (gfw_math.h). */
+typedef struct gfw_frame_stab {
+    double offset;                     /* CameraStabData.offset */
+    double sensor_size[2];             /* (u32, u32) */
+    double crop_area[4];               /* (f32 x, y, w, h) widened exactly */
+    double pixel_pitch[2];             /* (u32, u32) */
+    double width, height;              /* params.width, params.height */
+    int32_t ibis_count, ois_count;     /* control points of the two splines (ascending positions) */
+    const double *ibis;                /* host, ibis_count x 4: position, x, y, z */
+    const double *ois;                 /* host, ois_count x 4: position, x, y, z (z unused) */
+} gfw_frame_stab;
 int   gfw_set_quaternion_tracks(gfw_ctx *ctx, const int64_t *org_ts_us, const double *org_wxyz, int org_count,
                                 const int64_t *smoothed_ts_us, const double *smoothed_wxyz, int smoothed_count);
 int   gfw_build_matrices(gfw_ctx *ctx, const gfw_frame_timing *timing, float *rows16_out, float **out_ptr);
+/* The same with the frame's IBIS/OIS stabiliser data (`stab` may be NULL): rows carry m[9..13] and cos/sin(-m[11]). */
+int   gfw_build_matrices_stab(gfw_ctx *ctx, const gfw_frame_timing *timing, const gfw_frame_stab *stab, float *rows16_out, float **out_ptr);
+/* Gyro/video synchronisation of the clip (GyroSource.offsets_adjusted: BTreeMap<i64 timestamp_us, f64 offset_ms> and
+ * duration_ms): quat_at_timestamp subtracts offset_at_video_timestamp(t) from every lookup time — per row, since the offset is
+ * interpolated at the row's own time — and returns identity when duration_ms <= 0 (gyro_source/mod.rs:857-860, :884-908).
+ * Not calling this leaves no offsets and a positive duration.  `count` may be 0. */
+int   gfw_set_sync_offsets(gfw_ctx *ctx, double duration_ms, const int64_t *timestamps_us, const double *offsets_ms, int count);
 /* The tables of `count` (<= 64) upcoming frames in one launch, in order on the context's stream, into context-owned
  * memory (two batches alternate: a batch stays valid until the second next call).  out_ptrs[i] = device table of frame i,
  * to be passed as `matrices` with GFW_OPT_MATRICES_ON_DEVICE = 2.  Amortises the builder's latency and needs no
