@@ -48,6 +48,10 @@
 #ifndef GFW_TAP_ROW_UNROLL8
 #define GFW_TAP_ROW_UNROLL8 1     // tap rows in flight in the Lanczos4 path (measured: 1 beats 2)
 #endif
+#ifndef GFW_DOT_TAPS_U16
+#define GFW_DOT_TAPS_U16 0       // integer-dot taps for 16-bit planes in the default kernel: measured SLOWER on MI355X (96.5 vs 81.7 us per 4K
+                                 // frame: two dword gathers at 2-byte alignment against four aligned 16-bit ones); 8-bit planes gain (C1: 18.0 -> 16.3 us)
+#endif
 #ifndef GFW_TAP_ROW_UNROLL
 #define GFW_TAP_ROW_UNROLL 2      // tap rows fetched together by the bicubic / Lanczos4 paths (registers vs loads in flight)
 #endif
@@ -533,7 +537,7 @@ __device__ __forceinline__ void sample_store2(float u, float v, bool ok, const G
         if (__builtin_expect((unsigned)b.sx < (unsigned)(P.w - 1) && (unsigned)b.sy < (unsigned)(P.h - 1), 1)) {
             const int off0 = b.sy * P.src_stride + b.sx * (int)(N * sizeof(T));
             if (range_ok(aud, off0, 2 * N * sizeof(T), P.src_len) && range_ok(aud, (int64_t)off0 + P.src_stride, 2 * N * sizeof(T), P.src_len)) {
-                if constexpr (!is_f32<T>::value && (N == 1 || N == 2)) {
+                if constexpr (!is_f32<T>::value && (N == 1 || N == 2) && (sizeof(T) == 1 || GFW_DOT_TAPS_U16)) {
                     // integer-dot taps: the pixel value comes out as an integer; store it and leave
                     const uint32_t doff = (uint32_t)oy * (uint32_t)P.dst_stride + (uint32_t)ox * (uint32_t)(N * sizeof(T));
                     if (!range_ok(aud, doff, N * sizeof(T), P.dst_len)) return;
@@ -600,7 +604,7 @@ __device__ __forceinline__ void sample_store_uv2(float u, float v, bool ok, cons
             const int off0 = b.sy * PU.src_stride + b.sx * (int)sizeof(T);
             const int top = PU.src_len < PV.src_len ? PU.src_len : PV.src_len;
             if (range_ok(aud, off0, 2 * sizeof(T), top) && range_ok(aud, (int64_t)off0 + PU.src_stride, 2 * sizeof(T), top)) {
-                if constexpr (!is_f32<T>::value) {
+                if constexpr (!is_f32<T>::value && (sizeof(T) == 1 || GFW_DOT_TAPS_U16)) {
                     typedef HotTap<T, false> Tap;
                     const uint32_t doff = (uint32_t)oy * (uint32_t)PU.dst_stride + (uint32_t)ox * (uint32_t)sizeof(T);
                     if (!range_ok(aud, doff, sizeof(T), PU.dst_len < PV.dst_len ? PU.dst_len : PV.dst_len)) return;

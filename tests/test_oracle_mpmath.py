@@ -1,0 +1,259 @@
+"""Independent pin of the oracle's lens models: high-precision (mpmath, 40 digits) statements of the 14
+`distort_point` maps written from the Rust sources (distortion_models/*.rs) WITHOUT looking at oracle/gfw_oracle.c,
+compared with the oracle's f32 results.
+
+What this can and cannot show.  The reference's f32 evaluation rounds after every operation, so its results differ from
+the mathematical value by a few ULP; the oracle restates those very roundings, which no real-arithmetic model can check.
+What the comparison does catch is a MISREADING — a swapped coefficient, a wrong power, a missing term, a different branch
+condition — because any of those moves the result by orders of magnitude more than the tolerance used here (relative
+2e-5; observed worst case is printed by `-s`).  The inverse maps (`undistort_point`, Newton / fixed-point iterations with
+the reference's own stopping rules) are checked through their defining property: the exact forward map applied to the
+oracle's inverse returns the input within the iteration's stopping tolerance.
+Parity stays "unpinned by the reference" (it ships no vectors and cannot be built here); this file is the strongest
+independent evidence available on this box.
+"""
+import ctypes as C
+
+import mpmath as mp
+import numpy as np
+import pytest
+
+from gyroflow_amd import abi
+import _oracle as O
+
+mp.mp.dps = 40
+F = lambda v: mp.mpf(float(np.float32(v)))          # the exact value of an f32 input
+
+
+def kp(k=(), dl=(), w=1920, h=1080):
+    p = abi.KernelParams()
+    p.width, p.height, p.output_width, p.output_height = w, h, w, h
+    for i, v in enumerate(k):
+        p.k[i] = v
+    for i, v in enumerate(dl):
+        p.digital_lens_params[i] = v
+    return p
+
+
+def oracle_distort(model, p, x, y, z):
+    out = np.zeros(2, dtype=np.float32)
+    O.lib().gfw_oracle_distort_point(abi.MODELS[model], C.byref(p), float(x), float(y), float(z), out.ctypes.data)
+    return float(out[0]), float(out[1])
+
+
+# ---- exact forward maps, physical models (distort_point: 3-D ray -> normalised distorted point) ------------------------
+def t_opencv_fisheye(k, x, y, z):            # opencv_fisheye.rs:72-95
+    x, y = x / z, y / z
+    if all(v == 0 for v in k[:4]):
+        return x, y
+    r = mp.sqrt(x * x + y * y)
+    th = mp.atan(r)
+    thd = th * (1 + k[0] * th ** 2 + k[1] * th ** 4 + k[2] * th ** 6 + k[3] * th ** 8)
+    s = mp.mpf(1) if r == 0 else thd / r
+    return x * s, y * s
+
+
+def t_opencv_standard(k, x, y, z):           # opencv_standard.rs:33-48
+    x, y = x / z, y / z
+    r2 = x * x + y * y; r4 = r2 * r2; r6 = r4 * r2
+    a1 = 2 * x * y; a2 = r2 + 2 * x * x; a3 = r2 + 2 * y * y
+    cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6
+    icd2 = 1 / (1 + k[5] * r2 + k[6] * r4 + k[7] * r6)
+    return (x * cdist * icd2 + k[2] * a1 + k[3] * a2 + k[8] * r2 + k[9] * r4,
+            y * cdist * icd2 + k[2] * a3 + k[3] * a1 + k[10] * r2 + k[11] * r4)
+
+
+def t_poly3(k, x, y, z):                     # poly3.rs:44-53
+    x, y = x / z, y / z
+    s = k[0] * (x * x + y * y) + 1
+    return x * s, y * s
+
+
+def t_poly5(k, x, y, z):                     # poly5.rs:43-53
+    x, y = x / z, y / z
+    ru2 = x * x + y * y
+    s = 1 + k[0] * ru2 + k[1] * ru2 * ru2
+    return x * s, y * s
+
+
+def t_ptlens(k, x, y, z):                    # ptlens.rs:42-53
+    x, y = x / z, y / z
+    ru2 = x * x + y * y; r = mp.sqrt(ru2)
+    s = k[0] * ru2 * r + k[1] * ru2 + k[2] * r + 1
+    return x * s, y * s
+
+
+def t_insta360(k, x, y, z):                  # insta360.rs:27-46
+    k1, k2, k3, p1, p2, xi = k[:6]
+    ln = mp.sqrt(x * x + y * y + z * z)
+    x = (x / ln) / ((z / ln) + xi); y = (y / ln) / ((z / ln) + xi)
+    r2 = x * x + y * y; r4 = r2 * r2; r6 = r4 * r2
+    rad = 1 + k1 * r2 + k2 * r4 + k3 * r6
+    return x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x), y * rad + 2 * p2 * x * y + p1 * (r2 + 2 * y * y)
+
+
+def t_sony(k, x, y, z):                      # sony.rs:62-88
+    x, y = x / z, y / z
+    if all(v == 0 for v in k[:4]):
+        return x, y
+    r = mp.sqrt(x * x + y * y); th = mp.atan(r)
+    thd = sum(k[i] * th ** (i + 1) for i in range(6))
+    s = mp.mpf(1) if r == 0 else thd / r
+    return x * s, y * s
+
+
+def t_generic_polynomial(k, x, y, z):        # generic_polynomial.rs:83-122
+    x, y = x / z, y / z
+    if all(v == 0 for v in k[:12]):
+        return x, y
+    r = mp.sqrt(x * x + y * y); th = mp.atan(r)
+    thd = sum(k[i] * th ** (i + 1) for i in range(12))
+    s = mp.mpf(1) if r == 0 else thd / r
+    return x * s, y * s
+
+
+def t_gopro(k, x, y, z):                     # gopro.rs:56-68: theta = POLY(p), r_norm = k1 * p
+    x, y = x / z, y / z
+    if k[1] == 0:
+        return x, y
+    r = mp.sqrt(x * x + y * y)
+    tmax = F(1.5533); tt = mp.tan(tmax)
+    th = mp.atan(r) if r < tt else tmax + (r - tt) / (1 + tt * tt)
+    poly = lambda p: sum(k[i] * p ** i for i in range(7))
+    p = mp.findroot(lambda q: poly(q) - th, (th - k[0]) / k[1])
+    rn = k[1] * p
+    s = mp.mpf(1) if r < mp.mpf("1e-9") else rn / r
+    return x * s, y * s
+
+
+TRUE = {"opencv_fisheye": t_opencv_fisheye, "opencv_standard": t_opencv_standard, "poly3": t_poly3, "poly5": t_poly5, "ptlens": t_ptlens,
+        "insta360": t_insta360, "sony": t_sony, "generic_polynomial": t_generic_polynomial, "gopro": t_gopro}
+COEFFS = {
+    "opencv_fisheye": [[0.045, 0.02, -0.02, 0.006], [0.3, -0.1, 0.05, -0.01], [0.0, 0.0, 0.0, 0.0]],
+    "opencv_standard": [[0.12, -0.05, 0.001, 0.002, 0.01, 0.02, -0.01, 0.001, 0.0005, -0.0002, 0.0003, 0.0001]],
+    "poly3": [[0.06], [-0.02]],
+    "poly5": [[0.08, -0.02]],
+    "ptlens": [[0.01, -0.03, 0.02]],
+    "insta360": [[0.05, -0.01, 0.002, 0.001, -0.001, 0.6]],
+    "sony": [[1.0, 0.01, -0.05, 0.02, 0.003, -0.001]],
+    "generic_polynomial": [[1.0, 0.01, -0.05, 0.02, 0.003, -0.001, 0.0005, -0.0002, 0.0001, 0.0, 0.00002, -0.00001]],
+    "gopro": [[0.0, 1.0, 0.01, -0.12, 0.02, 0.01, -0.004], [0.001, 0.9, 0.0, -0.1, 0.0, 0.02, 0.0]],
+}
+
+
+def rays(n, seed):
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(-1.6, 1.6, size=(n, 2)).astype(np.float32)
+    z = rng.uniform(0.6, 1.4, size=n).astype(np.float32)
+    pts = [(float(a), float(b), float(c)) for (a, b), c in zip(xy, z)]
+    return pts + [(0.0, 0.0, 1.0), (1e-6, -2e-6, 1.0), (0.5, 0.0, 1.0), (0.0, -0.75, 2.0)]
+
+
+@pytest.mark.parametrize("model", sorted(TRUE))
+def test_physical_distort_point_matches_the_mathematical_map(model):
+    worst = 0.0
+    for k in COEFFS[model]:
+        kk = [F(v) for v in list(k) + [0.0] * (12 - len(k))]
+        p = kp(k)
+        for (x, y, z) in rays(120, 7):
+            got = oracle_distort(model, p, x, y, z)
+            want = TRUE[model](kk, F(x), F(y), F(z))
+            for g, w_ in zip(got, want):
+                err = abs(mp.mpf(g) - w_) / max(abs(w_), mp.mpf("1e-3"))
+                worst = max(worst, float(err))
+                assert err < 2e-5, (model, k, (x, y, z), g, float(w_))
+    print("%s: worst relative deviation from the exact map %.2e" % (model, worst))
+
+
+# ---- digital lenses: distort_point inverts a polynomial map by fixed-point iteration with |diff| < 1e-6 -------------------
+def superview(u, v):                         # gopro_superview.rs:9-16
+    x2, y2 = u * u, v * v
+    return (u * (F(1.2100393) + x2 * (F(-1.2758402) + x2 * F(1.7751845))),
+            v * (F(0.9364505) + (F(0.4465308) - F(0.7683315) * y2) * y2 + (F(-0.3574087) + F(1.1584653) * y2 + F(0.3529348) * x2) * x2))
+
+
+def hyperview(u, v):                         # gopro_hyperview.rs:9-16
+    x2, y2 = u * u, v * v
+    return (u * (F(1.5805143) + x2 * (F(-8.1668825) + x2 * (F(74.5198746) + x2 * (F(-451.5002441) + x2 * (F(1551.2922363) + x2 * (F(-2735.5422363) + x2 * F(1923.1572266)))))) + y2 * F(-0.1086027)),
+            v * (F(1.0238225) + y2 * F(-0.1025671) + x2 * (F(-0.2639930) + x2 * F(0.2979266))))
+
+
+def superview6(u, v):                        # gopro6_superview.rs:9-14
+    u = u * (1 - F(0.48) * abs(u))
+    u = u * (F(0.943396) * (1 + F(0.157895) * abs(u)))
+    v = v * (F(0.943396) * (1 + F(0.060000) * abs(v * 2)))
+    return u, v
+
+
+def gopro_map(p):                            # gopro_warp.rs:9-19
+    def f(u, v):
+        x = min(max(u, mp.mpf(-0.5)), mp.mpf(0.5)); y = min(max(v, mp.mpf(-0.5)), mp.mpf(0.5))
+        x2, y2 = x * x, y * y
+        px = p[0] + x2 * (p[1] + x2 * (p[2] + x2 * (p[3] + x2 * (p[4] + x2 * (p[5] + x2 * p[6])))))
+        return x * (px + p[7] * y2) + (u - x), y * (p[8] + p[9] * y2 + p[10] * y2 * y2 + x2 * (p[11] + p[12] * y2 + p[13] * x2)) + (v - y)
+    return f
+
+
+WARP_P = [1.32, -1.2, 1.6, -0.4, 0.1, 0.0, 0.0, -0.1, 0.95, 0.4, -0.7, -0.35, 1.1, 0.35, 1.3333334]
+
+
+@pytest.mark.parametrize("name,fmap,xscale,dl", [("gopro_superview", superview, 1.333333333, []), ("gopro_hyperview", hyperview, 1.555555555, []),
+                                                  ("gopro6_superview", superview6, 1.0, []), ("gopro_warp", None, None, WARP_P)])
+def test_digital_distort_point_inverts_its_map(name, fmap, xscale, dl):
+    w, h = 1920, 1080
+    p = kp(dl=dl, w=w, h=h)
+    if name == "gopro_warp":
+        fmap = gopro_map([F(v) for v in dl] + [mp.mpf(0)])
+        xscale = float(np.float32(dl[14]))
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for _ in range(150):
+        x, y = float(np.float32(rng.uniform(0.12 * w, 0.88 * w))), float(np.float32(rng.uniform(0.12 * h, 0.88 * h)))
+        gx, gy = oracle_distort(name, p, x, y, 1.0)
+        if gx == -99999.0:                                   # gopro_warp's out-of-domain marker
+            continue
+        # the reference's own algorithm in exact arithmetic: <= 12 rounds of P -= map(P) - target, stop at |diff| < 1e-6 in both
+        # coordinates (gopro_superview.rs:38-57 and siblings; the slow contraction of HyperView leaves ~1e-5 after 12 rounds, which
+        # is the reference's behaviour and therefore the oracle's)
+        tx, ty = (F(x) / w - mp.mpf(0.5)) * F(xscale), F(y) / h - mp.mpf(0.5)
+        px, py = ((F(x) / w - mp.mpf(0.5)), ty) if name == "gopro_warp" else (tx, ty)
+        for _ in range(12):
+            mx, my = fmap(px, py)
+            dx, dy = mx - tx, my - ty
+            if abs(dx) < mp.mpf("1e-6") and abs(dy) < mp.mpf("1e-6"):
+                break
+            px, py = px - dx, py - dy
+        wx, wy = (px + mp.mpf(0.5)) * w, (py + mp.mpf(0.5)) * h
+        res = max(abs(F(gx) - wx) / w, abs(F(gy) - wy) / h)          # in normalised units; f32 noise of the iteration ~1e-6
+        worst = max(worst, float(res))
+        assert res < 2e-5, (name, (x, y), (gx, gy), (float(wx), float(wy)))
+    print("%s: worst deviation from the exact-arithmetic iteration %.2e (normalised units)" % (name, worst))
+
+
+def test_digital_stretch():
+    p = kp(dl=[1.1, 0.95])
+    assert oracle_distort("digital_stretch", p, 100.0, 200.0, 1.0) == (float(np.float32(100.0) * np.float32(1.1)), float(np.float32(200.0) * np.float32(0.95)))
+
+
+# ---- inverse maps of the physical models: forward(exact) o inverse(oracle) = identity within the stopping rule ------------
+@pytest.mark.parametrize("model", sorted(TRUE))
+def test_physical_undistort_point_inverts_the_exact_forward_map(model):
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for k in COEFFS[model]:
+        kk = [F(v) for v in list(k) + [0.0] * (12 - len(k))]
+        p = kp(k)
+        n_ok = 0
+        for _ in range(120):
+            px, py = float(np.float32(rng.uniform(-0.7, 0.7))), float(np.float32(rng.uniform(-0.5, 0.5)))
+            ok, ux, uy = O.undistort_point(abi.MODELS[model], p, px, py)
+            if not ok:
+                continue
+            n_ok += 1
+            bx, by = TRUE[model](kk, F(ux), F(uy), mp.mpf(1))
+            res = max(abs(bx - F(px)), abs(by - F(py)))
+            worst = max(worst, float(res))
+            # Newton stopping rules are 1e-5 (poly3/5, ptlens: |f(ru)|) or 1e-6 on the angle; insta360 iterates to 1e-6; opencv_standard runs 20 fixed rounds
+            assert res < 4e-5, (model, k, (px, py), (ux, uy), float(res))
+        assert n_ok > 60, (model, n_ok)
+    print("%s: worst residual of forward(exact) o inverse(oracle) %.2e" % (model, worst))
