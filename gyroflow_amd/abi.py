@@ -169,7 +169,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("GFW_LIBRARY", "") or LIB_PATH      # GFW_LIBRARY: A/B builds of the library (tools/, benchmarking)
     if not os.path.exists(p):
         raise RuntimeError(
             "libgfwarp.so not found at %s — the HIP extension is not built. Run "

@@ -640,7 +640,8 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
         const gfw_kernel_params &p = params[i];
         if ((p.interpolation != 2 && p.interpolation != 4 && p.interpolation != 8) || p.interpolation != p0.interpolation) return false;
         if (p.background_mode < 0 || p.background_mode > 2 || p.background_mode != p0.background_mode || p.input_rotation != 0.0f) return false;
-        if (p.lens_correction_amount < 1.0f || !(p.lens_correction_amount == p.lens_correction_amount)) return false;
+        if (!(p.lens_correction_amount == p.lens_correction_amount) || p.lens_correction_amount != p0.lens_correction_amount) return false;
+        if (p.lens_correction_amount < 1.0f) extras |= 8;                        // the blend of :429-460 (generic-model instantiation)
         if (!(p.light_refraction_coefficient == p.light_refraction_coefficient) || p.light_refraction_coefficient != p0.light_refraction_coefficient) return false;
         if (p.light_refraction_coefficient != 1.0f && p.light_refraction_coefficient > 0.0f) extras |= 4;
         if ((p.flags ^ p0.flags) & GFW_FLAG_HAS_DIGITAL_LENS) return false;

@@ -52,6 +52,12 @@
 #define GFW_DOT_TAPS_U16 0       // integer-dot taps for 16-bit planes in the default kernel: measured SLOWER on MI355X (96.5 vs 81.7 us per 4K
                                  // frame: two dword gathers at 2-byte alignment against four aligned 16-bit ones); 8-bit planes gain (C1: 18.0 -> 16.3 us)
 #endif
+#ifndef GFW_WAVES_PER_EU
+#define GFW_WAVES_PER_EU 7       // register budget of the frame kernels, in waves per SIMD (512 / N VGPRs): the kernel is latency-bound and its speed follows occupancy
+#endif
+#ifndef GFW_PASS1_PAIR
+#define GFW_PASS1_PAIR 0         // first pass of the lane's pixel pair with packed math (hot_pass1_pair) in the default kernel
+#endif
 #ifndef GFW_TAP_ROW_UNROLL
 #define GFW_TAP_ROW_UNROLL 2      // tap rows fetched together by the bicubic / Lanczos4 paths (registers vs loads in flight)
 #endif
@@ -412,10 +418,12 @@ typedef float gfw_f2 __attribute__((ext_vector_type(2)));
 typedef unsigned short gfw_us2 __attribute__((ext_vector_type(2)));
 
 template <typename T, bool UV> struct HotTap;
-template <> struct HotTap<uint16_t, false> {                 // two u16 taps = one dword at a 2-byte aligned address
-    static constexpr int BYTES = 4, PX = 2;
-    typedef uint32_t u32u __attribute__((aligned(2)));
-    static __device__ __forceinline__ uint32_t load(const uint8_t *src, uint32_t off) { return *reinterpret_cast<const u32u *>(src + off); }
+template <> struct HotTap<uint16_t, false> {                 // two u16 taps: two ALIGNED 16-bit gathers packed into one word (a dword gather at
+    static constexpr int BYTES = 4, PX = 2;                  // 2-byte alignment costs the texture-address path ~3x: profiles/r01_membench_*.txt)
+    static __device__ __forceinline__ uint32_t load(const uint8_t *src, uint32_t off) {
+        const uint32_t lo = *reinterpret_cast<const uint16_t *>(src + off), hi = *reinterpret_cast<const uint16_t *>(src + off + 2u);
+        return lo | (hi << 16);
+    }
     static __device__ __forceinline__ uint32_t wpack(uint32_t k) { return (32u - k) | (k << 16); }
     static __device__ __forceinline__ uint32_t dot(uint32_t raw, uint32_t w) { return __builtin_amdgcn_udot2(__builtin_bit_cast(gfw_us2, raw), __builtin_bit_cast(gfw_us2, w), 0u, false); }
 };
@@ -436,10 +444,12 @@ template <> struct HotTap<uint8_t, true> {                   // four bytes at a 
         u = __builtin_amdgcn_udot4(raw, w, 0u, false); v = __builtin_amdgcn_udot4(raw, w << 8, 0u, false);
     }
 };
-template <> struct HotTap<uint16_t, true> {                  // eight bytes at a 4-byte aligned address
+template <> struct HotTap<uint16_t, true> {                  // eight bytes = two aligned dwords (a UV16 pixel is 4 bytes)
     static constexpr int BYTES = 8, PX = 4;
-    typedef uint2 uint2a __attribute__((aligned(2)));
-    static __device__ __forceinline__ uint2 load(const uint8_t *src, uint32_t off) { return *reinterpret_cast<const uint2a *>(src + off); }
+    static __device__ __forceinline__ uint2 load(const uint8_t *src, uint32_t off) {
+        typedef uint32_t u32u __attribute__((aligned(2)));
+        return uint2{*reinterpret_cast<const u32u *>(src + off), *reinterpret_cast<const u32u *>(src + off + 4u)};
+    }
     static __device__ __forceinline__ uint32_t wpack(uint32_t k) { return (32u - k) | (k << 16); }
     static __device__ __forceinline__ void dot(uint2 raw, uint32_t w, uint32_t &u, uint32_t &v) {
         const uint32_t uu = __builtin_amdgcn_perm(raw.y, raw.x, 0x05040100u);      // (U0, U1)
@@ -685,8 +695,43 @@ __device__ __forceinline__ bool pass1_fast(float ax, float ay, float aw, float o
     return good;
 }
 
+// Byte-offset addressing from a uniform base: a 32-bit lane offset on top of a scalar base register pair.
+template <typename V>
+__device__ __forceinline__ V hot_ld(const void *base, uint32_t byte_off) { return *reinterpret_cast<const V *>(reinterpret_cast<const uint8_t *>(base) + byte_off); }
+// First pass of the lane's two horizontally adjacent pixels at once (packed): the certified table-driven row pick of
+// pass1_fast, element-wise.  good[i] false -> the exact path decides that pixel's row.
+__device__ __forceinline__ void hot_pass1_pair(gfw_f2 ox, float oy, const Mid &M, const P1 &Q, const float2 *tab, bool hrs, float rl2,
+                                               int &sy0, int &sy1, bool &good0, bool &good1, gfw_f2 &v_out, unsigned long long *aud) {
+    const gfw_f2 oyv = {oy, oy};
+    const gfw_f2 X = __builtin_elementwise_fma(oyv, gfw_f2{M.m1, M.m1}, __builtin_elementwise_fma(ox, gfw_f2{M.m0, M.m0}, gfw_f2{M.m2, M.m2}));
+    const gfw_f2 Y = __builtin_elementwise_fma(oyv, gfw_f2{M.m4, M.m4}, __builtin_elementwise_fma(ox, gfw_f2{M.m3, M.m3}, gfw_f2{M.m5, M.m5}));
+    const gfw_f2 W = __builtin_elementwise_fma(oyv, gfw_f2{M.m7, M.m7}, __builtin_elementwise_fma(ox, gfw_f2{M.m6, M.m6}, gfw_f2{M.m8, M.m8}));
+    const gfw_f2 rw = {gfw_hw_rcp(W.x), gfw_hw_rcp(W.y)};
+    const gfw_f2 a = X * rw, b = Y * rw;
+    const gfw_f2 rho = __builtin_elementwise_fma(a, a, b * b);
+    bool g0 = (W.x > 0.0009765625f) & (rho.x < Q.rho_max), g1 = (W.y > 0.0009765625f) & (rho.y < Q.rho_max);
+    if (rl2 > 0.0f) {                                              // :139 — decide only when clear of the boundary
+        const gfw_f2 lhs = __builtin_elementwise_fma(X, X, Y * Y), rhs = W * (rl2 * 0.9999f);
+        g0 &= lhs.x < rhs.x; g1 &= lhs.y < rhs.y;
+    }
+    const gfw_f2 tpos = gfw_f2{fminf(fmaxf(rho.x, 0.0f), Q.rho_max), fminf(fmaxf(rho.y, 0.0f), Q.rho_max)} * Q.rho_scale;
+    const gfw_f2 ti = {floorf(tpos.x), floorf(tpos.y)};
+    if (aud && !((int)ti.x >= 0 && (int)ti.x <= GFW_P1_TABLE_N && (int)ti.y >= 0 && (int)ti.y <= GFW_P1_TABLE_N)) atomicAdd(&aud[5], 1ull);
+    const float2 e0 = hot_ld<float2>(tab, (uint32_t)(int)ti.x * 8u), e1 = hot_ld<float2>(tab, (uint32_t)(int)ti.y * 8u);
+    const gfw_f2 s = __builtin_elementwise_fma(tpos - ti, gfw_f2{e0.y, e1.y}, gfw_f2{e0.x, e1.x});
+    const gfw_f2 v = __builtin_elementwise_fma((hrs ? a : b) * s, gfw_f2{Q.f, Q.f}, gfw_f2{Q.c, Q.c});
+    v_out = v;
+    const gfw_f2 g = v - 0.5f;
+    const gfw_f2 d = g - gfw_f2{rintf(g.x), rintf(g.y)};           // distance of v to the nearest half-integer
+    const bool out0 = !(v.x > -0.25f) | !(v.x < Q.lim + 0.25f), out1 = !(v.y > -0.25f) | !(v.y < Q.lim + 0.25f);   // there the clamp decides
+    good0 = g0 & (out0 | (fabsf(d.x) > Q.eps)) & (v.x == v.x);
+    good1 = g1 & (out1 | (fabsf(d.y) > Q.eps)) & (v.y == v.y);
+    sy0 = max(min(gfw_f2i(rintf(v.x)), (int)Q.lim), 0);
+    sy1 = max(min(gfw_f2i(rintf(v.y)), (int)Q.lim), 0);
+}
+
 template <int MODEL, typename T, int N0, int I, int DW, int DH, bool INTERLEAVED_UV, int RB, bool FAST1, bool AUDIT>
-__global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFW_WAVES_PER_EU, 8))) void gfw_yuv_kernel(const GfwYuvArgs A) {
     // tile = 64 x 4 lanes; each lane owns RB vertically stacked DW x DH luma blocks (+ their chroma sites).
     constexpr int NPX = DW * DH;
     constexpr int QCAP = 128 * NPX;                  // a wave adds at most 64*NPX entries per row; flushed at half full
@@ -751,13 +796,33 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
             }
             #pragma unroll 1
             for (int r = 0; r < RB; ++r) {
+              if (GFW_PASS1_PAIR && FAST1 && !AUDIT && NPX == 2 && DW == 2) {
+                // the lane's two horizontally adjacent pixels at once, packed (hot_pass1_pair): same certificate, element-wise
+                const int lx0 = cx * 2, ly = cy0 + r;
+                const gfw_f2 oxp = {(float)lx0 + L.t2x, (float)(lx0 + 1) + L.t2x};
+                const float oy = (float)ly + L.t2y;
+                int sy0, sy1; bool g0, g1; gfw_f2 v_fast;
+                hot_pass1_pair(oxp, oy, M, Q, A.p1_table, hrs, L.rl2, sy0, sy1, g0, g1, v_fast, nullptr);
+                const bool in0 = lane_ok && lx0 < A.out_w && ly < A.out_h, in1 = lane_ok && lx0 + 1 < A.out_w && ly < A.out_h;
+                if (in0 && !g0) {
+                    const unsigned slot = atomicAdd(&q_n[wave], 1u);
+                    q_x[wave][slot] = oxp.x; q_y[wave][slot] = oy; q_dst[wave][slot] = (unsigned short)((lane << 6) | (r * NPX));
+                }
+                if (in1 && !g1) {
+                    const unsigned slot = atomicAdd(&q_n[wave], 1u);
+                    q_x[wave][slot] = oxp.y; q_y[wave][slot] = oy; q_dst[wave][slot] = (unsigned short)((lane << 6) | (r * NPX + 1));
+                }
+                s_rows[r * NPX][tid] = in0 ? sy0 : 0;
+                s_rows[r * NPX + 1][tid] = in1 ? sy1 : 0;
+              } else {
                 #pragma unroll (NPX <= 2 ? NPX : 1)
                 for (int k = 0; k < NPX; ++k) {
                     const int i = k % DW, j = k / DW;
                     const int lx = cx * DW + i, ly = (cy0 + r) * DH + j;
                     int sy = 0;
                     if (lane_ok && lx < A.out_w && ly < A.out_h) {
-                        const float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
+                        float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
+                        if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (A.extras & 8)) gfw_lens_correction_blend<MODEL>(ox, oy, A.kp, A.common);   // :429-460
                         if (FAST1) {
                             float v_fast;
                             const float ax = __builtin_fmaf(ox, M.m0, M.m2), ay = __builtin_fmaf(ox, M.m3, M.m5), aw = __builtin_fmaf(ox, M.m6, M.m8);
@@ -778,6 +843,7 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
                     }
                     s_rows[r * NPX + k][tid] = sy;
                 }
+              }
                 if (FAST1) {
                     // ---- phase 2: the wave resolves its queued pixels exactly, densely packed.  Flushed after
                     // the last row, or earlier when the next row (<= 64*NPX new entries) could overflow the queue.
@@ -809,7 +875,8 @@ __global__ __launch_bounds__(256) void gfw_yuv_kernel(const GfwYuvArgs A) {
                     const int i = k % DW, j = k / DW;
                     const int lx = cx * DW + i, ly = cy * DH + j;
                     if (lx >= A.out_w || ly >= A.out_h) continue;
-                    const float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
+                    float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
+                    if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (A.extras & 8)) gfw_lens_correction_blend<MODEL>(ox, oy, A.kp, A.common);       // :429-460
                     const int sy = two_pass ? s_rows[r * NPX + k][tid] : default_row<MODEL>(ox, oy, A);
                     GfwPt p;
                     if (A.ablate & 8) { p.x = ox * 0.5f; p.y = oy * 0.5f; p.ok = true; }              // timing ablation only
@@ -974,9 +1041,6 @@ __device__ __forceinline__ void hot_bins(gfw_f2 xy, int &bx, int &by) {         
     const gfw_f2 g = xy * 32.0f;
     bx = round_i32(g.x); by = round_i32(g.y);
 }
-// Byte-offset addressing from a uniform base: a 32-bit lane offset on top of a scalar base register pair.
-template <typename V>
-__device__ __forceinline__ V hot_ld(const void *base, uint32_t byte_off) { return *reinterpret_cast<const V *>(reinterpret_cast<const uint8_t *>(base) + byte_off); }
 
 // Second pass of one pixel with the matrix row at byte offset `moff`: exact head, certified middle, exact two-point tail.
 //   ok  : the reference's validity (w > 0, r_limit) — exact
@@ -1108,38 +1172,6 @@ __device__ __forceinline__ void hot_sample_uv_free(const GfwYuvPlane &PU, const 
     }
 }
 
-// First pass of the lane's two horizontally adjacent pixels at once (packed): the certified table-driven row pick of
-// pass1_fast, element-wise.  good[i] false -> the exact path decides that pixel's row.
-__device__ __forceinline__ void hot_pass1_pair(gfw_f2 ox, float oy, const Mid &M, const P1 &Q, const float2 *tab, bool hrs, float rl2,
-                                               int &sy0, int &sy1, bool &good0, bool &good1, gfw_f2 &v_out, unsigned long long *aud) {
-    const gfw_f2 oyv = {oy, oy};
-    const gfw_f2 X = __builtin_elementwise_fma(oyv, gfw_f2{M.m1, M.m1}, __builtin_elementwise_fma(ox, gfw_f2{M.m0, M.m0}, gfw_f2{M.m2, M.m2}));
-    const gfw_f2 Y = __builtin_elementwise_fma(oyv, gfw_f2{M.m4, M.m4}, __builtin_elementwise_fma(ox, gfw_f2{M.m3, M.m3}, gfw_f2{M.m5, M.m5}));
-    const gfw_f2 W = __builtin_elementwise_fma(oyv, gfw_f2{M.m7, M.m7}, __builtin_elementwise_fma(ox, gfw_f2{M.m6, M.m6}, gfw_f2{M.m8, M.m8}));
-    const gfw_f2 rw = {gfw_hw_rcp(W.x), gfw_hw_rcp(W.y)};
-    const gfw_f2 a = X * rw, b = Y * rw;
-    const gfw_f2 rho = __builtin_elementwise_fma(a, a, b * b);
-    bool g0 = (W.x > 0.0009765625f) & (rho.x < Q.rho_max), g1 = (W.y > 0.0009765625f) & (rho.y < Q.rho_max);
-    if (rl2 > 0.0f) {                                              // :139 — decide only when clear of the boundary
-        const gfw_f2 lhs = __builtin_elementwise_fma(X, X, Y * Y), rhs = W * (rl2 * 0.9999f);
-        g0 &= lhs.x < rhs.x; g1 &= lhs.y < rhs.y;
-    }
-    const gfw_f2 tpos = gfw_f2{fminf(fmaxf(rho.x, 0.0f), Q.rho_max), fminf(fmaxf(rho.y, 0.0f), Q.rho_max)} * Q.rho_scale;
-    const gfw_f2 ti = {floorf(tpos.x), floorf(tpos.y)};
-    if (aud && !((int)ti.x >= 0 && (int)ti.x <= GFW_P1_TABLE_N && (int)ti.y >= 0 && (int)ti.y <= GFW_P1_TABLE_N)) atomicAdd(&aud[5], 1ull);
-    const float2 e0 = hot_ld<float2>(tab, (uint32_t)(int)ti.x * 8u), e1 = hot_ld<float2>(tab, (uint32_t)(int)ti.y * 8u);
-    const gfw_f2 s = __builtin_elementwise_fma(tpos - ti, gfw_f2{e0.y, e1.y}, gfw_f2{e0.x, e1.x});
-    const gfw_f2 v = __builtin_elementwise_fma((hrs ? a : b) * s, gfw_f2{Q.f, Q.f}, gfw_f2{Q.c, Q.c});
-    v_out = v;
-    const gfw_f2 g = v - 0.5f;
-    const gfw_f2 d = g - gfw_f2{rintf(g.x), rintf(g.y)};           // distance of v to the nearest half-integer
-    const bool out0 = !(v.x > -0.25f) | !(v.x < Q.lim + 0.25f), out1 = !(v.y > -0.25f) | !(v.y < Q.lim + 0.25f);   // there the clamp decides
-    good0 = g0 & (out0 | (fabsf(d.x) > Q.eps)) & (v.x == v.x);
-    good1 = g1 & (out1 | (fabsf(d.y) > Q.eps)) & (v.y == v.y);
-    sy0 = max(min(gfw_f2i(rintf(v.x)), (int)Q.lim), 0);
-    sy1 = max(min(gfw_f2i(rintf(v.y)), (int)Q.lim), 0);
-}
-
 // The kernel-argument segment as scalar-addressable constant memory: rare paths read their uniforms from here at the point
 // of use instead of keeping them in (scarce) scalar registers across the pixel loop.
 #ifndef GFW_HOT_ABLATE
@@ -1149,7 +1181,7 @@ typedef const GfwYuvArgs __attribute__((address_space(4))) *HotKArgs;
 #define GFW_OPAQUE(p) asm volatile("" : "+s"(p))
 
 template <typename T, int DH, bool INTERLEAVED_UV, bool AUDIT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void gfw_hot_kernel(const GfwYuvArgs A) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFW_WAVES_PER_EU, 8))) void gfw_hot_kernel(const GfwYuvArgs A) {
     constexpr int MODEL = GFW_MODEL_OPENCV_FISHEYE, DW = 2, RB = GFW_YUV_RB_FAST;
     constexpr int NPX = DW * DH;
     constexpr unsigned QCAP = 256;                 // ring of deferred pixels per wave: <= 63 pending + <= 128 new per step

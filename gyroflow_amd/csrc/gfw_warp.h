@@ -582,15 +582,10 @@ __device__ __forceinline__ GfwPt gfw_rotate_and_distort(float px, float py, int 
 
 // undistort_coord up to (not including) the final source_rect map: cpu_undistort.rs:421-509.
 // (x, y) are OUTPUT-BUFFER pixel indices as floats.  The result is in full-resolution source pixels.
+// The lens-correction blend of undistort_coord (cpu_undistort.rs:429-460): the output position moves towards its
+// undistorted counterpart by (1 - lens_correction_amount) before any projection.
 template <int MODEL>
-__device__ __forceinline__ GfwPt gfw_undistort_coord_fullres(float x, float y, const gfw_kernel_params &P, const GfwCommon &C) {
-    float opx = gfw_map_coord(x, (float)P.output_rect[0], (float)(P.output_rect[0] + P.output_rect[2]), 0.0f, (float)P.output_width);
-    float opy = gfw_map_coord(y, (float)P.output_rect[1], (float)(P.output_rect[1] + P.output_rect[3]), 0.0f, (float)P.output_height);
-    opx += P.translation2d[0];
-    opy += P.translation2d[1];
-    const float r_limit_sq = P.r_limit * P.r_limit;
-
-    if (P.lens_correction_amount < 1.0f) {                                              // :429-460
+__device__ __forceinline__ void gfw_lens_correction_blend(float &opx, float &opy, const gfw_kernel_params &P, const GfwCommon &C) {
         const float factor = gfw_max(1.0f - P.lens_correction_amount, 0.001f);          // :526
         const float ocx = (float)P.output_width / 2.0f, ocy = (float)P.output_height / 2.0f;
         const float ofx = P.f[0] / P.fov / factor, ofy = P.f[1] / P.fov / factor;
@@ -615,7 +610,16 @@ __device__ __forceinline__ GfwPt gfw_undistort_coord_fullres(float x, float y, c
         nx = (nx * ofx) + ocx; ny = (ny * ofy) + ocy;
         opx = nx * (1.0f - P.lens_correction_amount) + (opx * P.lens_correction_amount);
         opy = ny * (1.0f - P.lens_correction_amount) + (opy * P.lens_correction_amount);
-    }
+}
+template <int MODEL>
+__device__ __forceinline__ GfwPt gfw_undistort_coord_fullres(float x, float y, const gfw_kernel_params &P, const GfwCommon &C) {
+    float opx = gfw_map_coord(x, (float)P.output_rect[0], (float)(P.output_rect[0] + P.output_rect[2]), 0.0f, (float)P.output_width);
+    float opy = gfw_map_coord(y, (float)P.output_rect[1], (float)(P.output_rect[1] + P.output_rect[3]), 0.0f, (float)P.output_height);
+    opx += P.translation2d[0];
+    opy += P.translation2d[1];
+    const float r_limit_sq = P.r_limit * P.r_limit;
+
+    if (P.lens_correction_amount < 1.0f) gfw_lens_correction_blend<MODEL>(opx, opy, P, C);   // :429-460
 
     const bool hrs = (P.flags & 16) == 16;                                              // :465-479
     const int32_t lim = hrs ? P.width : P.height;

@@ -47,6 +47,7 @@ def test_physical_lens_models(model, lca):
         lens["r_limit"] = 2.5
     fr = S.SyntheticFrame("YUV422P16LE", w, h, seed=31, lens=lens, fov=1.2, base_overrides={"lens_correction_amount": lca})
     run(fr)
+    assert warp.last_backend().startswith("yuv_fused")  # every physical model, with and without the lens-correction blend, runs fused
 
 
 @pytest.mark.parametrize("digital", sorted(DIGITAL))
@@ -59,8 +60,7 @@ def test_digital_lenses(digital, lca):
                           base_overrides={"lens_correction_amount": lca, "digital_lens_params": DIGITAL[digital]})
     assert fr.planes[0]["params"].flags & abi.FLAG_HAS_DIGITAL_LENS
     run(fr)
-    if lca == 1.0:
-        assert warp.last_backend() == "yuv_fused"       # digital lenses run fused; the lens-correction blend does not
+    assert warp.last_backend() == "yuv_fused"           # digital lenses and the lens-correction blend run fused (generic-model instantiation)
 
 
 def test_r_limit_and_stretch_and_input_rotation():
