@@ -279,7 +279,10 @@ int gfw_set_option(gfw_ctx *c, int option, int64_t value) {
 void *gfw_get_stream(gfw_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int gfw_set_stream(gfw_ctx *c, void *s) {
     if (!c) return GFW_ERR_INVALID_ARGUMENT;
-    if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    // the previous stream is drained first: frames still in flight on it use this context's staging buffers and matrix slots,
+    // and nothing orders the new stream behind them
+    (void)hipStreamSynchronize(c->stream);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)s; c->own_stream = false;
     return GFW_OK;
 }
@@ -744,7 +747,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     Y.grid_limit = c->tune_grid > 0 ? c->tune_grid : c->num_cus * 6;
     Y.ablate = (c->kernel_variant >= 16) ? (c->kernel_variant - 16) : 0;      // timing ablations (results are wrong by design)
     bool table_ok = false;
-    fast1 = extras ? false : p1_setup(c, p0, h_matrices, matrix_count, Y, table_ok);
+    fast1 = (extras || p0.output_width > 65535 || p0.output_height > 65535) ? false : p1_setup(c, p0, h_matrices, matrix_count, Y, table_ok);   // deferred pixels are parked as (x | y << 16)
     // gfw_hot_kernel: certified second pass + integer-dot taps for the production configuration
     Y.hot = 0;
     if (table_ok && c->p2_ok && !extras && (c->kernel_variant == 5 || c->kernel_variant == 6) && p0.interpolation == 2 &&

@@ -34,6 +34,8 @@
 #include "gfw_warp.h"
 #include "gfw_fastmath.h"
 #include "gfw_frame.h"
+#include <cstdio>
+#include <cstdlib>
 
 // measured switches (1 = on): branch-free rounding, exact-FMA row sums, hardware min for the limit clamp
 #ifndef GFW_EXP_ROUND
@@ -53,10 +55,33 @@
                                  // frame: two dword gathers at 2-byte alignment against four aligned 16-bit ones); 8-bit planes gain (C1: 18.0 -> 16.3 us)
 #endif
 #ifndef GFW_WAVES_PER_EU
-#define GFW_WAVES_PER_EU 7       // register budget of the frame kernels, in waves per SIMD (512 / N VGPRs): the kernel is latency-bound and its speed follows occupancy
+#define GFW_WAVES_PER_EU 6       // register budget of the frame kernels, in waves per SIMD (512 / N VGPRs).  6: 71 VGPRs, 106 SGPRs = six workgroups
+                                 // per CU.  7 (94 SGPRs, more scalar reloads) measures 2-4 % slower even with seven workgroups per CU resident, 8
+                                 // (78 SGPRs: 700 v_readlane) 6 % slower: profiles/r02_scheduling_experiments.md
 #endif
 #ifndef GFW_PASS1_PAIR
-#define GFW_PASS1_PAIR 0         // first pass of the lane's pixel pair with packed math (hot_pass1_pair) in the default kernel
+#define GFW_PASS1_PAIR 0         // first pass of the lane's pixel pair with packed math (hot_pass1_pair) in the default kernel: measured 11 % slower
+#endif
+#ifndef GFW_HOT_ONLY
+#define GFW_HOT_ONLY 0           // A/B builds (tools/build_variants.sh): only the C2 instantiation (u16, 4:2:2 planar, bilinear), seconds to compile
+#endif
+#ifndef GFW_XCD_CHUNK
+#define GFW_XCD_CHUNK 0          // 0: each XCD walks one contiguous band of tiles; C > 0: chunks of C consecutive tiles are dealt round-robin to the
+                                 // XCDs (the bands differ by 3 % in cost; measured +0..3 %, inside the run-to-run noise: not enabled)
+#endif
+#ifndef GFW_PRIO_MODE
+#define GFW_PRIO_MODE 1          // wave issue priority by remaining work (s_setprio).  The SIMD arbiter serves the oldest wave first, so the six
+                                 // waves of a SIMD progress at 0.115 ... 0.196 lane-rows/us and finish up to 17 us apart
+                                 // (profiles/r02_wave_timeline.txt).  1: priority = min(3, remaining lane-rows / GFW_PRIO_DIV), re-evaluated every
+                                 // row: waves with more work left are served first and the finish times close up — C2: 80.5 -> 76.4 us per frame
+                                 // (DIV 3; 78.1 with 2 or 4).  2: min(3, remaining tiles): no gain.  0: off.
+#endif
+#ifndef GFW_PRIO_DIV
+#define GFW_PRIO_DIV 3
+#endif
+#ifndef GFW_TIMELINE
+#define GFW_TIMELINE 0           // diagnosis builds only: per-wave start / end / phase clocks and HW_ID into a device array that the 60th launch
+                                 // dumps to $GFW_TIMELINE_FILE (tools/analyze_timeline.py)
 #endif
 #ifndef GFW_TAP_ROW_UNROLL
 #define GFW_TAP_ROW_UNROLL 2      // tap rows fetched together by the bicubic / Lanczos4 paths (registers vs loads in flight)
@@ -730,6 +755,9 @@ __device__ __forceinline__ void hot_pass1_pair(gfw_f2 ox, float oy, const Mid &M
     sy1 = max(min(gfw_f2i(rintf(v.y)), (int)Q.lim), 0);
 }
 
+#if GFW_TIMELINE
+__device__ unsigned long long gfw_tl[8192 * 8];
+#endif
 template <int MODEL, typename T, int N0, int I, int DW, int DH, bool INTERLEAVED_UV, int RB, bool FAST1, bool AUDIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFW_WAVES_PER_EU, 8))) void gfw_yuv_kernel(const GfwYuvArgs A) {
     // tile = 64 x 4 lanes; each lane owns RB vertically stacked DW x DH luma blocks (+ their chroma sites).
@@ -777,17 +805,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFW_WAVES_P
 
     // persistent walk over this workgroup's share of the XCD band of tiles
     const int n_tiles = A.tiles_x * A.tiles_y;
+#if GFW_XCD_CHUNK > 0
+    const int per_xcd = ((((n_tiles + GFW_XCD_CHUNK - 1) / GFW_XCD_CHUNK) + 7) >> 3) * GFW_XCD_CHUNK;
+#define GFW_XCD_TILE(l) ((((l) / GFW_XCD_CHUNK) * 8 + xcd) * GFW_XCD_CHUNK + (l) % GFW_XCD_CHUNK)
+#else
     const int per_xcd = (n_tiles + 7) >> 3;
+#define GFW_XCD_TILE(l) (xcd * per_xcd + (l))
+#endif
     const int wg_per_xcd = (int)gridDim.x >> 3;
     const int xcd = (int)blockIdx.x & 7;
+#if GFW_TIMELINE
+    const unsigned long long tl_start = wall_clock64();
+    unsigned long long tl_p1 = 0, tl_p3 = 0, tl_units = 0;
+#endif
+#if GFW_PRIO_MODE
+    auto set_prio = [](int p) {                       // s_setprio takes an immediate
+        if (p <= 0) __builtin_amdgcn_s_setprio(0); else if (p == 1) __builtin_amdgcn_s_setprio(1);
+        else if (p == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+    };
+    int tiles_left = 0;
+    for (int tb = (int)blockIdx.x >> 3; tb < per_xcd && GFW_XCD_TILE(tb) < n_tiles; tb += wg_per_xcd) ++tiles_left;
+#endif
     for (int tb = (int)blockIdx.x >> 3; tb < per_xcd; tb += wg_per_xcd) {
-        const int t = xcd * per_xcd + tb;
+        const int t = GFW_XCD_TILE(tb);
         if (t >= n_tiles) break;
+#if GFW_PRIO_MODE == 2
+        set_prio(tiles_left < 3 ? tiles_left : 3);
+#elif GFW_PRIO_MODE == 1
+        set_prio((tiles_left * RB) / GFW_PRIO_DIV);
+#endif
         const int ty = t / A.tiles_x, tx = t - ty * A.tiles_x;
         const int cx = tx * 64 + lane;
         const int cy0 = (ty * 4 + wave) * RB;            // first chroma-site row of this lane
         const bool lane_ok = cx < A.cw;
 
+#if GFW_TIMELINE
+        const unsigned long long tl_a = __builtin_readcyclecounter();
+#endif
         // ---- phase 1: rolling-shutter row of every luma pixel of this lane ----------------------------
         if (two_pass) {
             if (FAST1) {
@@ -863,10 +917,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFW_WAVES_P
             }
         }
 
+#if GFW_TIMELINE
+        const unsigned long long tl_b = __builtin_readcyclecounter();
+#endif
         // ---- phase 3: exact projection with the row's own matrix, then taps ---------------------------
         if (lane_ok) {
             #pragma unroll 1
             for (int r = 0; r < RB; ++r) {
+#if GFW_PRIO_MODE == 1
+                set_prio(((tiles_left * RB) - r) / GFW_PRIO_DIV);
+#endif
                 const int cy = cy0 + r;
                 if (cy >= A.ch) break;
                 float u0 = 0.0f, v0 = 0.0f; bool ok0 = false;
@@ -919,7 +979,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFW_WAVES_P
             }
         }
         if (FAST1 && two_pass) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // s_rows is rewritten by the next tile
+#if GFW_PRIO_MODE
+        --tiles_left;
+#endif
+#if GFW_TIMELINE
+        { const unsigned long long tl_c = __builtin_readcyclecounter(); tl_p1 += tl_b - tl_a; tl_p3 += tl_c - tl_b; tl_units += (unsigned long long)RB; }
+#endif
     }
+#if GFW_TIMELINE
+    if (lane == 0) {       // per wave: start, end (100 MHz device clock), phase clocks, lane-rows, HW_ID, XCC_ID, workgroup
+        unsigned long long *o = gfw_tl + ((size_t)blockIdx.x * 4 + wave) * 8;
+        o[0] = tl_start; o[1] = wall_clock64(); o[2] = tl_p1; o[3] = tl_p3; o[4] = tl_units;
+        o[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); o[6] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); o[7] = blockIdx.x;
+    }
+#endif
+#undef GFW_XCD_TILE
 }
 
 
@@ -946,7 +1020,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFW_WAVES_P
 // (v_dot2_u32_u16 / v_dot4_u32_u8), converted exactly (< 2^22), multiplied by the integer y weight and scaled by 2^-10 at the
 // end — power-of-two scaling commutes with round-to-nearest, so the two roundings are the reference's.
 // =====================================================================================================================
-#if GFW_FRAME_TAPS == 2 && GFW_FRAME_KIND != 4
+#if GFW_FRAME_TAPS == 2 && GFW_FRAME_KIND != 4 && !GFW_HOT_ONLY
 __device__ __forceinline__ Bins2 hot_bins2(int bx, int by) {
     Bins2 b;
     b.sx = bx >> 5; b.sy = by >> 5;
@@ -1444,6 +1518,9 @@ hipError_t launch_mt(const GfwYuvArgs &A, int dw, int dh, bool interleaved, hipS
     grid = (grid + 7) & ~7;
     dim3 block(64, 4);
 #define GFW_YUV_LAUNCH(DW, DH, IL) hipLaunchKernelGGL((gfw_yuv_kernel<MODEL, T, N0, I, DW, DH, IL, RB, FAST1, AUDIT>), dim3(grid), block, 0, s, A)
+#if GFW_HOT_ONLY
+    if (dw == 2 && dh == 1 && !interleaved) GFW_YUV_LAUNCH(2, 1, false); else return hipErrorInvalidValue;
+#else
     if constexpr (N0 > 1 || is_f32<T>::value) {          // packed single plane, or planar f32 planes: full resolution only
         if (dw == 1 && dh == 1 && !interleaved) GFW_YUV_LAUNCH(1, 1, false);
         else return hipErrorInvalidValue;
@@ -1456,6 +1533,7 @@ hipError_t launch_mt(const GfwYuvArgs &A, int dw, int dh, bool interleaved, hipS
         else if (dw == 1 && dh == 1 && interleaved) GFW_YUV_LAUNCH(1, 1, true);
         else return hipErrorInvalidValue;
     }
+#endif
 #undef GFW_YUV_LAUNCH
     return hipGetLastError();
 }
@@ -1498,7 +1576,23 @@ static hipError_t launch_m(const GfwYuvArgs &A, int n0, int dw, int dh, bool int
 #define GFW_CAT(a, b) GFW_CAT2(a, b)
 #define GFW_FN GFW_CAT(GFW_CAT(gfw_launch_yuv_kind, GFW_FRAME_KIND), GFW_CAT(_taps, GFW_FRAME_TAPS))
 hipError_t GFW_FN(const GfwYuvArgs &A, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s) {
-#if GFW_FRAME_TAPS == 2 && GFW_FRAME_KIND != 4
+#if GFW_HOT_ONLY
+    if (A.model == GFW_MODEL_OPENCV_FISHEYE && !A.extras && n0 == 1 && dw == 2 && dh == 1 && !interleaved && fast1 && !A.audit && !A.hot && GFW_FRAME_KIND == 2 && GFW_FRAME_TAPS == 2) {
+        const hipError_t e = launch_mt<GFW_MODEL_OPENCV_FISHEYE, uint16_t, 1, 2, GFW_YUV_RB_FAST, true, false>(A, dw, dh, interleaved, s);
+#if GFW_TIMELINE
+        static int n_launch = 0;
+        if (++n_launch == 60 && getenv("GFW_TIMELINE_FILE")) {
+            static unsigned long long host[8192 * 8];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(gfw_tl), sizeof(host));
+            if (FILE *f = fopen(getenv("GFW_TIMELINE_FILE"), "wb")) { fwrite(host, 1, sizeof(host), f); fclose(f); }
+        }
+#endif
+        return e;
+    }
+    return hipErrorInvalidValue;
+#else
+#if GFW_FRAME_TAPS == 2 && GFW_FRAME_KIND != 4 && !GFW_HOT_ONLY
     if (A.hot) {
         if (n0 != 1 || dw != 2 || A.model != GFW_MODEL_OPENCV_FISHEYE || A.extras) return hipErrorInvalidValue;
 #if GFW_FRAME_KIND == 1
@@ -1510,4 +1604,5 @@ hipError_t GFW_FN(const GfwYuvArgs &A, int n0, int dw, int dh, bool interleaved,
 #endif
     if (A.model == GFW_MODEL_OPENCV_FISHEYE && !A.extras) return launch_m<GFW_MODEL_OPENCV_FISHEYE>(A, n0, dw, dh, interleaved, fast1, s);
     return launch_m<-1>(A, n0, dw, dh, interleaved, false, s);
+#endif
 }

@@ -1,10 +1,15 @@
 #!/bin/bash
-# A/B builds of the hot translation unit (u16, bilinear): libgfwarp_<name>.so under build/variants (benchmarking only)
+# A/B builds of the hot translation unit (u16, bilinear, C2 instantiation only): variants/libgfwarp_<name>.so (benchmarking only).
+# usage: tools/build_variants.sh name:-DFOO=1,-DBAR=2 ...      (library selected at run time with GFW_LIBRARY=...)
 set -e
 cd /root/repo
-mkdir -p build/variants
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-result -DGFW_FRAME_KIND=2 -DGFW_FRAME_TAPS=2"
-build() { name=$1; shift; /opt/rocm/bin/hipcc $FLAGS "$@" -c gyroflow_amd/csrc/gfw_frame.hip -o build/variants/frame_$name.o 2>/dev/null; 
-  objs=$(ls build/gfwarp/*.o | grep -v gfw_frame_k2_t2.o); /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared $objs build/variants/frame_$name.o -o build/variants/libgfwarp_$name.so; echo built $name; }
-for spec in "$@"; do name=${spec%%:*}; defs=${spec#*:}; build $name $(echo $defs | tr ',' ' ') & done
+mkdir -p build/variants variants
+HIPCC=/opt/rocm/bin/hipcc
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-result -Wno-pass-failed -Iinclude -DGFW_FRAME_KIND=2 -DGFW_FRAME_TAPS=2 -DGFW_HOT_ONLY=1"
+[ build/variants/stubs.o -nt tools/variant_stubs.cpp ] || $HIPCC --offload-arch=gfx950 -O2 -std=c++17 -fPIC -Iinclude -c tools/variant_stubs.cpp -o build/variants/stubs.o
+build() { name=$1; shift
+  $HIPCC $FLAGS "$@" -c gyroflow_amd/csrc/gfw_frame.hip -o build/variants/frame_$name.o 2>build/variants/frame_$name.log || { cat build/variants/frame_$name.log; exit 1; }
+  $HIPCC --offload-arch=gfx950 -fPIC -shared build/gfwarp/gfw_api.o build/gfwarp/gfw_kernels.o build/gfwarp/gfw_matrices.o build/variants/stubs.o build/variants/frame_$name.o -o variants/libgfwarp_$name.so
+  echo "built $name ($(stat -c %s variants/libgfwarp_$name.so) bytes)"; }
+for spec in "$@"; do name=${spec%%:*}; defs=""; [[ "$spec" == *:* ]] && defs=${spec#*:}; build $name $(echo $defs | tr ',' ' ') & done
 wait

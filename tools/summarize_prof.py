@@ -12,7 +12,7 @@ for f in sorted(glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"),
     print("== kernel stats:", os.path.relpath(f, out))
     for row in csv.DictReader(open(f)):
         print("  %-90s calls=%s total_ns=%s avg_ns=%s pct=%s" % (row.get("Name", "")[:90], row.get("Calls"), row.get("TotalDurationNs"), row.get("AverageNs"), row.get("Percentage")))
-for d in ("pmc1", "pmc2", "pmc3", "pmc4", "pmc5"):
+for d in ["pmc%d" % i for i in range(1, 13)]:
     for f in sorted(glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True)):
         acc = defaultdict(lambda: defaultdict(list))
         for row in csv.DictReader(open(f)):
