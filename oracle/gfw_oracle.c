@@ -18,7 +18,12 @@
  * built here (no cargo/rustc).  What pins this file instead:
  *   - analytic known-answer tests (identity warp, integer translation,
  *     background fill, out-of-frame) in tests/test_oracle_kat.py,
- *   - self-generated golden checksums in tests/golden/ (script committed).
+ *   - self-generated golden checksums in tests/golden/ (script committed),
+ *   - 40-digit mpmath statements of the 14 lens models, both directions, written from
+ *     the Rust independently of this file (tests/test_oracle_mpmath.py),
+ *   - the reference's own OpenCL kernel compiled offline for gfx950 (oracle/build_ref_cl.py)
+ *     and run beside this file on the GPU box as a tolerance-level second opinion
+ *     (tests/test_gpu_ref_opencl.py: >= 99.8 % identical pixels).
  *
  * Rust semantics honoured here:
  *   f32::round      = half away from zero            -> roundf
