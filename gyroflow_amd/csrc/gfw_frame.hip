@@ -759,7 +759,11 @@ __device__ __forceinline__ void hot_pass1_pair(gfw_f2 ox, float oy, const Mid &M
 __device__ unsigned long long gfw_tl[8192 * 8];
 #endif
 template <int MODEL, typename T, int N0, int I, int DW, int DH, bool INTERLEAVED_UV, int RB, bool FAST1, bool AUDIT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFW_WAVES_PER_EU, 8))) void gfw_yuv_kernel(const GfwYuvArgs A) {
+// Register budget: the specialised-fisheye instantiations are held to GFW_WAVES_PER_EU waves per SIMD.  The generic-model ones
+// (every other lens, digital lenses, refraction, IBIS/OIS, lens-correction blend) would pay for that budget with 450-840 bytes
+// of scratch per lane, and left alone they take up to 277 VGPRs (one wave per SIMD); three waves per SIMD (168 VGPRs) holds them
+// with 0-250 bytes of scratch (tools/kernel_resources.py).  Not yet measured against 4 (128 VGPRs, 110-500 bytes).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GFW_MODEL_OPENCV_FISHEYE ? GFW_WAVES_PER_EU : 3, 8))) void gfw_yuv_kernel(const GfwYuvArgs A) {
     // tile = 64 x 4 lanes; each lane owns RB vertically stacked DW x DH luma blocks (+ their chroma sites).
     constexpr int NPX = DW * DH;
     constexpr int QCAP = 128 * NPX;                  // a wave adds at most 64*NPX entries per row; flushed at half full
@@ -1543,7 +1547,7 @@ hipError_t launch_mt(const GfwYuvArgs &A, int dw, int dh, bool interleaved, hipS
 template <int MODEL, typename T, int N0>
 static hipError_t launch_tn(const GfwYuvArgs &A, int dw, int dh, bool interleaved, bool fast1, hipStream_t s) {
     constexpr int I = GFW_FRAME_TAPS;
-    if (MODEL == GFW_MODEL_OPENCV_FISHEYE && fast1) {
+    if constexpr (MODEL == GFW_MODEL_OPENCV_FISHEYE) if (fast1) {      // the certified first pass exists for the specialised fisheye model only
         if (I == 2 && A.audit) return launch_mt<MODEL, T, N0, I, GFW_YUV_RB_FAST, true, (I == 2)>(A, dw, dh, interleaved, s);
         return launch_mt<MODEL, T, N0, I, GFW_YUV_RB_FAST, true, false>(A, dw, dh, interleaved, s);
     }
