@@ -84,6 +84,25 @@ __device__ __forceinline__ float gfw_atanf_pos(float x) {
     return (x != x) ? x + x : r;
 }
 
+// The same function with the reduction read from a 6-record table in LDS instead of selected (gfw_math.h: gfw_atanf_tab_*;
+// host-checked against gfw_atanf on every finite float >= 0).  For FINITE x >= 0 only (0 * inf would be NaN): the fused kernel
+// calls it on r = sqrt(a^2 + b^2) of operands inside the lean range, which is finite.  ~17 VALU instructions fewer than the
+// select-based form, two LDS reads more.  Opt-in (GFW_ATAN_TABLE) until it has been timed on the device.
+__device__ __forceinline__ float *gfw_atan_lds() { __shared__ float tab[48]; return tab; }
+__device__ const float GFW_ATAN_TAB[48] = GFW_ATAN_TAB_INIT;
+__device__ __forceinline__ void gfw_atan_lds_init(int tid) {                       // every thread of the workgroup, before the first use
+    if (tid < 48) gfw_atan_lds()[tid] = GFW_ATAN_TAB[tid];
+    __syncthreads();
+}
+__device__ __forceinline__ float gfw_atanf_pos_tab(float x) {
+    const float *rec = gfw_atan_lds() + 8 * gfw_atanf_tab_id(x);
+    const float4 ab = *reinterpret_cast<const float4 *>(rec);
+    const float2 hl = *reinterpret_cast<const float2 *>(rec + 4);
+    const float pn = ab.x * x, pd = ab.z * x;
+    const float num = pn + ab.y, den = pd + ab.w;
+    return gfw_atanf_tab_finish(gfw_div_lean(num, den), hl.x, hl.y);           // den in [1, 2^25.6], |num| <= 2^26: in range
+}
+
 // RN(RN(x * mul) / den) for a constant (mul, den) pair: the reference's map_coord with in_min = out_min = 0,
 //   (x - 0) * (out_max - 0) / (in_max - 0) + 0            (util.rs:144-147)
 // evaluated with the precomputed RN(1/den).  The host validates (exhaustively over all 2^23 significands) that

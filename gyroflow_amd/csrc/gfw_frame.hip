@@ -69,6 +69,10 @@
 #define GFW_XCD_CHUNK 0          // 0: each XCD walks one contiguous band of tiles; C > 0: chunks of C consecutive tiles are dealt round-robin to the
                                  // XCDs (the bands differ by 3 % in cost; measured +0..3 %, inside the run-to-run noise: not enabled)
 #endif
+#ifndef GFW_ATAN_TABLE
+#define GFW_ATAN_TABLE 0         // exact projection's atanf with the table-driven reduction (gfw_fastmath.h: gfw_atanf_pos_tab): bit-identical on
+                                 // the host, ~17 instructions fewer per projection; not yet timed on the device
+#endif
 #ifndef GFW_PRIO_MODE
 #define GFW_PRIO_MODE 1          // wave issue priority by remaining work (s_setprio).  The SIMD arbiter serves the oldest wave first, so the six
                                  // waves of a SIMD progress at 0.115 ... 0.196 lane-rows/us and finish up to 17 us apart
@@ -134,7 +138,11 @@ struct LeanOps {
             const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
             return x - x * (s1 + s2);
         }
+#if GFW_ATAN_TABLE
+        return gfw_atanf_pos_tab(x);
+#else
         return gfw_atanf_pos(x);
+#endif
     }
 };
 
@@ -774,6 +782,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
     __shared__ int s_rows[RB * NPX][256];                                        // phase-1 rows, one column per lane
     __shared__ float s_lut[I == 2 ? 1 : 448];                                    // bicubic / Lanczos4 tap table
     const int wave = threadIdx.y, lane = threadIdx.x, tid = wave * 64 + lane;
+#if GFW_ATAN_TABLE
+    if (MODEL == GFW_MODEL_OPENCV_FISHEYE) gfw_atan_lds_init(tid);
+#endif
     if (I != 2) {
         for (int i = tid; i < 448; i += 256) s_lut[i] = GFW_COEFFS[i];
         __syncthreads();

@@ -63,6 +63,39 @@ GFW_HD float gfw_atanf(float x) {
     return (hx >> 31) ? -r : r;
 }
 
+// ---- atanf for finite x >= 0 with the reduction read from a table ----------------------------------------------------
+// The five reduced arguments of gfw_atanf are all (a_n*x + b_n) / (a_d*x + b_d) with the products exact or rounded exactly
+// where the reference rounds (2x, 1.5x), so the interval only selects six constants: GFW_ATAN_TAB[id] = {a_n, b_n, a_d, b_d,
+// hi, lo, 0, 0}.  id 0 (x < 0.4375) has hi = lo = 0 and t = x/1, and -(t*(s1+s2) - t) is x - x*(s1+s2) bit for bit; id 5
+// (x >= 2^25) yields t = 0 and hi - (-lo) = hi3 + lo3.  Not for NaN / infinity (0 * inf).  The caller divides (IEEE `/` on the
+// host, the lean correctly-rounded divide on the device); tests/test_math_host.py compares the composition with gfw_atanf on
+// every finite non-negative float.
+#define GFW_ATAN_TAB_INIT { \
+    1.0f,  0.0f, 0.0f, 1.0f, 0.0f,             0.0f,             0.0f, 0.0f, \
+    2.0f, -1.0f, 1.0f, 2.0f, 4.6364760399e-01f, 5.0121582440e-09f, 0.0f, 0.0f, \
+    1.0f, -1.0f, 1.0f, 1.0f, 7.8539812565e-01f, 3.7748947079e-08f, 0.0f, 0.0f, \
+    1.0f, -1.5f, 1.5f, 1.0f, 9.8279368877e-01f, 3.4473217170e-08f, 0.0f, 0.0f, \
+    0.0f, -1.0f, 1.0f, 0.0f, 1.5707962513e+00f, 7.5497894159e-08f, 0.0f, 0.0f, \
+    0.0f,  0.0f, 0.0f, 1.0f, 1.5707962513e+00f, 7.5497894159e-08f, 0.0f, 0.0f }
+GFW_HD int gfw_atanf_tab_id(float x) {
+    return (int)(x >= 0.4375f) + (int)(x >= 0.6875f) + (int)(x >= 1.1875f) + (int)(x >= 2.4375f) + (int)(x >= 33554432.0f);
+}
+GFW_HD void gfw_atanf_tab_reduce(float x, const float *rec, float *num, float *den) {
+    const float pn = rec[0] * x, pd = rec[2] * x;       // separate roundings, as the reference's 2.0f*x and 1.5f*x
+    *num = pn + rec[1];
+    *den = pd + rec[3];
+}
+GFW_HD float gfw_atanf_tab_finish(float t, float hi, float lo) {
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+                aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+                aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    const float z = t * t;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    return hi - ((t * (s1 + s2) - lo) - t);
+}
+
 // ---- tanf -------------------------------------------------------------------
 // kernel on [-pi/4, pi/4] with a tail term y; iy = 1 -> tan, -1 -> -1/tan.
 GFW_HD float gfw_kernel_tanf(float x, float y, int iy) {

@@ -101,3 +101,36 @@ def test_sinf_cosf_bit_identical_to_libm_on_all_inputs(tmp_path):
     subprocess.check_call(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fno-fast-math", str(c), "-o", str(exe), "-lm"])
     out = subprocess.check_output([str(exe)], timeout=900).decode().split()
     assert out == ["0", "0"], "mismatches vs libm: sinf %s, cosf %s" % tuple(out)
+
+
+ATAN_TAB_SRC = r"""
+#include <math.h>
+#include <stdio.h>
+#include <stdint.h>
+#include "%s/gyroflow_amd/csrc/gfw_math.h"
+static const float TAB[48] = GFW_ATAN_TAB_INIT;
+int main(void) {
+    long bad = 0;
+    #pragma omp parallel for reduction(+:bad) schedule(static)
+    for (long i = 0; i < 0x7f800000L; ++i) {                      /* every finite float >= +0 */
+        const float x = gfw_u2f((uint32_t)i);
+        const float *rec = TAB + 8 * gfw_atanf_tab_id(x);
+        float num, den;
+        gfw_atanf_tab_reduce(x, rec, &num, &den);
+        const float got = gfw_atanf_tab_finish(num / den, rec[4], rec[5]);
+        if (gfw_f2u(got) != gfw_f2u(gfw_atanf(x))) bad++;
+    }
+    printf("%%ld\n", bad);
+    return 0;
+}
+"""
+
+
+def test_table_driven_atan_reduction_equals_gfw_atanf_on_every_finite_non_negative_float(tmp_path):
+    """gfw_atanf_tab_{id,reduce,finish} (the select-free reduction prepared for the fused kernel, GFW_ATAN_TABLE) composed with an
+    IEEE division, against gfw_atanf — which the first test of this file pins to libm — on all 2^31 - 2^23 finite floats >= 0."""
+    c = tmp_path / "t.c"
+    c.write_text(ATAN_TAB_SRC % ROOT)
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fno-fast-math", str(c), "-o", str(exe), "-lm"])
+    assert subprocess.check_output([str(exe)], timeout=900).decode().split() == ["0"]
