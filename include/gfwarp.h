@@ -270,6 +270,7 @@ int   gfw_set_option(gfw_ctx *ctx, int option, int64_t value);
  * own stream (e.g. the decoder's) — mirrors passing the cl_command_queue in
  * BufferSource::OpenCL{queue} (gpu/mod.rs:37-40). */
 void *gfw_get_stream(gfw_ctx *ctx);
+/* Drains the stream in use (hipStreamSynchronize), then adopts `hip_stream` (not owned; NULL = the legacy default stream). */
 int   gfw_set_stream(gfw_ctx *ctx, void *hip_stream);
 int   gfw_synchronize(gfw_ctx *ctx);
 /* Name of the kernel path the last call took ("plane_generic", "yuv_fused", ...):
