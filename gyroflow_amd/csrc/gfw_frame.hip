@@ -69,6 +69,9 @@
 #define GFW_XCD_CHUNK 0          // 0: each XCD walks one contiguous band of tiles; C > 0: chunks of C consecutive tiles are dealt round-robin to the
                                  // XCDs (the bands differ by 3 % in cost; measured +0..3 %, inside the run-to-run noise: not enabled)
 #endif
+#ifndef GFW_GENERIC_WAVES_PER_EU
+#define GFW_GENERIC_WAVES_PER_EU 3   // register budget of the generic-model instantiations (see the kernel's attribute)
+#endif
 #ifndef GFW_ATAN_TABLE
 #define GFW_ATAN_TABLE 0         // exact projection's atanf with the table-driven reduction (gfw_fastmath.h: gfw_atanf_pos_tab): bit-identical on
                                  // the host, ~17 instructions fewer per projection; not yet timed on the device
@@ -771,7 +774,7 @@ template <int MODEL, typename T, int N0, int I, int DW, int DH, bool INTERLEAVED
 // (every other lens, digital lenses, refraction, IBIS/OIS, lens-correction blend) would pay for that budget with 450-840 bytes
 // of scratch per lane, and left alone they take up to 277 VGPRs (one wave per SIMD); three waves per SIMD (168 VGPRs) holds them
 // with 0-250 bytes of scratch (tools/kernel_resources.py).  Not yet measured against 4 (128 VGPRs, 110-500 bytes).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GFW_MODEL_OPENCV_FISHEYE ? GFW_WAVES_PER_EU : 3, 8))) void gfw_yuv_kernel(const GfwYuvArgs A) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GFW_MODEL_OPENCV_FISHEYE ? GFW_WAVES_PER_EU : GFW_GENERIC_WAVES_PER_EU, 8))) void gfw_yuv_kernel(const GfwYuvArgs A) {
     // tile = 64 x 4 lanes; each lane owns RB vertically stacked DW x DH luma blocks (+ their chroma sites).
     constexpr int NPX = DW * DH;
     constexpr int QCAP = 128 * NPX;                  // a wave adds at most 64*NPX entries per row; flushed at half full

@@ -1,0 +1,19 @@
+#!/bin/bash
+# A/B runs queued for the first GPU call of the next round (everything below builds in seconds and is bit-exact by construction
+# or host-checked; none of it has been timed).  Run on the CPU box:   bash tools/next_round_ab.sh build
+# then:   gpurun --timeout 300 -- 'bash tools/next_round_ab.sh run'
+set -e
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+if [ "$1" = build ]; then
+  rm -f variants/*
+  bash tools/build_variants.sh "base:" "prio0:-DGFW_PRIO_MODE=0" \
+      "atan_tab:-DGFW_ATAN_TABLE=1" "ck30:-DGFW_XCD_CHUNK=30" "atan_ck30:-DGFW_ATAN_TABLE=1,-DGFW_XCD_CHUNK=30" \
+      "tl:-DGFW_TIMELINE=1" "tl_atan:-DGFW_TIMELINE=1,-DGFW_ATAN_TABLE=1"
+  # register budget of the generic-model instantiations (digital lenses, refraction, IBIS, non-fisheye lenses): whole translation unit
+  GFW_VARIANT_FULL=1 bash tools/build_variants.sh "gen3:-DGFW_GENERIC_WAVES_PER_EU=3" "gen4:-DGFW_GENERIC_WAVES_PER_EU=4" \
+      "gen6:-DGFW_GENERIC_WAVES_PER_EU=6" "gen2:-DGFW_GENERIC_WAVES_PER_EU=2"
+  exit 0
+fi
+bash tools/gpu_ab.sh r03a base prio0 atan_tab ck30 atan_ck30 tl tl_atan base \
+    "gen3:--digital gopro_superview --steps 60" "gen4:--digital gopro_superview --steps 60" \
+    "gen6:--digital gopro_superview --steps 60" "gen2:--digital gopro_superview --steps 60"
