@@ -82,6 +82,9 @@ def parse_args(argv):
     ap.add_argument("--digital", default="", help="digital lens on top of the physical one (gopro_superview, gopro_hyperview, ...)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=1, choices=(1, 2, 4),
+                    help="contexts (each with its own HIP stream) the frames are dealt to in turn: consecutive frames are independent, so the "
+                         "occupancy tail of one frame's kernel can be filled by the next frame's workgroups (resident-matrices workloads only)")
     ap.add_argument("--build-matrices", action="store_true",
                     help="build every frame's per-row matrices on the device from quaternion tracks (gfw_build_matrices, "
                          "the 'next' row f-1) inside the timed region instead of using pre-packed resident tables")
@@ -304,6 +307,23 @@ def worker(args):
         d_mat = [torch.from_numpy(warp.pack_matrices(fr.matrices)).to(dev) for fr in frames]
         be.set_option(abi.OPT_MATRICES_ON_DEVICE, 2)
         calls = [warp.FrameCall(be, bufsets[j * N_DST + (j % N_DST)], tmpl, types, d_mat[j].data_ptr(), rows_n) for j in range(NR)]
+    # --streams S: S contexts, each on a stream of its own, take the frames in turn.  Frame k writes destination set k mod N_DST and
+    # S divides N_DST, so two frames that share a destination set always share a stream (ordered); everything else may overlap.
+    n_streams = args.streams if not (device_built or args.upload_matrices or args.host_buffers or args.c5) else 1
+    extra_bes, extra_streams, calls_by_stream = [], [], [calls]
+    for _ in range(1, n_streams):
+        st = torch.cuda.Stream(device=dev)
+        b2 = warp.Backend(tmpl[0], types[0], frames[0].model, frames[0].digital, bufsets[0][0])
+        b2.set_stream(st.cuda_stream)
+        b2.set_option(abi.OPT_SYNCHRONOUS, 0)
+        if args.variant:
+            b2.set_option(abi.OPT_KERNEL_VARIANT, args.variant)
+        if args.grid:
+            b2.set_option(abi.OPT_TUNE_GRID, args.grid)
+        b2.set_option(abi.OPT_MATRICES_ON_DEVICE, 2)
+        extra_bes.append(b2); extra_streams.append(st)
+        calls_by_stream.append([warp.FrameCall(b2, bufsets[j * N_DST + (j % N_DST)], tmpl, types, d_mat[j].data_ptr(), rows_n) for j in range(NR)])
+    all_bes = [be] + extra_bes
 
     # what step k of this rank reads and writes: (global frame, source set, destination set)
     def plan(k):
@@ -340,6 +360,8 @@ def worker(args):
             call()
             if args.c5:
                 sum_fn(ctxp, dst_ptrs[d], dst_total, sum_base + 8 * k)           # the frame's checksum, in order on the same stream
+        elif n_streams > 1:
+            calls_by_stream[k % n_streams][j]()
         else:
             calls[j]()
 
@@ -349,15 +371,17 @@ def worker(args):
     if args.c5:
         d_sums.zero_()                                # gfw_checksum64 accumulates
     pe = args.profile_every
-    be.set_option(abi.OPT_PROFILE, 1 if pe == 1 else 0)
-    be.get_profile(reset=True)
+    for b in all_bes:
+        b.set_option(abi.OPT_PROFILE, 1 if pe == 1 else 0)
+        b.get_profile(reset=True)
     shard.barrier(dist)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     if pe > 1:
-        set_opt, ctxp2 = be.lib.gfw_set_option, be.ctx
+        set_opt, ctxps = be.lib.gfw_set_option, [b.ctx for b in all_bes]
         for k in range(n_steps):
             if k % pe == 0:
+                ctxp2 = ctxps[k % n_streams]
                 set_opt(ctxp2, abi.OPT_PROFILE, 1)
                 step(k)
                 set_opt(ctxp2, abi.OPT_PROFILE, 0)
@@ -371,8 +395,11 @@ def worker(args):
     shard.barrier(dist)
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    kernel_ms, launches = be.get_profile(reset=True)
-    be.set_option(abi.OPT_PROFILE, 0)
+    kernel_ms, launches = 0.0, 0
+    for b in all_bes:
+        km, ln = b.get_profile(reset=True)
+        kernel_ms += km; launches += ln
+        b.set_option(abi.OPT_PROFILE, 0)
     elapsed = shard.reduce_max(dist, elapsed, cdev)
 
     def dst_host(d, p):
@@ -412,7 +439,8 @@ def worker(args):
         "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": n_steps, "warmup": n_warm,
         "ms_per_step": round(elapsed / max(n_steps, 1) * 1e3, 5), "higher_is_better": True, "scaling": "strong" if args.c5 else "weak",
         "vs_baseline": None, "dtype": "f32 coordinates, %s pixels" % np.dtype(abi.PIXEL_TYPES[types[0]][1]).name, "data": "synthetic",
-        "config": {"workload": workload, "frames_per_rank": n_steps, "frames_total": frames_done, "parallelism": "frame-sharded x%d" % world,
+        "config": {"workload": workload + ("" if n_streams == 1 else "; frames dealt to %d contexts / HIP streams in turn (bracketed kernel times overlap their neighbours)" % n_streams),
+                   "streams_per_rank": n_streams, "frames_per_rank": n_steps, "frames_total": frames_done, "parallelism": "frame-sharded x%d" % world,
                    "backend": warp.last_backend(), "checksum": crc, "rank_checksums": rank_crcs,
                    "host_enqueue_ms_per_step": round(t_enq / max(n_steps, 1) * 1e3, 5),
                    "device": info.value.decode(), "collectives": (args.backend if dist is not None else "none (1 rank)")},
@@ -485,6 +513,8 @@ def worker(args):
             out["cpu_baseline"] = {"value": round(luma_px / med / 1e6, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
                                    "sample": "median of %d frames of the same workload (2 warm-ups) through oracle/gfw_oracle.c, OpenMP rows on %d threads "
                                              "(nproc %d); mean %.3f Mpix/s" % (len(times), cores, os.cpu_count() or 0, luma_px * len(times) / sum(times) / 1e6)}
+    for b in extra_bes:
+        b.close()
     be.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
