@@ -642,7 +642,14 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     for (int i = 0; i < nplanes; ++i) {
         const gfw_kernel_params &p = params[i];
         if ((p.interpolation != 2 && p.interpolation != 4 && p.interpolation != 8) || p.interpolation != p0.interpolation) return false;
-        if (p.background_mode < 0 || p.background_mode > 2 || p.background_mode != p0.background_mode || p.input_rotation != 0.0f) return false;
+        // background mode 3 (margin with feather) runs fused only on request (GFW_OPT_KERNEL_VARIANT = 7) until that path has been
+        // through the GPU parity suite; by default it takes the per-plane kernel like every setting the fused kernel does not serve
+        const int bg_max = (c->kernel_variant == 7) ? 3 : 2;
+        if (p.background_mode < 0 || p.background_mode > bg_max || p.background_mode != p0.background_mode || p.input_rotation != 0.0f) return false;
+        if (p.background_mode == 3) {
+            if (p.background_margin != p0.background_margin || p.background_margin_feather != p0.background_margin_feather) return false;
+            extras |= 16;                                                        // two samples + blend (:576-613), generic-model instantiation
+        }
         if (!(p.lens_correction_amount == p.lens_correction_amount) || p.lens_correction_amount != p0.lens_correction_amount) return false;
         if (p.lens_correction_amount < 1.0f) extras |= 8;                        // the blend of :429-460 (generic-model instantiation)
         if (!(p.light_refraction_coefficient == p.light_refraction_coefficient) || p.light_refraction_coefficient != p0.light_refraction_coefficient) return false;

@@ -32,11 +32,12 @@ struct GfwYuvArgs {
     int32_t model;
     int32_t k_all_zero;               // k[0..3] all zero (opencv_fisheye.rs:75)
     int32_t hstretch_div, vstretch_div;
-    int32_t background_mode;          // 0 solid, 1 edge repeat, 2 edge mirror (3 = margin+feather stays on the per-plane kernel)
+    int32_t background_mode;          // 0 solid, 1 edge repeat, 2 edge mirror, 3 margin + feather (with extras & 16)
     int32_t grid_limit;               // persistent workgroups to launch (0 = default)
     int32_t extras;                   // features served by the generic-model instantiation only: 1 IBIS/OIS terms in the
                                       // matrix rows, 2 digital lens, 4 light refraction (cpu_undistort.rs:143-165, :216-220),
-                                      // 8 lens-correction blend (lens_correction_amount < 1, :429-460)
+                                      // 8 lens-correction blend (lens_correction_amount < 1, :429-460),
+                                      // 16 background mode 3: margin with feather (:576-613)
     int32_t ablate;                   // benchmark-only ablation bits (0 in production): 1 no first pass, 2 no luma taps, 4 no chroma, 8 no projection
     float hstretch, vstretch;
     float f[2], c[2], k[12];

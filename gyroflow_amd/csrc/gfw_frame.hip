@@ -676,6 +676,55 @@ __device__ __forceinline__ void sample_store_uv2(float u, float v, bool ok, cons
     store_px<T, 1>(PV.dst, doff, &ov);
 }
 
+// ---- background mode 3 ("margin with feather", cpu_undistort.rs:576-613) ----------------------------------------------------
+// Near the frame border the pixel is c1 * alpha + c2 * (1 - alpha): c1 sampled at the projected point, c2 at the point pulled
+// towards the centre by background_margin, alpha the distance to the border in units of the feather.  uv lives in full-resolution
+// coordinates for every plane, so alpha and the second point are the same for a luma pixel and the chroma site that shares its
+// coordinate.  Served by the generic-model instantiation only (extras & 16).
+struct Feather { float alpha, x2, y2; };
+__device__ __forceinline__ Feather feather_of(float ux, float uy, const GfwYuvArgs &A) {
+    const float width_f = (float)A.width, height_f = (float)A.height;
+    const float widthf = width_f - 1.0f, heightf = height_f - 1.0f;
+    const float feather = fmaxf(A.kp.background_margin_feather * heightf, 0.0001f);
+    Feather f{1.0f, ux, uy};
+    if ((ux > widthf - feather) || (ux < feather) || (uy > heightf - feather) || (uy < feather)) {
+        f.alpha = fmaxf(fminf(fminf(fminf(fminf(widthf - ux, heightf - uy), ux), uy) / feather, 1.0f), 0.0f);
+        float p2x = ux / width_f, p2y = uy / height_f;
+        p2x = ((p2x - 0.5f) * (1.0f - A.kp.background_margin)) + 0.5f;
+        p2y = ((p2y - 0.5f) * (1.0f - A.kp.background_margin)) + 0.5f;
+        f.x2 = p2x * width_f; f.y2 = p2y * height_f;
+    }
+    return f;
+}
+// sample_input_at for the LUT samplers (cpu_undistort.rs:371-418) without the store: N channels of one plane at (u, v).
+template <typename T, int N, int I>
+__device__ __forceinline__ void sample_only(float u, float v, const GfwYuvPlane &P, const float *bg, float limit, const float *lut, float *out) {
+    if (I == 2) {
+        const Bins2 b = make_bins2(u, v);
+        if ((unsigned)b.sx < (unsigned)(P.w - 1) && (unsigned)b.sy < (unsigned)(P.h - 1))
+            taps_inside2<T, N>(P.src, b.sy * P.src_stride + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
+        else
+            taps_edge2<T, N>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
+    } else {
+        const Bins<I> b = make_bins<I>(u, v, lut);
+        if (bins_inside<T, N, I>(b, P.w, P.h))
+            taps_inside<T, N, I>(P.src, b.sy * P.src_stride + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
+        else
+            taps_edge<T, N, I>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
+    }
+}
+// One plane's pixel in background mode 3: two samples, blended, stored.  (mul_x, mul_y) = the plane's source_rect map.
+template <typename T, int N, int I, bool INF_SAFE>
+__device__ __forceinline__ void feather_store(float ux, float uy, const Feather &f, const GfwYuvPlane &P, const float *bg, float limit,
+                                              float mul_x, float mul_y, const Maps &MP, int ox, int oy, const float *lut) {
+    float c1[N], c2[N], px[N];
+    sample_only<T, N, I>(map_c<INF_SAFE>(ux, mul_x, MP.den_x, MP.rcp_x), map_c<INF_SAFE>(uy, mul_y, MP.den_y, MP.rcp_y), P, bg, limit, lut, c1);
+    sample_only<T, N, I>(map_c<INF_SAFE>(f.x2, mul_x, MP.den_x, MP.rcp_x), map_c<INF_SAFE>(f.y2, mul_y, MP.den_y, MP.rcp_y), P, bg, limit, lut, c2);
+    #pragma unroll
+    for (int c = 0; c < N; ++c) px[c] = c1[c] * f.alpha + c2[c] * (1.0f - f.alpha);
+    store_px<T, N>(P.dst, oy * P.dst_stride + ox * (int)(N * sizeof(T)), px);
+}
+
 // ---- first pass (rolling-shutter row pick) -----------------------------------------------------------------
 // The mid-row projection of undistort_coord (cpu_undistort.rs:470-479) is used for ONE thing: the integer
 // sy = clamp(round(p.y)).  FAST1 evaluates p.y with fused arithmetic and a per-lens table of
@@ -963,7 +1012,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
                         if (AUDIT && (unsigned)row >= (unsigned)A.matrix_count) atomicAdd(&A.audit[5], 1ull);
                         p = rd_row<MODEL>(ox, oy, row, L, A);
                     }
-                    if (A.background_mode != 0 && p.ok) {                      // cpu_undistort.rs:495-509 (edge repeat / edge mirror)
+                    if ((A.background_mode == 1 || A.background_mode == 2) && p.ok) {                      // cpu_undistort.rs:495-509 (edge repeat / edge mirror)
                         const float width_f = (float)A.width, height_f = (float)A.height;
                         if (A.background_mode == 1) {
                             p.x = fminf(fmaxf(p.x, 3.0f), width_f - 3.0f);
@@ -978,11 +1027,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
                         }
                     }
                     if (k == 0) { u0 = p.x; v0 = p.y; ok0 = p.ok; }
+                    if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (A.extras & 16) && p.ok) {          // background mode 3: two samples, blended (:576-613)
+                        feather_store<T, N0, I, true>(p.x, p.y, feather_of(p.x, p.y, A), A.pl[0], bg_y, lim_y, MP.mul_lx, MP.mul_ly, MP, lx, ly, s_lut);
+                        continue;
+                    }
                     const float lu = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(p.x, MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(p.y, MP.mul_ly, MP.den_y, MP.rcp_y);   // cpu_undistort.rs:511-514
                     if (A.ablate & 2) { if (lane == 99) A.pl[0].dst[0] = (uint8_t)(lu + lv); continue; }  // timing ablation only
                     if (I == 2) sample_store2<T, N0>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly, AUDIT ? A.audit : nullptr);
                     else sample_store<T, N0, I>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly, s_lut);
                 }
+                if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (A.extras & 16) && ok0 && A.nplanes > 1) {  // background mode 3 for the chroma site
+                    const Feather f = feather_of(u0, v0, A);
+                    if (INTERLEAVED_UV) feather_store<T, 2, I, true>(u0, v0, f, A.pl[1], bg_c, lim_u, MP.mul_cx, MP.mul_cy, MP, cx, cy, s_lut);
+                    else for (int pi = 1; pi < A.nplanes; ++pi)
+                        feather_store<T, 1, I, true>(u0, v0, f, A.pl[pi], A.pl[pi].bg, A.pl[pi].limit, MP.mul_cx, MP.mul_cy, MP, cx, cy, s_lut);
+                } else
                 if (A.nplanes > 1 && !(A.ablate & 4)) {
                     const float cu = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(u0, MP.mul_cx, MP.den_x, MP.rcp_x), cv = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(v0, MP.mul_cy, MP.den_y, MP.rcp_y);
                     if (I == 2) {

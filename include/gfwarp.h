@@ -260,7 +260,9 @@ enum {
     GFW_OPT_KERNEL_VARIANT     = 3,  /* 0 auto; 1 generic per-plane kernel; 2 fused kernel with the exact first pass;
                                         3 fused kernel, certified first pass in audit mode (see gfw_get_audit);
                                         5 experimental gfw_hot_kernel (certified SECOND pass): bit-exact,
-                                        fewer instructions, measured slower than the default on MI355X; 6 = 5 in audit mode */
+                                        fewer instructions, measured slower than the default on MI355X; 6 = 5 in audit mode;
+                                        7 staging: settings whose fused path is written but not yet through the GPU parity suite
+                                        (background mode 3) run fused instead of per plane */
     GFW_OPT_PROFILE            = 4,  /* 1: bracket every warp-kernel launch with hipEvents on the context stream */
     GFW_OPT_TUNE_ROWS          = 5,  /* reserved (ignored) */
     GFW_OPT_TUNE_GRID          = 6   /* tuning: persistent workgroups of the fused kernel (0 = 6 per CU) */
