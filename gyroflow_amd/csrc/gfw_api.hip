@@ -613,7 +613,13 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
                            const GfwPlane *launches, const float *h_matrices, int matrix_count, size_t mesh_len,
                            GfwYuvArgs &Y, int &bytes_per_sample, int &n0, int &dw, int &dh, bool &interleaved, bool &fast1) {
     if (c->kernel_variant == 1) return false;                       // forced generic (tests / A-B benchmarking)
-    if (nplanes < 1 || nplanes > 4 || mesh_len != 0) return false;
+    if (nplanes < 1 || nplanes > 4) return false;
+#ifndef GFW_STAGED_FUSED
+#define GFW_STAGED_FUSED 0
+#endif
+    // staged fused paths (gfw_frame.hip: GFW_STAGED_FUSED): built only on request, taken only with GFW_OPT_KERNEL_VARIANT = 7
+    const bool staged = GFW_STAGED_FUSED && c->kernel_variant == 7;
+    if (mesh_len != 0 && !staged) return false;
     const gfw_kernel_params &p0 = params[0];
     const int t0 = pixel_types[0];
     // plane 0: sample kind (1 = u8, 2 = u16, 4 = f32) and channel count; RGBAf16 / UV-as-plane-0 stay on the generic kernel
@@ -636,6 +642,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
         else { for (int i = 1; i < nplanes; ++i) if (pixel_types[i] != t0) return false; }
     }
     int extras = 0;
+    if (mesh_len != 0) extras |= 32;
     if (c->digital != GFW_MODEL_NONE && (p0.flags & GFW_FLAG_HAS_DIGITAL_LENS)) extras |= 2;
     if (c->model < GFW_MODEL_OPENCV_FISHEYE || c->model > GFW_MODEL_GOPRO) return false;
     // plane-invariant parameters must really be invariant, and inside the fused kernel's feature set
@@ -644,7 +651,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
         if ((p.interpolation != 2 && p.interpolation != 4 && p.interpolation != 8) || p.interpolation != p0.interpolation) return false;
         // background mode 3 (margin with feather) runs fused only on request (GFW_OPT_KERNEL_VARIANT = 7) until that path has been
         // through the GPU parity suite; by default it takes the per-plane kernel like every setting the fused kernel does not serve
-        const int bg_max = (c->kernel_variant == 7) ? 3 : 2;
+        const int bg_max = staged ? 3 : 2;
         if (p.background_mode < 0 || p.background_mode > bg_max || p.background_mode != p0.background_mode || p.input_rotation != 0.0f) return false;
         if (p.background_mode == 3) {
             if (p.background_margin != p0.background_margin || p.background_margin_feather != p0.background_margin_feather) return false;
@@ -655,6 +662,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
         if (!(p.light_refraction_coefficient == p.light_refraction_coefficient) || p.light_refraction_coefficient != p0.light_refraction_coefficient) return false;
         if (p.light_refraction_coefficient != 1.0f && p.light_refraction_coefficient > 0.0f) extras |= 4;
         if ((p.flags ^ p0.flags) & GFW_FLAG_HAS_DIGITAL_LENS) return false;
+        if (mesh_len != 0 && ((p.flags ^ p0.flags) & 128)) return false;          // the mesh terms read flag 128 (vertically flipped frame buffer)
         if (memcmp(p.digital_lens_params, p0.digital_lens_params, sizeof(p.digital_lens_params))) return false;
         if (p.flags & (GFW_FLAG_FIX_COLOR_RANGE | GFW_FLAG_FILL_WITH_BACKGROUND)) return false;
         if (p.translation3d[0] != 0.0f || p.translation3d[1] != 0.0f || p.translation3d[2] != 0.0f) return false;
@@ -827,7 +835,7 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
                                       matrix_count, mesh_len, Y, bps, n0, dw, dh, interleaved, fast1);
     prof_begin(c);
     if (fused) {
-        fill_common(c, &params[0], d_mat, nullptr, 0, Y.common);
+        fill_common(c, &params[0], d_mat, (Y.extras & 32) ? d_mesh : nullptr, (Y.extras & 32) ? (int)mesh_len : 0, Y.common);
         Y.matrices = d_mat;
         HIP_TRY(gfw_launch_yuv(Y, bps, params[0].interpolation, n0, dw, dh, interleaved, fast1, c->stream), GFW_ERR_HIP);
         c->last_backend = Y.hot ? (fast1 ? "yuv_fused_p1_c2" : "yuv_fused_c2") : (fast1 ? "yuv_fused_p1" : "yuv_fused");

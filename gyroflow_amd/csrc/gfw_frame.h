@@ -37,7 +37,8 @@ struct GfwYuvArgs {
     int32_t extras;                   // features served by the generic-model instantiation only: 1 IBIS/OIS terms in the
                                       // matrix rows, 2 digital lens, 4 light refraction (cpu_undistort.rs:143-165, :216-220),
                                       // 8 lens-correction blend (lens_correction_amount < 1, :429-460),
-                                      // 16 background mode 3: margin with feather (:576-613)
+                                      // 16 background mode 3: margin with feather (:576-613),
+                                      // 32 Sony lens-distortion mesh / focal-plane distortion in `common.mesh` (:169-214)
     int32_t ablate;                   // benchmark-only ablation bits (0 in production): 1 no first pass, 2 no luma taps, 4 no chroma, 8 no projection
     float hstretch, vstretch;
     float f[2], c[2], k[12];

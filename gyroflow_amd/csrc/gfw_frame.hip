@@ -69,6 +69,11 @@
 #define GFW_XCD_CHUNK 0          // 0: each XCD walks one contiguous band of tiles; C > 0: chunks of C consecutive tiles are dealt round-robin to the
                                  // XCDs (the bands differ by 3 % in cost; measured +0..3 %, inside the run-to-run noise: not enabled)
 #endif
+#ifndef GFW_STAGED_FUSED
+#define GFW_STAGED_FUSED 0       // 1: build the fused paths that are written but not yet through the GPU parity suite (background mode 3, Sony
+                                 // mesh; tests/test_staged_fused_coverage.py, GFW_OPT_KERNEL_VARIANT = 7).  0: they do not exist in the binary —
+                                 // inside the generic-model instantiation they cost every other user of it registers and scratch
+#endif
 #ifndef GFW_GENERIC_WAVES_PER_EU
 #define GFW_GENERIC_WAVES_PER_EU 3   // register budget of the generic-model instantiations (see the kernel's attribute)
 #endif
@@ -226,6 +231,9 @@ __device__ __forceinline__ GfwPt rd(float px, float py, const float4 ma, const f
             }
         }
         u = u + L.c0; v = v + L.c1;
+#if GFW_STAGED_FUSED
+        if (A.extras & 32) gfw_mesh_apply(u, v, A.kp, A.common);                   // Sony mesh + focal-plane distortion (:169-214)
+#endif
         if (A.extras & 2) {
             float d0, d1;
             gfw_lens::distort<-1>(A.common.digital, u, v, 1.0f, A.kp, A.common, d0, d1);
@@ -676,6 +684,7 @@ __device__ __forceinline__ void sample_store_uv2(float u, float v, bool ok, cons
     store_px<T, 1>(PV.dst, doff, &ov);
 }
 
+#if GFW_STAGED_FUSED
 // ---- background mode 3 ("margin with feather", cpu_undistort.rs:576-613) ----------------------------------------------------
 // Near the frame border the pixel is c1 * alpha + c2 * (1 - alpha): c1 sampled at the projected point, c2 at the point pulled
 // towards the centre by background_margin, alpha the distance to the border in units of the feather.  uv lives in full-resolution
@@ -724,6 +733,8 @@ __device__ __forceinline__ void feather_store(float ux, float uy, const Feather 
     for (int c = 0; c < N; ++c) px[c] = c1[c] * f.alpha + c2[c] * (1.0f - f.alpha);
     store_px<T, N>(P.dst, oy * P.dst_stride + ox * (int)(N * sizeof(T)), px);
 }
+
+#endif   // GFW_STAGED_FUSED
 
 // ---- first pass (rolling-shutter row pick) -----------------------------------------------------------------
 // The mid-row projection of undistort_coord (cpu_undistort.rs:470-479) is used for ONE thing: the integer
@@ -1027,21 +1038,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
                         }
                     }
                     if (k == 0) { u0 = p.x; v0 = p.y; ok0 = p.ok; }
+#if GFW_STAGED_FUSED
                     if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (A.extras & 16) && p.ok) {          // background mode 3: two samples, blended (:576-613)
                         feather_store<T, N0, I, true>(p.x, p.y, feather_of(p.x, p.y, A), A.pl[0], bg_y, lim_y, MP.mul_lx, MP.mul_ly, MP, lx, ly, s_lut);
                         continue;
                     }
+#endif
                     const float lu = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(p.x, MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(p.y, MP.mul_ly, MP.den_y, MP.rcp_y);   // cpu_undistort.rs:511-514
                     if (A.ablate & 2) { if (lane == 99) A.pl[0].dst[0] = (uint8_t)(lu + lv); continue; }  // timing ablation only
                     if (I == 2) sample_store2<T, N0>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly, AUDIT ? A.audit : nullptr);
                     else sample_store<T, N0, I>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly, s_lut);
                 }
+#if GFW_STAGED_FUSED
                 if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (A.extras & 16) && ok0 && A.nplanes > 1) {  // background mode 3 for the chroma site
                     const Feather f = feather_of(u0, v0, A);
                     if (INTERLEAVED_UV) feather_store<T, 2, I, true>(u0, v0, f, A.pl[1], bg_c, lim_u, MP.mul_cx, MP.mul_cy, MP, cx, cy, s_lut);
                     else for (int pi = 1; pi < A.nplanes; ++pi)
                         feather_store<T, 1, I, true>(u0, v0, f, A.pl[pi], A.pl[pi].bg, A.pl[pi].limit, MP.mul_cx, MP.mul_cy, MP, cx, cy, s_lut);
                 } else
+#endif
                 if (A.nplanes > 1 && !(A.ablate & 4)) {
                     const float cu = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(u0, MP.mul_cx, MP.den_x, MP.rcp_x), cv = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(v0, MP.mul_cy, MP.den_y, MP.rcp_y);
                     if (I == 2) {

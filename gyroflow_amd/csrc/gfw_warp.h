@@ -497,6 +497,53 @@ __device__ inline double bivariate(int n_x, int n_y, double size_x, double size_
 }  // namespace gfw_mesh
 
 // ----------------------------------------------------------------------------
+#if defined(GFW_STAGED_FUSED) && GFW_STAGED_FUSED
+// Sony lens-distortion mesh + focal-plane-distortion terms of rotate_and_distort (cpu_undistort.rs:169-214) on the distorted
+// point (u, v), after `+ c` and before the digital lens, for the fused kernel's staged generic path — a copy of the block inside
+// gfw_rotate_and_distort below (the per-plane kernels keep their validated code byte for byte until the staged path is promoted).
+__device__ __forceinline__ void gfw_mesh_apply(float &u, float &v, const gfw_kernel_params &P, const GfwCommon &C) {
+    if (C.mesh_len > 0) {
+        const float *md32 = C.mesh;
+        const double md0 = (double)md32[0];
+        if (md0 > 10.0) {                                                              // :169-185
+            const double ms0 = (double)md32[3], ms1 = (double)md32[4];
+            const float or0 = (float)(double)md32[5], or1 = (float)(double)md32[6];
+            const float cs0 = (float)(double)md32[7], cs1 = (float)(double)md32[8];
+            if ((P.flags & 128) == 128) v = (float)P.height - v;
+            u = gfw_map_coord(u, 0.0f, (float)P.width,  or0, or0 + cs0);
+            v = gfw_map_coord(v, 0.0f, (float)P.height, or1, or1 + cs1);
+            const int nx = (int)gfw_mesh::d2us((double)md32[1]), ny = (int)gfw_mesh::d2us((double)md32[2]);
+            const double nxp = gfw_mesh::bivariate(nx, ny, ms0, ms1, md32, 0, (double)u, (double)v);
+            const double nyp = gfw_mesh::bivariate(nx, ny, ms0, ms1, md32, 1, (double)u, (double)v);
+            u = gfw_map_coord((float)nxp, or0, or0 + cs0, 0.0f, (float)P.width);
+            v = gfw_map_coord((float)nyp, or1, or1 + cs1, 0.0f, (float)P.height);
+            if ((P.flags & 128) == 128) v = (float)P.height - v;
+        }
+        if (md0 > 0.0 && (double)md32[gfw_mesh::d2us(md0)] > 0.0) {                   // :188-214
+            const int64_t o = gfw_mesh::d2us(md0);
+            const double ms1 = (double)md32[4];
+            const float or0 = (float)(double)md32[5], or1 = (float)(double)md32[6];
+            const float cs0 = (float)(double)md32[7], cs1 = (float)(double)md32[8];
+            const double grid = ms1 / 8.0;
+            if ((P.flags & 128) == 128) v = (float)P.height - v;
+            u = gfw_map_coord(u, 0.0f, (float)P.width,  or0, or0 + cs0);
+            v = gfw_map_coord(v, 0.0f, (float)P.height, or1, or1 + cs1);
+            const int64_t idx2 = gfw_mesh::d2us(fmin(fmax(floor((double)v / grid), 0.0), 7.0));
+            const double delta = (double)v - grid * (double)idx2;
+            u -= (float)((double)md32[o + 4 + idx2 * 2 + 0] * delta);
+            v -= (float)((double)md32[o + 4 + idx2 * 2 + 1] * delta);
+            for (int64_t j = 0; j < idx2; ++j) {
+                u -= (float)((double)md32[o + 4 + j * 2 + 0] * grid);
+                v -= (float)((double)md32[o + 4 + j * 2 + 1] * grid);
+            }
+            u = gfw_map_coord(u, or0, or0 + cs0, 0.0f, (float)P.width);
+            v = gfw_map_coord(v, or1, or1 + cs1, 0.0f, (float)P.height);
+            if ((P.flags & 128) == 128) v = (float)P.height - v;
+        }
+    }
+}
+#endif
+
 // rotate_and_distort: cpu_undistort.rs:133-228
 template <int MODEL>
 __device__ __forceinline__ GfwPt gfw_rotate_and_distort(float px, float py, int idx, const gfw_kernel_params &P, const GfwCommon &C, float r_limit_sq) {

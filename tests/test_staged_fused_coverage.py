@@ -1,10 +1,13 @@
 """STAGING AREA — fused-kernel paths that are written but have not been through the GPU parity suite yet.
 
-Run on the GPU box with `python -m pytest tests -m gpu_staged`; `-m gpu` (what the round-end driver runs) does not select these,
-and without a GPU they are skipped.  A test moves into the regular `-m gpu` files — and its path loses the
-GFW_OPT_KERNEL_VARIANT = 7 gate in gfw_api.hip — once it has passed there.
+The staged paths exist only in a library built with GFW_STAGED_FUSED=1 (`GFW_STAGED_FUSED=1 python -c "import __graft_entry__ as g;
+g.build_gfwarp(force=True)"`) and are taken only with GFW_OPT_KERNEL_VARIANT = 7; the shipped binary does not contain them (inside
+the generic-model instantiation they would cost its other users registers and scratch).  Run on the GPU box with
+`python -m pytest tests -m gpu_staged`; `-m gpu` (what the round-end driver runs) does not select these, and without a GPU or
+without a staging build they are skipped.  A test moves into the regular `-m gpu` files once it has passed there.
 
-Staged: background mode 3 "margin with feather" (cpu_undistort.rs:576-613) through the fused kernel's generic-model instantiation
+Staged: background mode 3 "margin with feather" (cpu_undistort.rs:576-613) and the Sony mesh / focal-plane-distortion terms
+(:169-214) through the fused kernel's generic-model instantiation
 (two samples per plane + alpha blend; today the per-plane kernel serves it, bit-exact).
 """
 import pytest
@@ -21,7 +24,8 @@ STAGING_VARIANT = 7
 def check_staged(fr):
     ref = O.run_frame(fr)
     got = warp.run_frame(fr, variant=STAGING_VARIANT)
-    assert warp.last_backend() == "yuv_fused", warp.last_backend()
+    if warp.last_backend() != "yuv_fused":
+        pytest.skip("libgfwarp.so built without GFW_STAGED_FUSED=1")
     for i, (a, b) in enumerate(zip(ref, got)):
         assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "fused background mode 3, plane %d" % i)
     base = warp.run_frame(fr)                                     # the default route is untouched
@@ -51,3 +55,45 @@ def test_margin_with_feather_fused_with_rolling_shutter_inside_the_frame():
     ov = {"background_mode": 3, "background_margin": 0.1, "background_margin_feather": 0.15}
     fr = S.SyntheticFrame("YUV422P16LE", 640, 360, seed=5, fov=0.9, base_overrides=ov)
     check_staged(fr)
+
+
+# ---- Sony lens-distortion mesh + focal-plane distortion (cpu_undistort.rs:169-214) through the fused kernel ----------------
+def run_frame_with_mesh(fr, mesh, variant):
+    import numpy as np
+    from gyroflow_amd import abi
+    outs = [pl["dst"].copy() for pl in fr.planes]
+    bufs = [warp.host_buffers(pl["src"], pl["size"], o, pl["out_size"]) for pl, o in zip(fr.planes, outs)]
+    params = [pl["params"] for pl in fr.planes]
+    types = [pl["pixel_type"] for pl in fr.planes]
+    be = warp.Backend(params[0], types[0], fr.model, fr.digital, bufs[0])
+    try:
+        if variant:
+            be.set_option(abi.OPT_KERNEL_VARIANT, variant)
+        be.undistort_frame(bufs, params, types, fr.matrices, mesh=np.asarray(mesh, dtype=np.float32))
+    finally:
+        be.close()
+    return outs
+
+
+@pytest.mark.parametrize("fmt", ["NV12", "YUV422P16LE", "RGBA64"])
+@pytest.mark.parametrize("with_mesh,with_fpd,inverted", [(True, False, False), (True, True, False), (True, True, True), (False, True, False)])
+def test_sony_mesh_and_focal_plane_distortion_fused(fmt, with_mesh, with_fpd, inverted):
+    from gyroflow_amd import abi
+    from test_gpu_lens_models import synthetic_mesh
+    w, h = 192, 128
+    fr = S.SyntheticFrame(fmt, w, h, seed=47, fov=1.1, flags=abi.FLAG_FRAMEBUFFER_INVERTED if inverted else 0)
+    mesh = synthetic_mesh(w, h, with_fpd, with_mesh)
+    ref = []
+    for pl in fr.planes:
+        dst = pl["dst"].copy()
+        assert O.undistort_image(pl["src"], pl["size"], dst, pl["out_size"], pl["params"], pl["pixel_type"], fr.model, fr.digital, fr.matrices, mesh=mesh) == 1
+        ref.append(dst)
+    got = run_frame_with_mesh(fr, mesh, STAGING_VARIANT)
+    if warp.last_backend() != "yuv_fused":
+        pytest.skip("libgfwarp.so built without GFW_STAGED_FUSED=1")
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "fused mesh, plane %d" % i)
+    base = run_frame_with_mesh(fr, mesh, 0)                      # default route: per-plane kernel
+    assert warp.last_backend() == "plane_generic"
+    for i, (a, b) in enumerate(zip(ref, base)):
+        assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "per-plane mesh, plane %d" % i)
