@@ -17,3 +17,10 @@ fi
 bash tools/gpu_ab.sh r03a base "base:--streams 2" "base:--streams 4" prio0 "prio0:--streams 2" atan_tab "atan_tab:--streams 2" ck30 atan_ck30 tl tl_atan base \
     "gen3:--digital gopro_superview --steps 60" "gen4:--digital gopro_superview --steps 60" \
     "gen6:--digital gopro_superview --steps 60" "gen2:--digital gopro_superview --steps 60"
+
+# ---- staged fused paths (background mode 3, Sony mesh): validate, then promote --------------------------------------------------
+# On the CPU box:   GFW_STAGED_FUSED=1 python -c "import __graft_entry__ as g; g.build_gfwarp(force=True)"
+# GPU:              gpurun --timeout 300 -- 'python -m pytest tests -m gpu_staged -q'
+# Afterwards rebuild the shipped library:   python -c "import __graft_entry__ as g; g.build_gfwarp(force=True)"
+# Promotion = drop the GFW_STAGED_FUSED gates, give the two extras their own instantiation (they cost the generic one ~700 B of
+# scratch: tools/kernel_resources.py), move the tests to -m gpu.
