@@ -110,6 +110,17 @@ __device__
 #ifndef GFW_PIN_UNIFORMS
 #define GFW_PIN_UNIFORMS 0
 #endif
+#ifndef GFW_PIN_LENS
+#define GFW_PIN_LENS 0            // only the eight lens constants of the exact projection (f, c, k0..k3) pinned in VGPRs: the compiler otherwise
+                                  // re-reads them from the kernel-argument segment inside the pixel loop (s_load_dwordx8 + wait, twice per pixel)
+#endif
+__device__ __forceinline__ float vu_lens(float s) {
+#if GFW_PIN_LENS
+    float v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v;
+#else
+    return s;
+#endif
+}
 __device__ __forceinline__ float vu(float s) {
 #if GFW_PIN_UNIFORMS
     float v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v;
@@ -857,8 +868,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
 
     // uniform floats of the pixel loops, pinned in VGPRs once per wave
     Lens L;
-    L.f0 = vu(A.f[0]); L.f1 = vu(A.f[1]); L.c0 = vu(A.c[0]); L.c1 = vu(A.c[1]);
-    L.k0 = vu(A.k[0]); L.k1 = vu(A.k[1]); L.k2 = vu(A.k[2]); L.k3 = vu(A.k[3]);
+    L.f0 = vu_lens(vu(A.f[0])); L.f1 = vu_lens(vu(A.f[1])); L.c0 = vu_lens(vu(A.c[0])); L.c1 = vu_lens(vu(A.c[1]));
+    L.k0 = vu_lens(vu(A.k[0])); L.k1 = vu_lens(vu(A.k[1])); L.k2 = vu_lens(vu(A.k[2])); L.k3 = vu_lens(vu(A.k[3]));
     L.t2x = vu(A.t2[0]); L.t2y = vu(A.t2[1]); L.rl2 = vu(A.r_limit_sq);
     Maps MP;
     MP.mul_lx = vu(A.map_lx.mul); MP.mul_ly = vu(A.map_ly.mul); MP.mul_cx = vu(A.map_cx.mul); MP.mul_cy = vu(A.map_cy.mul);
