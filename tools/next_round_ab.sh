@@ -14,7 +14,7 @@ if [ "$1" = build ]; then
       "gen6:-DGFW_GENERIC_WAVES_PER_EU=6" "gen2:-DGFW_GENERIC_WAVES_PER_EU=2"
   exit 0
 fi
-bash tools/gpu_ab.sh r03a base "base:--streams 2" "base:--streams 4" prio0 "prio0:--streams 2" atan_tab "atan_tab:--streams 2" pin atan_pin ck30 atan_ck30 tl tl_atan base \
+bash tools/gpu_ab.sh r03a base "base:--streams 2" "base:--streams 4" prio0 "prio0:--streams 2" atan_tab "atan_tab:--streams 2" pin atan_pin ck30 atan_ck30 tl "tl:--streams 2" tl_atan base \
     "gen3:--digital gopro_superview --steps 60" "gen4:--digital gopro_superview --steps 60" \
     "gen6:--digital gopro_superview --steps 60" "gen2:--digital gopro_superview --steps 60"
 
