@@ -281,6 +281,7 @@ int gfw_set_stream(gfw_ctx *c, void *s) {
     if (!c) return GFW_ERR_INVALID_ARGUMENT;
     // the previous stream is drained first: frames still in flight on it use this context's staging buffers and matrix slots,
     // and nothing orders the new stream behind them
+    HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
     (void)hipStreamSynchronize(c->stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)s; c->own_stream = false;
