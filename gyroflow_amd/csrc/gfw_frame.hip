@@ -91,6 +91,10 @@
 #ifndef GFW_PRIO_DIV
 #define GFW_PRIO_DIV 3
 #endif
+#ifndef GFW_PRIO_AGE_ROWS
+#define GFW_PRIO_AGE_ROWS 0      // A/B: lane-rows of head start the LAST workgroup dispatched to a CU gets in the priority formula (earlier ones
+                                 // proportionally less): counters the arbiter's oldest-first rule directly.  0 = off
+#endif
 #ifndef GFW_TIMELINE
 #define GFW_TIMELINE 0           // diagnosis builds only: per-wave start / end / phase clocks and HW_ID into a device array that the 60th launch
                                  // dumps to $GFW_TIMELINE_FILE (tools/analyze_timeline.py)
@@ -912,6 +916,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
         if (p <= 0) __builtin_amdgcn_s_setprio(0); else if (p == 1) __builtin_amdgcn_s_setprio(1);
         else if (p == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
     };
+    const int prio_age = (((int)blockIdx.x >> 3) * GFW_PRIO_AGE_ROWS) / (wg_per_xcd > 0 ? wg_per_xcd : 1);
     int tiles_left = 0;
     for (int tb = (int)blockIdx.x >> 3; tb < per_xcd && GFW_XCD_TILE(tb) < n_tiles; tb += wg_per_xcd) ++tiles_left;
 #endif
@@ -921,7 +926,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
 #if GFW_PRIO_MODE == 2
         set_prio(tiles_left < 3 ? tiles_left : 3);
 #elif GFW_PRIO_MODE == 1
-        set_prio((tiles_left * RB) / GFW_PRIO_DIV);
+        set_prio((tiles_left * RB + prio_age) / GFW_PRIO_DIV);
 #endif
         const int ty = t / A.tiles_x, tx = t - ty * A.tiles_x;
         const int cx = tx * 64 + lane;
@@ -1014,7 +1019,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
             #pragma unroll 1
             for (int r = 0; r < RB; ++r) {
 #if GFW_PRIO_MODE == 1
-                set_prio(((tiles_left * RB) - r) / GFW_PRIO_DIV);
+                set_prio(((tiles_left * RB) - r + prio_age) / GFW_PRIO_DIV);
 #endif
                 const int cy = cy0 + r;
                 if (cy >= A.ch) break;
