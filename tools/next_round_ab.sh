@@ -24,3 +24,5 @@ bash tools/gpu_ab.sh r03a base "base:--streams 2" "base:--streams 4" prio0 "prio
 # Afterwards rebuild the shipped library:   python -c "import __graft_entry__ as g; g.build_gfwarp(force=True)"
 # Promotion = drop the GFW_STAGED_FUSED gates, give the two extras their own instantiation (they cost the generic one ~700 B of
 # scratch: tools/kernel_resources.py), move the tests to -m gpu.
+# Reference-OpenCL second opinion for the other eight lens models: `python -m pytest tests/test_staged_ref_opencl_models.py -m gpu_staged -s`
+# prints the agreement per model; put the measured numbers into the assertions and move the file to -m gpu.
