@@ -69,6 +69,11 @@
 #define GFW_XCD_CHUNK 0          // 0: each XCD walks one contiguous band of tiles; C > 0: chunks of C consecutive tiles are dealt round-robin to the
                                  // XCDs (the bands differ by 3 % in cost; measured +0..3 %, inside the run-to-run noise: not enabled)
 #endif
+#ifndef GFW_LUT_TILE
+#define GFW_LUT_TILE 0           // bicubic / Lanczos4 taps of planar 8/16-bit frames from a per-wave LDS tile of the source (tile_sample_store):
+                                 // one coalesced fetch of the wave's bounding box per output row and plane instead of I row fetches per sample.
+                                 // Written, compiles, not yet run on the device: off in the shipped binary
+#endif
 #ifndef GFW_STAGED_FUSED
 #define GFW_STAGED_FUSED 0       // 1: build the fused paths that are written but not yet through the GPU parity suite (background mode 3, Sony
                                  // mesh; tests/test_staged_fused_coverage.py, GFW_OPT_KERNEL_VARIANT = 7).  0: they do not exist in the binary —
@@ -751,6 +756,89 @@ __device__ __forceinline__ void feather_store(float ux, float uy, const Feather 
 
 #endif   // GFW_STAGED_FUSED
 
+#if GFW_LUT_TILE
+// ---- LUT taps from an LDS tile (bicubic / Lanczos4, single-channel 8/16-bit planes) -------------------------------------------
+// The I x I windows of a wave's samples of one output row overlap almost entirely (neighbouring lanes are ~1 source pixel apart),
+// yet taps_inside fetches I rows per sample, one waited-for row at a time.  Here the wave copies the bounding box of its windows —
+// GFW_TILE_H rows of GFW_TILE_W source pixels starting at the wave-wide minimum (sx, sy) — into LDS with one 8-byte fetch per lane
+// and row, all in flight together, and every sample whose window lies inside that box takes its taps from LDS in the reference's
+// order (cpu_undistort.rs:391-411: xs = xs + p*cx over a row, sum = sum + xs*cy over the rows).  Samples that do not fit (steep
+// rotation, zoom-out beyond 160/128, frame edges) go through sample_store as before.  Needs every lane of the wave active (the
+// copy is cooperative), the plane 4-byte aligned with a 4-byte multiple pitch.
+constexpr int GFW_TILE_W = 160, GFW_TILE_H = 12;
+template <typename T, int I, int NS>
+__device__ __forceinline__ void tile_sample_store(const GfwYuvPlane &P, const float *u, const float *v, const bool *ok, const bool *need,
+                                                  const int *ox, const int *oy, const float *bg, float limit,
+                                                  uint2 *tile, int *org, const float *lut, int lane) {
+    constexpr int TWB = GFW_TILE_W * (int)sizeof(T);           // bytes per tile row
+    constexpr int CH = TWB / 8;                                // 8-byte chunks per row = lanes that copy
+    static_assert(TWB % 8 == 0 && CH <= 64, "tile row must be whole 8-byte chunks, one per lane");
+    Bins<I> b[NS];
+    bool inside[NS];
+    #pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        inside[q] = false;
+        b[q].sx = 0; b[q].sy = 0; b[q].tx = lut; b[q].ty = lut;
+        if (need[q] && ok[q]) { b[q] = make_bins<I>(u[q], v[q], lut); inside[q] = bins_inside<T, 1, I>(b[q], P.w, P.h); }
+    }
+    const bool all_lanes = __builtin_amdgcn_read_exec() == ~0ull;
+    const bool aligned = ((P.src_stride & 3) == 0) && (((uintptr_t)P.src & 3u) == 0);
+    bool have = false;
+    int x0 = 0, y0 = 0, valid_w = 0;
+    if (all_lanes && aligned) {
+        if (lane == 0) { org[0] = 0x7fffffff; org[1] = 0x7fffffff; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        #pragma unroll
+        for (int q = 0; q < NS; ++q) if (inside[q]) { atomicMin(&org[0], b[q].sx); atomicMin(&org[1], b[q].sy); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int mx = __builtin_amdgcn_readfirstlane(org[0]);
+        y0 = __builtin_amdgcn_readfirstlane(org[1]);
+        if (mx != 0x7fffffff) {
+            have = true;
+            x0 = mx & ~(int)(4 / (int)sizeof(T) - 1);                      // the box starts on a 4-byte boundary of the row
+            const int row_bytes = P.w * (int)sizeof(T), x0b = x0 * (int)sizeof(T);
+            const int chunks = min(CH, (row_bytes - x0b) / 8);             // whole chunks that lie inside the row
+            valid_w = chunks * (8 / (int)sizeof(T));
+            const int xb = x0b + 8 * lane;
+            #pragma unroll 1
+            for (int r = 0; r < GFW_TILE_H; ++r) {
+                const int y = y0 + r;
+                if (y >= P.h) break;                                       // rows past the plane are never part of an inside window
+                if (lane < chunks) {
+                    const uint2 d = *reinterpret_cast<const uint2 *>(P.src + (int64_t)y * P.src_stride + xb);
+                    tile[r * CH + lane] = d;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+    #pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        if (!need[q]) continue;
+        const bool fit = have && inside[q] && (b[q].sx - x0 + I <= valid_w) && (b[q].sy - y0 + I <= GFW_TILE_H);
+        if (fit) {
+            const T *t0 = reinterpret_cast<const T *>(tile) + (b[q].sy - y0) * GFW_TILE_W + (b[q].sx - x0);
+            float cx[I];
+            #pragma unroll
+            for (int i = 0; i < I; ++i) cx[i] = b[q].tx[i];
+            float s1 = 0.0f;
+            #pragma unroll
+            for (int yp = 0; yp < I; ++yp) {
+                float xs = 0.0f;
+                #pragma unroll
+                for (int xp = 0; xp < I; ++xp) xs = xs + (float)t0[yp * GFW_TILE_W + xp] * cx[xp];
+                s1 = s1 + xs * b[q].ty[yp];
+            }
+            const float o = fminf(s1, limit);
+            store_px<T, 1>(P.dst, oy[q] * P.dst_stride + ox[q] * (int)sizeof(T), &o);
+        } else {
+            sample_store<T, 1, I>(u[q], v[q], ok[q], P, bg, limit, ox[q], oy[q], lut);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");              // the next call overwrites the tile
+}
+#endif   // GFW_LUT_TILE
+
 // ---- first pass (rolling-shutter row pick) -----------------------------------------------------------------
 // The mid-row projection of undistort_coord (cpu_undistort.rs:470-479) is used for ONE thing: the integer
 // sy = clamp(round(p.y)).  FAST1 evaluates p.y with fused arithmetic and a per-lens table of
@@ -859,6 +947,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
     __shared__ unsigned q_n[4];
     __shared__ int s_rows[RB * NPX][256];                                        // phase-1 rows, one column per lane
     __shared__ float s_lut[I == 2 ? 1 : 448];                                    // bicubic / Lanczos4 tap table
+#if GFW_LUT_TILE
+    constexpr bool TILE = MODEL == GFW_MODEL_OPENCV_FISHEYE && I != 2 && !is_f32<T>::value && N0 == 1 && !INTERLEAVED_UV && NPX <= 2;
+    __shared__ uint2 s_tile[TILE ? 4 : 1][TILE ? (GFW_TILE_H * GFW_TILE_W * (int)sizeof(T)) / 8 : 1];
+    __shared__ int s_org[4][2];
+#endif
     const int wave = threadIdx.y, lane = threadIdx.x, tid = wave * 64 + lane;
 #if GFW_ATAN_TABLE
     if (MODEL == GFW_MODEL_OPENCV_FISHEYE) gfw_atan_lds_init(tid);
@@ -1024,6 +1117,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
                 const int cy = cy0 + r;
                 if (cy >= A.ch) break;
                 float u0 = 0.0f, v0 = 0.0f; bool ok0 = false;
+#if GFW_LUT_TILE
+                float tl_u[NPX], tl_v[NPX]; bool tl_ok[NPX], tl_need[NPX]; int tl_x[NPX], tl_y[NPX];
+                #pragma unroll
+                for (int k = 0; k < NPX; ++k) { tl_u[k] = 0.0f; tl_v[k] = 0.0f; tl_ok[k] = false; tl_need[k] = false; tl_x[k] = 0; tl_y[k] = 0; }
+#endif
                 #pragma unroll (NPX <= 2 ? NPX : 1)
                 for (int k = 0; k < NPX; ++k) {
                     const int i = k % DW, j = k / DW;
@@ -1063,8 +1161,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
                     const float lu = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(p.x, MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(p.y, MP.mul_ly, MP.den_y, MP.rcp_y);   // cpu_undistort.rs:511-514
                     if (A.ablate & 2) { if (lane == 99) A.pl[0].dst[0] = (uint8_t)(lu + lv); continue; }  // timing ablation only
                     if (I == 2) sample_store2<T, N0>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly, AUDIT ? A.audit : nullptr);
+#if GFW_LUT_TILE
+                    else if constexpr (TILE) { if (k < NPX) { tl_u[k] = lu; tl_v[k] = lv; tl_ok[k] = p.ok; tl_need[k] = true; tl_x[k] = lx; tl_y[k] = ly; } }
+#endif
                     else sample_store<T, N0, I>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly, s_lut);
                 }
+#if GFW_LUT_TILE
+                if constexpr (TILE) {
+                    if (!(A.ablate & 2)) tile_sample_store<T, I, NPX>(A.pl[0], tl_u, tl_v, tl_ok, tl_need, tl_x, tl_y, bg_y, lim_y, s_tile[wave], s_org[wave], s_lut, lane);
+                    if (A.nplanes == 3 && !(A.ablate & 4)) {               // planar U and V: same bins, one tile each
+                        const float cu = map_c<false>(u0, MP.mul_cx, MP.den_x, MP.rcp_x), cv = map_c<false>(v0, MP.mul_cy, MP.den_y, MP.rcp_y);
+                        const bool need1 = true;
+                        tile_sample_store<T, I, 1>(A.pl[1], &cu, &cv, &ok0, &need1, &cx, &cy, bg_c, lim_u, s_tile[wave], s_org[wave], s_lut, lane);
+                        tile_sample_store<T, I, 1>(A.pl[2], &cu, &cv, &ok0, &need1, &cx, &cy, &bg_v, lim_v, s_tile[wave], s_org[wave], s_lut, lane);
+                        continue;
+                    }
+                }
+#endif
 #if GFW_STAGED_FUSED
                 if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (A.extras & 16) && ok0 && A.nplanes > 1) {  // background mode 3 for the chroma site
                     const Feather f = feather_of(u0, v0, A);

@@ -26,3 +26,8 @@ bash tools/gpu_ab.sh r03a base "base:--streams 2" "base:--streams 4" prio0 "prio
 # scratch: tools/kernel_resources.py), move the tests to -m gpu.
 # Reference-OpenCL second opinion for the other eight lens models: `python -m pytest tests/test_staged_ref_opencl_models.py -m gpu_staged -s`
 # prints the agreement per model; put the measured numbers into the assertions and move the file to -m gpu.
+# Lanczos4 through the LDS tile (GFW_LUT_TILE, written / compiled / never run): first parity, then time.  The tile kernel holds
+# 35.6 KB of LDS and 100 VGPRs: four workgroups per CU, so give it --grid 1024 as well.
+#   CPU box:  GFW_VARIANT_TAPS=8 bash tools/build_variants.sh "l8_base:" "l8_tile:-DGFW_LUT_TILE=1"
+#   GPU:      bash tools/gpu_ab.sh r03l "l8_base:--interp 8 --steps 60" "l8_tile:--interp 8 --steps 60" "l8_tile:--interp 8 --steps 60 --grid 1024"
+#   (bench.py checks the last frames of the timed region against the oracle: parity_vs_oracle must read bit-exact)
