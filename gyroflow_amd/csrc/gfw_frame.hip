@@ -837,6 +837,68 @@ __device__ __forceinline__ void tile_sample_store(const GfwYuvPlane &P, const fl
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");              // the next call overwrites the tile
 }
+// The same for bilinear taps (the north-star's "source tile in LDS" for the hot configuration): 8 rows of the wave's bounding box.
+// Staged to be measured, not expected to win — the bilinear kernel is bound by instruction issue, not by its eight gathers per
+// lane-row, and the copy adds ~25 instructions per plane and row.
+constexpr int GFW_TILE2_H = 8;
+template <typename T, int NS>
+__device__ __forceinline__ void tile_sample_store2(const GfwYuvPlane &P, const float *u, const float *v, const bool *ok, const bool *need,
+                                                   const int *ox, const int *oy, const float *bg, float limit,
+                                                   uint2 *tile, int *org, int lane) {
+    constexpr int TWB = GFW_TILE_W * (int)sizeof(T), CH = TWB / 8;
+    Bins2 b[NS];
+    bool inside[NS];
+    #pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        inside[q] = false;
+        b[q] = Bins2{0, 0, 0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u};
+        if (need[q] && ok[q]) { b[q] = make_bins2(u[q], v[q]); inside[q] = (unsigned)b[q].sx < (unsigned)(P.w - 1) && (unsigned)b[q].sy < (unsigned)(P.h - 1); }
+    }
+    const bool all_lanes = __builtin_amdgcn_read_exec() == ~0ull;
+    const bool aligned = ((P.src_stride & 3) == 0) && (((uintptr_t)P.src & 3u) == 0);
+    bool have = false;
+    int x0 = 0, y0 = 0, valid_w = 0;
+    if (all_lanes && aligned) {
+        if (lane == 0) { org[0] = 0x7fffffff; org[1] = 0x7fffffff; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        #pragma unroll
+        for (int q = 0; q < NS; ++q) if (inside[q]) { atomicMin(&org[0], b[q].sx); atomicMin(&org[1], b[q].sy); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int mx = __builtin_amdgcn_readfirstlane(org[0]);
+        y0 = __builtin_amdgcn_readfirstlane(org[1]);
+        if (mx != 0x7fffffff) {
+            have = true;
+            x0 = mx & ~(int)(4 / (int)sizeof(T) - 1);
+            const int row_bytes = P.w * (int)sizeof(T), x0b = x0 * (int)sizeof(T);
+            const int chunks = min(CH, (row_bytes - x0b) / 8);
+            valid_w = chunks * (8 / (int)sizeof(T));
+            const int xb = x0b + 8 * lane;
+            #pragma unroll 1
+            for (int r = 0; r < GFW_TILE2_H; ++r) {
+                const int y = y0 + r;
+                if (y >= P.h) break;
+                if (lane < chunks) tile[r * CH + lane] = *reinterpret_cast<const uint2 *>(P.src + (int64_t)y * P.src_stride + xb);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+    #pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        if (!need[q]) continue;
+        const bool fit = have && inside[q] && (b[q].sx - x0 + 2 <= valid_w) && (b[q].sy - y0 + 2 <= GFW_TILE2_H);
+        if (fit) {
+            const T *t0 = reinterpret_cast<const T *>(tile) + (b[q].sy - y0) * GFW_TILE_W + (b[q].sx - x0);
+            // taps_inside2, integer pixels: the leading zero-adds of the reference are exact identities (every tap >= +0)
+            const float xs0 = (float)t0[0] * b[q].cx0 + (float)t0[1] * b[q].cx1;
+            const float xs1 = (float)t0[GFW_TILE_W] * b[q].cx0 + (float)t0[GFW_TILE_W + 1] * b[q].cx1;
+            const float o = fminf(xs0 * b[q].cy0 + xs1 * b[q].cy1, limit);
+            store_px<T, 1>(P.dst, oy[q] * P.dst_stride + ox[q] * (int)sizeof(T), &o);
+        } else {
+            sample_store2<T, 1>(u[q], v[q], ok[q], P, bg, limit, ox[q], oy[q], nullptr);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
 #endif   // GFW_LUT_TILE
 
 // ---- first pass (rolling-shutter row pick) -----------------------------------------------------------------
@@ -948,8 +1010,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
     __shared__ int s_rows[RB * NPX][256];                                        // phase-1 rows, one column per lane
     __shared__ float s_lut[I == 2 ? 1 : 448];                                    // bicubic / Lanczos4 tap table
 #if GFW_LUT_TILE
-    constexpr bool TILE = MODEL == GFW_MODEL_OPENCV_FISHEYE && I != 2 && !is_f32<T>::value && N0 == 1 && !INTERLEAVED_UV && NPX <= 2;
-    __shared__ uint2 s_tile[TILE ? 4 : 1][TILE ? (GFW_TILE_H * GFW_TILE_W * (int)sizeof(T)) / 8 : 1];
+    // GFW_LUT_TILE = 1: bicubic / Lanczos4 only; 2: bilinear as well (the A/B the north-star asks for)
+    constexpr bool TILE = MODEL == GFW_MODEL_OPENCV_FISHEYE && (I != 2 || GFW_LUT_TILE == 2) && !AUDIT && !is_f32<T>::value && N0 == 1 && !INTERLEAVED_UV && NPX <= 2;
+    __shared__ uint2 s_tile[TILE ? 4 : 1][TILE ? ((I == 2 ? GFW_TILE2_H : GFW_TILE_H) * GFW_TILE_W * (int)sizeof(T)) / 8 : 1];
     __shared__ int s_org[4][2];
 #endif
     const int wave = threadIdx.y, lane = threadIdx.x, tid = wave * 64 + lane;
@@ -1160,20 +1223,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
 #endif
                     const float lu = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(p.x, MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(p.y, MP.mul_ly, MP.den_y, MP.rcp_y);   // cpu_undistort.rs:511-514
                     if (A.ablate & 2) { if (lane == 99) A.pl[0].dst[0] = (uint8_t)(lu + lv); continue; }  // timing ablation only
-                    if (I == 2) sample_store2<T, N0>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly, AUDIT ? A.audit : nullptr);
 #if GFW_LUT_TILE
-                    else if constexpr (TILE) { if (k < NPX) { tl_u[k] = lu; tl_v[k] = lv; tl_ok[k] = p.ok; tl_need[k] = true; tl_x[k] = lx; tl_y[k] = ly; } }
+                    if constexpr (TILE) { tl_u[k] = lu; tl_v[k] = lv; tl_ok[k] = p.ok; tl_need[k] = true; tl_x[k] = lx; tl_y[k] = ly; }
+                    else
 #endif
+                    if (I == 2) sample_store2<T, N0>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly, AUDIT ? A.audit : nullptr);
                     else sample_store<T, N0, I>(lu, lv, p.ok, A.pl[0], bg_y, lim_y, lx, ly, s_lut);
                 }
 #if GFW_LUT_TILE
                 if constexpr (TILE) {
-                    if (!(A.ablate & 2)) tile_sample_store<T, I, NPX>(A.pl[0], tl_u, tl_v, tl_ok, tl_need, tl_x, tl_y, bg_y, lim_y, s_tile[wave], s_org[wave], s_lut, lane);
+                    if (!(A.ablate & 2)) {
+                        if constexpr (I == 2) tile_sample_store2<T, NPX>(A.pl[0], tl_u, tl_v, tl_ok, tl_need, tl_x, tl_y, bg_y, lim_y, s_tile[wave], s_org[wave], lane);
+                        else tile_sample_store<T, I, NPX>(A.pl[0], tl_u, tl_v, tl_ok, tl_need, tl_x, tl_y, bg_y, lim_y, s_tile[wave], s_org[wave], s_lut, lane);
+                    }
                     if (A.nplanes == 3 && !(A.ablate & 4)) {               // planar U and V: same bins, one tile each
                         const float cu = map_c<false>(u0, MP.mul_cx, MP.den_x, MP.rcp_x), cv = map_c<false>(v0, MP.mul_cy, MP.den_y, MP.rcp_y);
                         const bool need1 = true;
-                        tile_sample_store<T, I, 1>(A.pl[1], &cu, &cv, &ok0, &need1, &cx, &cy, bg_c, lim_u, s_tile[wave], s_org[wave], s_lut, lane);
-                        tile_sample_store<T, I, 1>(A.pl[2], &cu, &cv, &ok0, &need1, &cx, &cy, &bg_v, lim_v, s_tile[wave], s_org[wave], s_lut, lane);
+                        if constexpr (I == 2) {
+                            tile_sample_store2<T, 1>(A.pl[1], &cu, &cv, &ok0, &need1, &cx, &cy, bg_c, lim_u, s_tile[wave], s_org[wave], lane);
+                            tile_sample_store2<T, 1>(A.pl[2], &cu, &cv, &ok0, &need1, &cx, &cy, &bg_v, lim_v, s_tile[wave], s_org[wave], lane);
+                        } else {
+                            tile_sample_store<T, I, 1>(A.pl[1], &cu, &cv, &ok0, &need1, &cx, &cy, bg_c, lim_u, s_tile[wave], s_org[wave], s_lut, lane);
+                            tile_sample_store<T, I, 1>(A.pl[2], &cu, &cv, &ok0, &need1, &cx, &cy, &bg_v, lim_v, s_tile[wave], s_org[wave], s_lut, lane);
+                        }
                         continue;
                     }
                 }
