@@ -69,6 +69,10 @@
 #define GFW_XCD_CHUNK 0          // 0: each XCD walks one contiguous band of tiles; C > 0: chunks of C consecutive tiles are dealt round-robin to the
                                  // XCDs (the bands differ by 3 % in cost; measured +0..3 %, inside the run-to-run noise: not enabled)
 #endif
+#ifndef GFW_LDS_MATRICES
+#define GFW_LDS_MATRICES 0       // second pass reads its matrix rows from a per-wave LDS window (32 rows from the tile's smallest row index) instead
+                                 // of L1/L2 — the north-star's "per-row matrices staged in LDS".  Certified-first-pass kernels only.  Staged for A/B
+#endif
 #ifndef GFW_LUT_TILE
 #define GFW_LUT_TILE 0           // bicubic / Lanczos4 taps of planar 8/16-bit frames from a per-wave LDS tile of the source (tile_sample_store):
                                  // one coalesced fetch of the wave's bounding box per output row and plane instead of I row fetches per sample.
@@ -1008,6 +1012,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
     __shared__ unsigned short q_dst[FAST1 ? 4 : 1][FAST1 ? QCAP : 1];           // (owner lane << 6) | slot in s_rows
     __shared__ unsigned q_n[4];
     __shared__ int s_rows[RB * NPX][256];                                        // phase-1 rows, one column per lane
+#if GFW_LDS_MATRICES
+    constexpr bool MWIN = FAST1 && !AUDIT;
+    constexpr int MW_ROWS = 32, MW_PITCH = 12;                                   // 32 rows of 12 floats (m0..m8 + 3 of padding: 16-byte rows)
+    __shared__ __attribute__((aligned(16))) float s_mat[MWIN ? 4 : 1][MWIN ? MW_ROWS * MW_PITCH : 4];
+    __shared__ int s_mrow[4];
+#endif
     __shared__ float s_lut[I == 2 ? 1 : 448];                                    // bicubic / Lanczos4 tap table
 #if GFW_LUT_TILE
     // GFW_LUT_TILE = 1: bicubic / Lanczos4 only; 2: bilinear as well (the A/B the north-star asks for)
@@ -1167,6 +1177,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
             }
         }
 
+#if GFW_LDS_MATRICES
+        int mw0 = 0; bool mw_on = false;
+        if constexpr (MWIN) if (two_pass) {
+            // smallest row index any pixel of this wave's tile uses; the window holds the 32 rows from there
+            int my_min = 0x7fffffff;
+            #pragma unroll 1
+            for (int q = 0; q < RB * NPX; ++q) {
+                const int r = q / NPX, k = q - r * NPX;
+                const int lx = cx * DW + k % DW, ly = (cy0 + r) * DH + k / DW;
+                if (lane_ok && lx < A.out_w && ly < A.out_h) my_min = min(my_min, s_rows[q][tid]);
+            }
+            if (lane == 0) s_mrow[wave] = 0x7fffffff;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (my_min != 0x7fffffff) atomicMin(&s_mrow[wave], my_min);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const int m = __builtin_amdgcn_readfirstlane(s_mrow[wave]);
+            if (m != 0x7fffffff) {
+                mw0 = min(m, A.matrix_count - 1);
+                #pragma unroll
+                for (int e = lane; e < MW_ROWS * MW_PITCH; e += 64) {
+                    const int row = e / MW_PITCH, col = e - row * MW_PITCH;
+                    s_mat[wave][e] = A.matrices[(size_t)min(mw0 + row, A.matrix_count - 1) * GFW_MAT_STRIDE + col];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                mw_on = true;
+            }
+        }
+#endif
 #if GFW_TIMELINE
         const unsigned long long tl_b = __builtin_readcyclecounter();
 #endif
@@ -1198,6 +1236,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
                     else {
                         const int row = min(sy, A.matrix_count - 1);
                         if (AUDIT && (unsigned)row >= (unsigned)A.matrix_count) atomicAdd(&A.audit[5], 1ull);
+#if GFW_LDS_MATRICES
+                        if constexpr (MWIN) {                                  // one projection, its nine matrix entries from the window or from memory
+                            const float *g = A.matrices + (size_t)row * GFW_MAT_STRIDE;
+                            float4 ma, mb; float m8;
+                            if (mw_on && (unsigned)(row - mw0) < (unsigned)MW_ROWS) {
+                                const float *w = &s_mat[wave][(row - mw0) * MW_PITCH];
+                                ma = *reinterpret_cast<const float4 *>(w); mb = *reinterpret_cast<const float4 *>(w + 4); m8 = w[8];
+                            } else {
+                                ma = *reinterpret_cast<const float4 *>(g); mb = *reinterpret_cast<const float4 *>(g + 4); m8 = g[8];
+                            }
+                            p = rd<MODEL>(ox, oy, ma, mb, m8, g + 8, L, A);
+                        } else
+#endif
                         p = rd_row<MODEL>(ox, oy, row, L, A);
                     }
                     if ((A.background_mode == 1 || A.background_mode == 2) && p.ok) {                      // cpu_undistort.rs:495-509 (edge repeat / edge mirror)
