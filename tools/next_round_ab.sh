@@ -8,13 +8,13 @@ if [ "$1" = build ]; then
   rm -f variants/*
   bash tools/build_variants.sh "base:" "prio0:-DGFW_PRIO_MODE=0" \
       "atan_tab:-DGFW_ATAN_TABLE=1" "ck30:-DGFW_XCD_CHUNK=30" "atan_ck30:-DGFW_ATAN_TABLE=1,-DGFW_XCD_CHUNK=30" \
-      "ldsmat:-DGFW_LDS_MATRICES=1" "bl_tile:-DGFW_LUT_TILE=2" "age3:-DGFW_PRIO_AGE_ROWS=3" "age6:-DGFW_PRIO_AGE_ROWS=6" "pin:-DGFW_PIN_LENS=1" "atan_pin:-DGFW_ATAN_TABLE=1,-DGFW_PIN_LENS=1" "tl:-DGFW_TIMELINE=1" "tl_atan:-DGFW_TIMELINE=1,-DGFW_ATAN_TABLE=1"
+      "atan_w7:-DGFW_ATAN_TABLE=1,-DGFW_WAVES_PER_EU=7" "atan_w8:-DGFW_ATAN_TABLE=1,-DGFW_WAVES_PER_EU=8" "ldsmat:-DGFW_LDS_MATRICES=1" "bl_tile:-DGFW_LUT_TILE=2" "age3:-DGFW_PRIO_AGE_ROWS=3" "age6:-DGFW_PRIO_AGE_ROWS=6" "pin:-DGFW_PIN_LENS=1" "atan_pin:-DGFW_ATAN_TABLE=1,-DGFW_PIN_LENS=1" "tl:-DGFW_TIMELINE=1" "tl_atan:-DGFW_TIMELINE=1,-DGFW_ATAN_TABLE=1"
   # register budget of the generic-model instantiations (digital lenses, refraction, IBIS, non-fisheye lenses): whole translation unit
   GFW_VARIANT_FULL=1 bash tools/build_variants.sh "gen3:-DGFW_GENERIC_WAVES_PER_EU=3" "gen4:-DGFW_GENERIC_WAVES_PER_EU=4" \
       "gen6:-DGFW_GENERIC_WAVES_PER_EU=6" "gen2:-DGFW_GENERIC_WAVES_PER_EU=2"
   exit 0
 fi
-bash tools/gpu_ab.sh r03a base "base:--streams 2" "base:--streams 4" prio0 "prio0:--streams 2" atan_tab "atan_tab:--streams 2" ldsmat "bl_tile:--grid 1280" bl_tile age3 age6 pin atan_pin ck30 atan_ck30 tl "tl:--streams 2" tl_atan base \
+bash tools/gpu_ab.sh r03a base "base:--streams 2" "base:--streams 4" prio0 "prio0:--streams 2" atan_tab "atan_tab:--streams 2" "atan_w7:--grid 1792" "atan_w8:--grid 2048" ldsmat "bl_tile:--grid 1280" bl_tile age3 age6 pin atan_pin ck30 atan_ck30 tl "tl:--streams 2" tl_atan base \
     "gen3:--digital gopro_superview --steps 60" "gen4:--digital gopro_superview --steps 60" \
     "gen6:--digital gopro_superview --steps 60" "gen2:--digital gopro_superview --steps 60"
 
