@@ -35,6 +35,7 @@
 #include "gfw_fastmath.h"
 #include "gfw_frame.h"
 #include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 
 // measured switches (1 = on): branch-free rounding, exact-FMA row sums, hardware min for the limit clamp
@@ -774,8 +775,12 @@ template <typename T, int I, int NS>
 __device__ __forceinline__ void tile_sample_store(const GfwYuvPlane &P, const float *u, const float *v, const bool *ok, const bool *need,
                                                   const int *ox, const int *oy, const float *bg, float limit,
                                                   uint2 *tile, int *org, const float *lut, int lane) {
-    constexpr int TWB = GFW_TILE_W * (int)sizeof(T);           // bytes per tile row
-    constexpr int CH = TWB / 8;                                // 8-byte chunks per row = lanes that copy
+    // GFW_LUT_TILE = 3: the tile holds f32 (each source pixel converted once, two instead of three instructions per tap, twice the
+    // LDS: three workgroups per CU); otherwise the raw 8/16-bit pixels
+    typedef typename std::conditional<GFW_LUT_TILE == 3, float, T>::type E;
+    constexpr int TWB = GFW_TILE_W * (int)sizeof(T);           // source bytes per tile row
+    constexpr int CH = TWB / 8;                                // 8-byte source chunks per row = lanes that copy
+    constexpr int PXC = 8 / (int)sizeof(T);                    // pixels per chunk
     static_assert(TWB % 8 == 0 && CH <= 64, "tile row must be whole 8-byte chunks, one per lane");
     Bins<I> b[NS];
     bool inside[NS];
@@ -810,7 +815,15 @@ __device__ __forceinline__ void tile_sample_store(const GfwYuvPlane &P, const fl
                 if (y >= P.h) break;                                       // rows past the plane are never part of an inside window
                 if (lane < chunks) {
                     const uint2 d = *reinterpret_cast<const uint2 *>(P.src + (int64_t)y * P.src_stride + xb);
-                    tile[r * CH + lane] = d;
+                    if constexpr (GFW_LUT_TILE == 3) {
+                        E *dst = reinterpret_cast<E *>(tile) + r * GFW_TILE_W + lane * PXC;
+                        T px[PXC];
+                        __builtin_memcpy(px, &d, 8);
+                        #pragma unroll
+                        for (int i = 0; i < PXC; ++i) dst[i] = (float)px[i];
+                    } else {
+                        tile[r * CH + lane] = d;
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -821,7 +834,7 @@ __device__ __forceinline__ void tile_sample_store(const GfwYuvPlane &P, const fl
         if (!need[q]) continue;
         const bool fit = have && inside[q] && (b[q].sx - x0 + I <= valid_w) && (b[q].sy - y0 + I <= GFW_TILE_H);
         if (fit) {
-            const T *t0 = reinterpret_cast<const T *>(tile) + (b[q].sy - y0) * GFW_TILE_W + (b[q].sx - x0);
+            const E *t0 = reinterpret_cast<const E *>(tile) + (b[q].sy - y0) * GFW_TILE_W + (b[q].sx - x0);
             float cx[I];
             #pragma unroll
             for (int i = 0; i < I; ++i) cx[i] = b[q].tx[i];
@@ -1022,7 +1035,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == GF
 #if GFW_LUT_TILE
     // GFW_LUT_TILE = 1: bicubic / Lanczos4 only; 2: bilinear as well (the A/B the north-star asks for)
     constexpr bool TILE = MODEL == GFW_MODEL_OPENCV_FISHEYE && (I != 2 || GFW_LUT_TILE == 2) && !AUDIT && !is_f32<T>::value && N0 == 1 && !INTERLEAVED_UV && NPX <= 2;
-    __shared__ uint2 s_tile[TILE ? 4 : 1][TILE ? ((I == 2 ? GFW_TILE2_H : GFW_TILE_H) * GFW_TILE_W * (int)sizeof(T)) / 8 : 1];
+    __shared__ uint2 s_tile[TILE ? 4 : 1][TILE ? ((I == 2 ? GFW_TILE2_H : GFW_TILE_H) * GFW_TILE_W * (int)(GFW_LUT_TILE == 3 && I != 2 ? sizeof(float) : sizeof(T))) / 8 : 1];
     __shared__ int s_org[4][2];
 #endif
     const int wave = threadIdx.y, lane = threadIdx.x, tid = wave * 64 + lane;

@@ -28,6 +28,7 @@ bash tools/gpu_ab.sh r03a base "base:--streams 2" "base:--streams 4" prio0 "prio
 # prints the agreement per model; put the measured numbers into the assertions and move the file to -m gpu.
 # Lanczos4 through the LDS tile (GFW_LUT_TILE, written / compiled / never run): first parity, then time.  The tile kernel holds
 # 35.6 KB of LDS and 100 VGPRs: four workgroups per CU, so give it --grid 1024 as well.
-#   CPU box:  GFW_VARIANT_TAPS=8 bash tools/build_variants.sh "l8_base:" "l8_tile:-DGFW_LUT_TILE=1"
-#   GPU:      bash tools/gpu_ab.sh r03l "l8_base:--interp 8 --steps 60" "l8_tile:--interp 8 --steps 60" "l8_tile:--interp 8 --steps 60 --grid 1024"
+#   CPU box:  GFW_VARIANT_TAPS=8 bash tools/build_variants.sh "l8_base:" "l8_tile:-DGFW_LUT_TILE=1" "l8_tilef:-DGFW_LUT_TILE=3"
+#   GPU:      bash tools/gpu_ab.sh r03l "l8_base:--interp 8 --steps 60" "l8_tile:--interp 8 --steps 60" "l8_tile:--interp 8 --steps 60 --grid 1024" \
+#                                       "l8_tilef:--interp 8 --steps 60 --grid 768"        (f32 tile: 51 KB of LDS, three workgroups per CU)
 #   (bench.py checks the last frames of the timed region against the oracle: parity_vs_oracle must read bit-exact)
