@@ -5,12 +5,15 @@
 
 A "step" is one pass of the hot path over one synthetic frame: all planes of a 4K (3840x2160) u16 4:2:2 frame
 (BASELINE.json configs[1], "C2": planar YUV422P16LE = 3 x Luma16, GoPro-style opencv_fisheye lens, per-row
-rolling-shutter matrices) warped through libgfwarp's C ABI from buffers already resident in HBM.
+rolling-shutter matrices) warped through libgfwarp's C ABI from buffers already resident in HBM.  The steps go to the
+library the way a render loop hands it a clip: `gfw_undistort_clip` calls of `--clip` frames each (default 8; exactly K
+frames are warped in the timed region), served by the context's run-time specialised kernel (GFW_OPT_JIT = 2: built
+during the warm-up, `config.jit` reports the build) in launches of up to 8 frames.
 
 Process model.  Started plainly, this file is a *launcher*: it spawns one worker process per GPU (RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* in the environment, rendezvous on 127.0.0.1), relays rank 0's JSON line and exits with the
-workers' status; a worker set that dies abnormally is re-run (at most twice more) and the line says so under
-`launcher`.  Started by `torch.distributed.run` (RANK already in the environment) it is a worker itself.  N >= 2 ranks
+workers' status; a worker set that dies abnormally fails the run (exit status != 0, no JSON line) unless `--retry` asks
+for up to two more attempts, which the line then reports under `launcher`.  Started by `torch.distributed.run` (RANK already in the environment) it is a worker itself.  N >= 2 ranks
 talk over RCCL (`nccl` backend); frames shard across ranks and no pixel ever crosses GPUs — the only collectives are a
 broadcast of the clip-invariant block, a barrier either side of the timed region, a MAX of the elapsed time and an
 all-gather of output checksums.
@@ -45,9 +48,9 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FMT, WIDTH, HEIGHT = "YUV422P16LE", 3840, 2160
 N_RESIDENT = 64                  # distinct source frames + per-row matrix tables resident in HBM, cycled by the steps
                                  # (SURVEY.md 8d "64 distinct resident source frames cycled": 2.1 GB, far beyond L2 + MALL)
-N_DST = 4                        # destination frame sets written round-robin
+N_DST = 8                        # destination frame sets written round-robin (the frames of one clip launch are in flight together: one set each)
 N_CHECK = 3                      # frames of the timed region compared with the oracle afterwards
-TRAFFIC_FILE = os.path.join("profiles", "r02_c2_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_c2_traffic.json")
 
 
 def parse_args(argv):
@@ -58,7 +61,16 @@ def parse_args(argv):
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N >= 2 (nccl = RCCL; gloo for the 1-GPU test of the N-rank path)")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (testing the N-rank path on a 1-GPU box; with --backend gloo)")
-    ap.add_argument("--no-retry", action="store_true", help="launcher: do not re-run a worker set that died")
+    ap.add_argument("--retry", action="store_true", help="launcher: re-run a worker set that died abnormally (GPU fault, signal) up to twice; "
+                                                        "by default such a death fails the run")
+    ap.add_argument("--no-retry", action="store_true", help=argparse.SUPPRESS)      # the default since round 3
+    ap.add_argument("--jit", type=int, default=2, choices=(0, 1, 2),
+                    help="GFW_OPT_JIT of the contexts: 2 (default) the per-clip specialised kernel is built during the warm-up; 0 ahead-of-time kernels only")
+    ap.add_argument("--clip", type=int, default=8,
+                    help="frames per gfw_undistort_clip call (resident-matrices workloads); 1 = one gfw_undistort_frame call per frame")
+    ap.add_argument("--preheat-ms", type=float, default=60.0,
+                    help="untimed launches of the same workload for this long right before the timed region (declared in config.preheat_ms): "
+                         "a 20-step region lasts 1.5 ms, shorter than the clock governor's ramp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the last timed frames")
     ap.add_argument("--width", type=int, default=WIDTH)
@@ -106,11 +118,12 @@ def _free_port():
 
 
 def launcher(args, argv):
-    """Spawn one worker per GPU, relay rank 0's JSON line.  A worker set that dies abnormally (GPU fault, signal) is
-    re-run — at most three attempts in all — and every failed attempt is reported in the line (`launcher.failures`)."""
+    """Spawn one worker per GPU, relay rank 0's JSON line.  A worker set that dies abnormally (GPU fault, signal) fails the run;
+    with --retry it is re-run — at most three attempts in all — and every failed attempt is reported in the line
+    (`launcher.failures`)."""
     n = max(1, args.gpus)
     failures = []
-    attempts = 1 if args.no_retry else 3
+    attempts = 3 if args.retry else 1
     for attempt in range(1, attempts + 1):
         env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -262,6 +275,7 @@ def worker(args):
         be.set_option(abi.OPT_KERNEL_VARIANT, args.variant)
     if args.grid:
         be.set_option(abi.OPT_TUNE_GRID, args.grid)
+    be.set_option(abi.OPT_JIT, args.jit)
     rows_n = frames[0].matrices.shape[0]
     nk = S.new_k(frames[0].lens, fov, W, H)
 
@@ -310,6 +324,8 @@ def worker(args):
     # --streams S: S contexts, each on a stream of its own, take the frames in turn.  Frame k writes destination set k mod N_DST and
     # S divides N_DST, so two frames that share a destination set always share a stream (ordered); everything else may overlap.
     n_streams = args.streams if not (device_built or args.upload_matrices or args.host_buffers or args.c5) else 1
+    if n_streams > 1 and (NR % N_DST or N_DST % n_streams):
+        raise SystemExit("bench.py: --streams %d needs --resident to be a multiple of %d (two streams would write one destination set unordered)" % (n_streams, N_DST))
     extra_bes, extra_streams, calls_by_stream = [], [], [calls]
     for _ in range(1, n_streams):
         st = torch.cuda.Stream(device=dev)
@@ -321,20 +337,62 @@ def worker(args):
         if args.grid:
             b2.set_option(abi.OPT_TUNE_GRID, args.grid)
         b2.set_option(abi.OPT_MATRICES_ON_DEVICE, 2)
+        b2.set_option(abi.OPT_JIT, args.jit)
         extra_bes.append(b2); extra_streams.append(st)
         calls_by_stream.append([warp.FrameCall(b2, bufsets[j * N_DST + (j % N_DST)], tmpl, types, d_mat[j].data_ptr(), rows_n) for j in range(NR)])
     all_bes = [be] + extra_bes
+
+    # ---- clip mode: the steps reach the library as gfw_undistort_clip calls of `clip_n` frames (the frames of one call use distinct
+    # destination sets: the specialised kernel takes up to 8 of them in one launch)
+    clip_n = max(1, min(args.clip, N_DST))
+    if args.upload_matrices or args.host_buffers or n_streams > 1 or (device_built and not args.c5) or (NR % clip_n and not device_built):
+        clip_n = 1
+    if args.c5 and BATCH % clip_n:
+        clip_n = 1
 
     # what step k of this rank reads and writes: (global frame, source set, destination set)
     def plan(k):
         f = own[k] if args.c5 else k
         j = f % NR
-        return f, j, ((k if device_built else j) % N_DST)
+        if device_built:
+            return f, j, (k % clip_n if clip_n > 1 else k % N_DST)
+        return f, j, j % N_DST
 
     if args.c5:
         d_sums = torch.zeros(max(1, n_steps), dtype=torch.int64, device=dev)
         sum_fn, sum_base = be.lib.gfw_checksum64, d_sums.data_ptr()
         dst_ptrs = [b.data_ptr() for b in d_dstbuf]
+
+    clip_cache = {}
+
+    def clip_for(k0, ln):
+        """pre-marshalled gfw_undistort_clip call for steps k0 .. k0+ln-1"""
+        js = tuple(plan(k0 + i)[1] for i in range(ln))
+        call = clip_cache.get(js)
+        if call is None:
+            if device_built:                            # C5: frame i of the call writes destination set i; its table pointer is set per call
+                call = warp.ClipCall(be, [bufsets[j * N_DST + i] for i, j in enumerate(js)], tmpl, types, [table0] * ln, rows_n)
+            else:
+                call = warp.ClipCall(be, [bufsets[j * N_DST + (j % N_DST)] for j in js], tmpl, types, [d_mat[j].data_ptr() for j in js], rows_n)
+            clip_cache[js] = call
+        return call
+
+    def clip_step(k0, ln):
+        call = clip_for(k0, ln)
+        if device_built:
+            if k0 % BATCH == 0:                         # one launch builds the tables of the next BATCH frames, in order on the warp's stream
+                for i in range(BATCH):
+                    kk = min(k0 + i, n_steps - 1)
+                    timings[i].timestamp_ms = ts_of(own[kk] if args.c5 else kk)
+                rc = batch_fn(ctxp, timings, BATCH, tptrs)
+                if rc != 0:
+                    be._check(rc)
+            for i in range(ln):
+                call.marr[i] = tptrs[(k0 + i) % BATCH]
+        call()
+        if args.c5:
+            for i in range(ln):                         # each frame's checksum, in order on the same stream
+                sum_fn(ctxp, dst_ptrs[i], dst_total, sum_base + 8 * (k0 + i))
 
     def step(k):
         f, j, d = plan(k)
@@ -365,40 +423,61 @@ def worker(args):
         else:
             calls[j]()
 
-    for k in range(n_warm):
-        step(k)
+    def run_steps(n, bracket_every=0):
+        """steps 0 .. n-1 of the workload, as clip calls or frame by frame; every bracket_every-th launch has its kernel time taken"""
+        set_opt, ctxps = be.lib.gfw_set_option, [b.ctx for b in all_bes]
+        if clip_n > 1:
+            for c, k0 in enumerate(range(0, n, clip_n)):
+                ln = min(clip_n, n - k0)
+                if bracket_every and c % 2 == 0:        # a launch carries clip_n frames: every other one is bracketed
+                    set_opt(ctxps[0], abi.OPT_PROFILE, 1)
+                    clip_step(k0, ln)
+                    set_opt(ctxps[0], abi.OPT_PROFILE, 0)
+                else:
+                    clip_step(k0, ln)
+        elif bracket_every > 1:
+            for k in range(n):
+                if k % bracket_every == 0:
+                    ctxp2 = ctxps[k % n_streams]
+                    set_opt(ctxp2, abi.OPT_PROFILE, 1)
+                    step(k)
+                    set_opt(ctxp2, abi.OPT_PROFILE, 0)
+                else:
+                    step(k)
+        else:
+            for k in range(n):
+                step(k)
+
+    run_steps(n_warm)
     torch.cuda.synchronize(dev)
+    jit_state = be.jit_status()
+    # declared, untimed pre-heat: the same launches for --preheat-ms, so that a short timed region runs at the clocks a long one does
+    preheat_ms = 0.0
+    if args.preheat_ms > 0 and n_steps > 0 and not args.host_buffers:
+        t_ph = time.perf_counter()
+        while (time.perf_counter() - t_ph) * 1e3 < args.preheat_ms:
+            run_steps(min(n_steps, 4 * max(clip_n, 8)))
+            torch.cuda.synchronize(dev)
+        preheat_ms = (time.perf_counter() - t_ph) * 1e3
     if args.c5:
         d_sums.zero_()                                # gfw_checksum64 accumulates
     pe = args.profile_every
     for b in all_bes:
-        b.set_option(abi.OPT_PROFILE, 1 if pe == 1 else 0)
+        b.set_option(abi.OPT_PROFILE, 1 if (pe == 1 and clip_n == 1) else 0)
         b.get_profile(reset=True)
     shard.barrier(dist)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    if pe > 1:
-        set_opt, ctxps = be.lib.gfw_set_option, [b.ctx for b in all_bes]
-        for k in range(n_steps):
-            if k % pe == 0:
-                ctxp2 = ctxps[k % n_streams]
-                set_opt(ctxp2, abi.OPT_PROFILE, 1)
-                step(k)
-                set_opt(ctxp2, abi.OPT_PROFILE, 0)
-            else:
-                step(k)
-    else:
-        for k in range(n_steps):
-            step(k)
+    run_steps(n_steps, pe)
     t_enq = time.perf_counter() - t0                 # host time to enqueue the steps (the GPU runs behind it)
     torch.cuda.synchronize(dev)
     shard.barrier(dist)
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    kernel_ms, launches = 0.0, 0
+    kernel_ms, launches, prof_frames = 0.0, 0, 0
     for b in all_bes:
-        km, ln = b.get_profile(reset=True)
-        kernel_ms += km; launches += ln
+        km, ln, nf = b.get_profile_frames(reset=True)
+        kernel_ms += km; launches += ln; prof_frames += nf
         b.set_option(abi.OPT_PROFILE, 0)
     elapsed = shard.reduce_max(dist, elapsed, cdev)
 
@@ -434,6 +513,8 @@ def worker(args):
         "" if device_built else " + per-row matrix tables", how)
     if args.c5:
         workload += "; %d-frame clip dealt round-robin to %d rank(s), one 64-bit checksum per frame" % (total, world)
+    if clip_n > 1:
+        workload += "; steps handed to the library as gfw_undistort_clip calls of %d frames" % clip_n
     out = {
         "metric": "Mpix/s (4K u16 YUV, rolling-shutter warp)" if not args.c1 else "Mpix/s (1080p u8 NV12 warp)",
         "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": n_steps, "warmup": n_warm,
@@ -443,11 +524,15 @@ def worker(args):
                    "streams_per_rank": n_streams, "frames_per_rank": n_steps, "frames_total": frames_done, "parallelism": "frame-sharded x%d" % world,
                    "backend": warp.last_backend(), "checksum": crc, "rank_checksums": rank_crcs,
                    "host_enqueue_ms_per_step": round(t_enq / max(n_steps, 1) * 1e3, 5),
+                   "clip_frames_per_call": clip_n, "preheat_ms": round(preheat_ms, 1),
+                   "jit": {"mode": args.jit, "state": {0: "none", 1: "compiling", 2: "ready", 3: "failed"}.get(jit_state[0], str(jit_state[0])),
+                           "compile_ms": round(jit_state[1], 1), "log": jit_state[2][-300:] if jit_state[0] == 3 else ""},
                    "device": info.value.decode(), "collectives": (args.backend if dist is not None else "none (1 rank)")},
     }
     if launches:
         per_launch_ms = kernel_ms / launches
-        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
+        fpl = max(prof_frames, launches) / launches                 # frames per bracketed launch (a clip launch carries up to 8)
+        achieved = alg_bytes * fpl / (per_launch_ms * 1e-3) / 1e9
         # HBM bytes per launch: rocprofv3 PMC passes cannot run inside bench.py; the stored figure of this exact workload is quoted
         traffic, tsrc = None, None
         tpath = os.path.join(ROOT, TRAFFIC_FILE)
@@ -458,7 +543,8 @@ def worker(args):
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                            "kernel": warp.last_backend(), "kernel_ms_per_launch": round(per_launch_ms, 5),
-                           "algorithmic_bytes_per_launch": alg_bytes, "launches": launches}
+                           "frames_per_launch": round(fpl, 3), "kernel_ms_per_frame": round(per_launch_ms / fpl, 5),
+                           "algorithmic_bytes_per_launch": int(alg_bytes * fpl), "launches": launches}
 
     # ---- parity of the timed region's own output, and the CPU baseline (rank 0) ---------------------------------
     if rank == 0 and not (args.no_parity and (args.no_cpu_baseline or world > 1)):

@@ -114,7 +114,7 @@ ERRORS = {
 
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP = -9, -10, -11
 POINT_INDEX_SINGLE, POINT_INDEX_PER_POINT, POINT_INDEX_PER_ROW, POINT_INDEX_PER_COLUMN = 0, 1, 2, 3
-OPT_SYNCHRONOUS, OPT_MATRICES_ON_DEVICE, OPT_KERNEL_VARIANT, OPT_PROFILE, OPT_TUNE_ROWS, OPT_TUNE_GRID = 1, 2, 3, 4, 5, 6
+OPT_SYNCHRONOUS, OPT_MATRICES_ON_DEVICE, OPT_KERNEL_VARIANT, OPT_PROFILE, OPT_TUNE_ROWS, OPT_TUNE_GRID, OPT_JIT = 1, 2, 3, 4, 5, 6, 7
 
 _lib = None
 
@@ -140,6 +140,11 @@ def bind(lib):
     lib.gfw_synchronize.argtypes = [vp]; lib.gfw_synchronize.restype = i32
     lib.gfw_last_backend.argtypes = [vp]; lib.gfw_last_backend.restype = C.c_char_p
     lib.gfw_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]; lib.gfw_get_profile.restype = i32
+    lib.gfw_get_profile_frames.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64), i32]; lib.gfw_get_profile_frames.restype = i32
+    lib.gfw_undistort_clip.argtypes = [vp, i32, i32, C.POINTER(Buffers), C.POINTER(KernelParams), C.POINTER(i32), C.POINTER(vp), i32]
+    lib.gfw_undistort_clip.restype = i32
+    lib.gfw_debug_jit_compile.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz]; lib.gfw_debug_jit_compile.restype = C.c_long
+    lib.gfw_jit_status.argtypes = [vp, C.POINTER(C.c_double), C.c_char_p, sz]; lib.gfw_jit_status.restype = i32
     lib.gfw_set_quaternion_tracks.argtypes = [vp, vp, vp, i32, vp, vp, i32]; lib.gfw_set_quaternion_tracks.restype = i32
     lib.gfw_build_matrices.argtypes = [vp, C.POINTER(FrameTiming), vp, C.POINTER(vp)]; lib.gfw_build_matrices.restype = i32
     lib.gfw_build_matrices_stab.argtypes = [vp, C.POINTER(FrameTiming), C.POINTER(FrameStab), vp, C.POINTER(vp)]; lib.gfw_build_matrices_stab.restype = i32
@@ -161,7 +166,7 @@ def bind(lib):
 EXPORTS = ["gfw_abi_version", "gfw_list_devices", "gfw_set_device", "gfw_get_info", "gfw_is_buffer_supported",
            "gfw_create", "gfw_destroy", "gfw_undistort_image", "gfw_undistort_frame", "gfw_set_option",
            "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_last_backend", "gfw_get_profile", "gfw_last_error", "gfw_debug_math", "gfw_debug_selftest", "gfw_get_audit", "gfw_pack_matrices", "gfw_checksum64", "gfw_set_quaternion_tracks", "gfw_build_matrices", "gfw_build_matrices_stab", "gfw_set_sync_offsets", "gfw_build_matrices_batch", "gfw_stmap_undistort", "gfw_undistort_points",
-           "gfw_pixel_type_info"]
+           "gfw_pixel_type_info", "gfw_undistort_clip", "gfw_jit_status", "gfw_get_profile_frames", "gfw_debug_jit_compile"]
 
 
 def load_library(path=None):

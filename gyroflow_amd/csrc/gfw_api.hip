@@ -19,6 +19,8 @@
 #include "gfw_launch.h"
 #include "gfw_frame.h"
 #include "gfw_matrices.h"
+#include "gfw_jit.h"
+#include <stdlib.h>
 #include <map>
 #include <mutex>
 
@@ -87,7 +89,6 @@ struct gfw_ctx {
     // certified first pass of the fused kernel: s(rho) table cache
     DevBuf d_p1_table, d_audit;
     float p1_k[4] = {0, 0, 0, 0}; float p1_rho_max = 0.0f; double p1_etab = 0.0; double p1_smax = 1.0; bool p1_valid = false;
-    double p2_kappa = 0.0; bool p2_ok = false;    // certified second pass: relative bound on |s~ - s_ref| for this table (p2_bound)
     DevBuf d_pts_in, d_pts_out, d_pts_rot, d_pts_shift, d_pts_mesh;   // gfw_undistort_points staging
     DevBuf d_tracks;                              // quaternion tracks
     // context-owned per-row tables built on the device (gfw_build_matrices): a small ring, built on copy_stream so that
@@ -105,10 +106,18 @@ struct gfw_ctx {
     int bslot_next = 0, bslot_cur = -1;
     GfwTracks tracks = {nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, 1.0};
     DevBuf d_offsets, d_stab;                      // sync offsets of the clip; IBIS/OIS control points of the frame being built
+    // run-time specialised kernel (gfw_jit.hip): 0 off; 1 build in the background once the context has seen kJitAfter frames of one
+    // clip, warp ahead-of-time meanwhile; 2 build at the first frame and wait for it
+    int jit_mode = 1;
+    std::string arch;                              // gcnArchName of the device
+    std::string jit_header; int jit_seen = 0;      // bake header of the frames being seen, and how many in a row
+    GfwJitInfo jit_info = {GFW_JIT_UNAVAILABLE, 0.0, std::string()};
+    static constexpr int kJitAfter = 3;
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;   // recorded, not yet harvested
     size_t ev_used = 0;
-    double prof_ms = 0.0; int64_t prof_launches = 0;
+    double prof_ms = 0.0; int64_t prof_launches = 0, prof_frames = 0;
+    std::vector<int> ev_frames;                   // frames covered by each bracketed launch
 };
 
 static void prof_begin(gfw_ctx *c) {
@@ -120,15 +129,17 @@ static void prof_begin(gfw_ctx *c) {
     }
     (void)hipEventRecord(c->ev_pool[c->ev_used].first, c->stream);
 }
-static void prof_end(gfw_ctx *c) {
+static void prof_end(gfw_ctx *c, int frames = 1) {
     if (!c->profile) return;
     (void)hipEventRecord(c->ev_pool[c->ev_used].second, c->stream);
+    if (c->ev_frames.size() <= c->ev_used) c->ev_frames.resize(c->ev_used + 1);
+    c->ev_frames[c->ev_used] = frames;
     c->ev_used++;
 }
 static void prof_harvest(gfw_ctx *c) {
     for (size_t i = 0; i < c->ev_used; ++i) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second) == hipSuccess) { c->prof_ms += ms; c->prof_launches++; }
+        if (hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second) == hipSuccess) { c->prof_ms += ms; c->prof_launches++; c->prof_frames += c->ev_frames[i]; }
     }
     c->ev_used = 0;
 }
@@ -214,7 +225,8 @@ gfw_ctx *gfw_create(const gfw_kernel_params *params, int pixel_type, int distort
 
     gfw_ctx *c = new gfw_ctx();
     c->device = g_current_device;
-    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, c->device) == hipSuccess && pr.multiProcessorCount > 0) c->num_cus = pr.multiProcessorCount; }
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, c->device) == hipSuccess && pr.multiProcessorCount > 0) { c->num_cus = pr.multiProcessorCount; c->arch = pr.gcnArchName; } }
+    if (const char *e = getenv("GFW_JIT")) c->jit_mode = atoi(e);          // deployment / test override of GFW_OPT_JIT's default
     c->pixel_type = pixel_type; c->model = distortion_model; c->digital = digital_lens;
     c->src_len = buffers->input.len; c->dst_len = buffers->output.len;
     c->max_matrix_rows = ((params->flags & GFW_FLAG_HORIZONTAL_RS) ? params->width : params->height);   // opencl.rs:287
@@ -273,6 +285,8 @@ int gfw_set_option(gfw_ctx *c, int option, int64_t value) {
     case GFW_OPT_PROFILE: c->profile = value != 0; return GFW_OK;
     case GFW_OPT_TUNE_ROWS: c->tune_rb = (int)value; return GFW_OK;
     case GFW_OPT_TUNE_GRID: c->tune_grid = (int)value; return GFW_OK;
+    case GFW_OPT_JIT: if (value < 0 || value > 2) { set_error("GFW_OPT_JIT %lld", (long long)value); return GFW_ERR_INVALID_ARGUMENT; }
+                      c->jit_mode = (int)value; return GFW_OK;
     default: set_error("unknown option %d", option); return GFW_ERR_INVALID_ARGUMENT;
     }
 }
@@ -293,6 +307,12 @@ int gfw_synchronize(gfw_ctx *c) {
     return GFW_OK;
 }
 const char *gfw_last_backend(gfw_ctx *c) { return c ? c->last_backend : ""; }
+int gfw_jit_status(gfw_ctx *c, double *compile_ms, char *log, size_t cap) {
+    if (!c) return GFW_ERR_INVALID_ARGUMENT;
+    if (compile_ms) *compile_ms = c->jit_info.compile_ms;
+    if (log && cap) { snprintf(log, cap, "%s", c->jit_info.log.c_str()); }
+    return c->jit_info.state == GFW_JIT_READY ? 2 : c->jit_info.state == GFW_JIT_COMPILING ? 1 : c->jit_info.state == GFW_JIT_FAILED ? 3 : 0;
+}
 int gfw_get_audit(gfw_ctx *c, unsigned long long *counters8, int reset) {
     if (!c || !counters8) return GFW_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
@@ -310,8 +330,13 @@ int gfw_get_profile(gfw_ctx *c, double *kernel_ms, int64_t *launches, int reset)
     prof_harvest(c);
     if (kernel_ms) *kernel_ms = c->prof_ms;
     if (launches) *launches = c->prof_launches;
-    if (reset) { c->prof_ms = 0.0; c->prof_launches = 0; }
+    if (reset) { c->prof_ms = 0.0; c->prof_launches = 0; c->prof_frames = 0; }
     return GFW_OK;
+}
+int gfw_get_profile_frames(gfw_ctx *c, double *kernel_ms, int64_t *launches, int64_t *frames, int reset) {
+    if (!c) return GFW_ERR_INVALID_ARGUMENT;
+    if (frames) { HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP); prof_harvest(c); *frames = c->prof_frames; }
+    return gfw_get_profile(c, kernel_ms, launches, reset);
 }
 
 }  // extern "C"
@@ -486,44 +511,6 @@ static double p1_s_of_rho(double rho, const float *k) {
     const double t = atan(r), t2 = t * t;
     return t * (1.0 + t2 * ((double)k[0] + t2 * ((double)k[1] + t2 * ((double)k[2] + t2 * (double)k[3])))) / r;
 }
-// Certified second pass (gfw_hot_kernel): relative bound kappa on |s~ - s_ref|, where s_ref = fl(theta_d / r) is what the
-// reference computes from its a, b (opencv_fisheye.rs:77-93) and s~ the table value at rho~ = fma(a, a, b*b).  DESIGN.md
-// section 2b derives it; with eps = 2^-24, t = atan(r), P(t) = 1 + k0 t^2 + k1 t^4 + k2 t^6 + k3 t^8, S(rho) = t P(t) / r:
-//   reference:  r = sqrt(rho)(1 + 2 eps) [a^2, b^2, +, sqrt];  atanf: (1 + cA eps), cA = 1.4163 measured over ALL positive
-//               floats against the restated libm routine (tests/test_math_host.py);  polynomial: KP eps relative to P
-//               (8 products, 4 sums);  t*poly and /r: 2 eps;  t's error through t P(t): cA (1 + RP) eps, RP = max |t P'/P|;
-//               r's error through S: 4 RL eps, RL = max |rho S'(rho) / S(rho)|
-//   table path: rho~ (2 eps) and rho~*scale (1 eps) through S: 3 RL eps;  the interpolating fma: 1 eps;  interpolation and
-//               entry rounding: 1.5 etab / S_min;  forming s(1 -+ kappa): eps / 2, taken three times
-// All maxima are taken over the table's domain on a fine grid and inflated by 2 %.
-static bool p2_bound(const float *k, double rho_max, double etab_abs, double &kappa) {
-    const double eps = ldexp(1.0, -24), cA = 1.4163;
-    const double ak[4] = {fabs((double)k[0]), fabs((double)k[1]), fabs((double)k[2]), fabs((double)k[3])};
-    const double t_hi = atan(sqrt(rho_max)) * 1.0005;
-    double RP = 0.0, KP = 0.0, RL = 0.0, Pmin = 1e300, Smin = 1e300;
-    const int n = 8192;
-    for (int i = 0; i <= n; ++i) {
-        const double t = t_hi * i / n, t2 = t * t;
-        const double P = 1.0 + t2 * ((double)k[0] + t2 * ((double)k[1] + t2 * ((double)k[2] + t2 * (double)k[3])));
-        const double tPp = t2 * (2.0 * k[0] + t2 * (4.0 * k[1] + t2 * (6.0 * k[2] + t2 * 8.0 * k[3])));          // t P'(t)
-        const double A2 = t2 * (2.0 * ak[0] + t2 * (4.0 * ak[1] + t2 * (6.0 * ak[2] + t2 * 8.0 * ak[3])));
-        const double Q = 1.0 + t2 * (ak[0] + t2 * (ak[1] + t2 * (ak[2] + t2 * ak[3])));
-        if (!(P > 0.0)) return false;
-        Pmin = fmin(Pmin, P);
-        RP = fmax(RP, fabs(tPp) / P);
-        KP = fmax(KP, (A2 + 4.0 * Q) / P);
-        const double r = tan(t);
-        if (r > 0.0) {
-            const double theta_d = t * P, dtheta_d = P + tPp;
-            Smin = fmin(Smin, theta_d / r);
-            RL = fmax(RL, 0.5 * fabs(r * dtheta_d / ((1.0 + r * r) * theta_d) - 1.0));
-        }
-    }
-    if (!(Pmin >= 0.25) || !(Smin >= 0.05) || !(RP == RP) || !(KP == KP) || !(RL == RL)) return false;
-    kappa = eps * (cA * (1.0 + RP) + KP + 2.0 + 4.0004 * RL + 3.0 * RL + 1.0) * 1.02 + 1.5 * etab_abs / Smin + 1.5 * eps;
-    return kappa == kappa && kappa < 2e-5;
-}
-
 static int p1_prepare_table(gfw_ctx *c, const gfw_kernel_params &p, float rho_max) {
     if (c->p1_valid && memcmp(c->p1_k, p.k, sizeof(c->p1_k)) == 0 && rho_max <= c->p1_rho_max && rho_max >= 0.5f * c->p1_rho_max) return GFW_OK;
     const int N = GFW_P1_TABLE_N;
@@ -550,8 +537,6 @@ static int p1_prepare_table(gfw_ctx *c, const gfw_kernel_params &p, float rho_ma
     HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);      // `tab` is a stack-lifetime source
     memcpy(c->p1_k, p.k, sizeof(c->p1_k));
     c->p1_rho_max = rho_max; c->p1_etab = etab; c->p1_smax = smax; c->p1_valid = true;
-    const bool k_all_zero = p.k[0] == 0.0f && p.k[1] == 0.0f && p.k[2] == 0.0f && p.k[3] == 0.0f;
-    c->p2_ok = !k_all_zero && p2_bound(p.k, (double)rho_max, etab, c->p2_kappa);
     return GFW_OK;
 }
 // Fill the first-pass fields of the fused kernel's arguments; returns true when the certified pass may be used.
@@ -597,7 +582,7 @@ static bool p1_setup(gfw_ctx *c, const gfw_kernel_params &p0, const float *h_mat
     Y.p1_eps = (float)eps;
     Y.p1_f = hrs ? p0.f[0] : p0.f[1]; Y.p1_c = hrs ? p0.c[0] : p0.c[1];
     table_ok = true;
-    if (c->kernel_variant == 3 || c->kernel_variant == 6) {     // audit mode: count certificates and check each one
+    if (c->kernel_variant == 3) {                               // audit mode: count certificates and check each one
         const bool fresh = c->d_audit.cap == 0;
         if (c->d_audit.ensure(8 * sizeof(unsigned long long)) != hipSuccess) { table_ok = false; return false; }
         if (fresh) (void)hipMemsetAsync(c->d_audit.ptr, 0, 8 * sizeof(unsigned long long), c->stream);
@@ -615,12 +600,6 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
                            GfwYuvArgs &Y, int &bytes_per_sample, int &n0, int &dw, int &dh, bool &interleaved, bool &fast1) {
     if (c->kernel_variant == 1) return false;                       // forced generic (tests / A-B benchmarking)
     if (nplanes < 1 || nplanes > 4) return false;
-#ifndef GFW_STAGED_FUSED
-#define GFW_STAGED_FUSED 0
-#endif
-    // staged fused paths (gfw_frame.hip: GFW_STAGED_FUSED): built only on request, taken only with GFW_OPT_KERNEL_VARIANT = 7
-    const bool staged = GFW_STAGED_FUSED && c->kernel_variant == 7;
-    if (mesh_len != 0 && !staged) return false;
     const gfw_kernel_params &p0 = params[0];
     const int t0 = pixel_types[0];
     // plane 0: sample kind (1 = u8, 2 = u16, 4 = f32) and channel count; RGBAf16 / UV-as-plane-0 stay on the generic kernel
@@ -650,10 +629,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     for (int i = 0; i < nplanes; ++i) {
         const gfw_kernel_params &p = params[i];
         if ((p.interpolation != 2 && p.interpolation != 4 && p.interpolation != 8) || p.interpolation != p0.interpolation) return false;
-        // background mode 3 (margin with feather) runs fused only on request (GFW_OPT_KERNEL_VARIANT = 7) until that path has been
-        // through the GPU parity suite; by default it takes the per-plane kernel like every setting the fused kernel does not serve
-        const int bg_max = staged ? 3 : 2;
-        if (p.background_mode < 0 || p.background_mode > bg_max || p.background_mode != p0.background_mode || p.input_rotation != 0.0f) return false;
+        if (p.background_mode < 0 || p.background_mode > 3 || p.background_mode != p0.background_mode || p.input_rotation != 0.0f) return false;
         if (p.background_mode == 3) {
             if (p.background_margin != p0.background_margin || p.background_margin_feather != p0.background_margin_feather) return false;
             extras |= 16;                                                        // two samples + blend (:576-613), generic-model instantiation
@@ -764,25 +740,106 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     Y.ablate = (c->kernel_variant >= 16) ? (c->kernel_variant - 16) : 0;      // timing ablations (results are wrong by design)
     bool table_ok = false;
     fast1 = (extras || p0.output_width > 65535 || p0.output_height > 65535) ? false : p1_setup(c, p0, h_matrices, matrix_count, Y, table_ok);   // deferred pixels are parked as (x | y << 16)
-    // gfw_hot_kernel: certified second pass + integer-dot taps for the production configuration
-    Y.hot = 0;
-    if (table_ok && c->p2_ok && !extras && (c->kernel_variant == 5 || c->kernel_variant == 6) && p0.interpolation == 2 &&
-        (bytes_per_sample == 1 || bytes_per_sample == 2) && n0 == 1 && dw == 2 && (dh == 1 || dh == 2) &&
-        nplanes == (interleaved ? 2 : 3) && p0.background_mode == 0 && !Y.k_all_zero && p0.f[0] > 0.0f && p0.f[1] > 0.0f &&
-        (matrix_count <= 1 || fast1)) {
-        const uintptr_t pair = 2u * (uintptr_t)bytes_per_sample;                 // the lane's two luma pixels / one UV pair are stored as one word
-        bool aligned = ((uintptr_t)launches[0].dst % pair) == 0 && (planes[0].output.stride % (int)pair) == 0;
-        if (interleaved) aligned = aligned && ((uintptr_t)launches[1].dst % pair) == 0 && (planes[1].output.stride % (int)pair) == 0 &&
-                                   ((uintptr_t)launches[1].src % pair) == 0 && (params[1].stride % (int)pair) == 0;
-        if (aligned) { Y.hot = 1; Y.p2_kappa = (float)c->p2_kappa; }
-    }
-    const int rb = gfw_yuv_rows_per_lane(fast1 || Y.hot, Y.audit ? 0 : c->tune_rb);
+    const int rb = gfw_yuv_rows_per_lane(fast1, Y.audit ? 0 : c->tune_rb);
     Y.tiles_x = (Y.cw + 63) / 64; Y.tiles_y = (Y.ch + 4 * rb - 1) / (4 * rb);
     return true;
 }
 
+// Frames of one gfw_undistort_clip call waiting to go out in one launch of the specialised kernel.
+struct ClipBatch {
+    GfwClipArgs CA;
+    hipFunction_t fn = nullptr;
+    int grid = 0, n = 0;
+};
+static int clip_flush(gfw_ctx *c, ClipBatch *b) {
+    if (!b || b->n == 0) return GFW_OK;
+    b->CA.n_frames = b->n; b->CA.pad_ = 0;
+    prof_begin(c);
+    const hipError_t e = gfw_jit_launch(b->fn, b->CA, b->grid, c->stream);
+    prof_end(c, b->n);
+    b->n = 0;
+    if (e != hipSuccess) { set_error("clip launch failed: %s", hipGetErrorString(e)); return GFW_ERR_HIP; }
+    return GFW_OK;
+}
+
+// ---- run-time specialisation (gfw_jit.hip) ----------------------------------------------------------------------------------------
+// The bake header: every clip-invariant field of the fused kernel's argument block as a literal, GFW_BK_<field> (floats by bit
+// pattern; gfw_frame.hip reads them through AF()).  What stays
+// an argument: plane pointers and lengths, the matrix table, the first-pass table and its three range constants (the table may be
+// rebuilt mid-clip), the grid.  Two frames with the same header run the same specialised kernel.
+static void bake_f(std::string &o, const char *name, float v) {
+    uint32_t u; memcpy(&u, &v, 4);
+    char b[128]; snprintf(b, sizeof(b), "#define GFW_BK_%s __builtin_bit_cast(float, 0x%08xu)\n", name, u); o += b;
+}
+static void bake_i(std::string &o, const char *name, long long v) { char b[128]; snprintf(b, sizeof(b), "#define GFW_BK_%s (%lld)\n", name, v); o += b; }
+static std::string bake_header(const GfwYuvArgs &Y) {
+    std::string o;
+    o.reserve(4096);
+    bake_i(o, "nplanes", Y.nplanes); bake_i(o, "width", Y.width); bake_i(o, "height", Y.height); bake_i(o, "out_w", Y.out_w); bake_i(o, "out_h", Y.out_h);
+    bake_i(o, "cw", Y.cw); bake_i(o, "ch", Y.ch); bake_i(o, "tiles_x", Y.tiles_x); bake_i(o, "tiles_y", Y.tiles_y); bake_i(o, "matrix_count", Y.matrix_count);
+    bake_i(o, "hrs", Y.hrs); bake_i(o, "model", Y.model); bake_i(o, "k_all_zero", Y.k_all_zero);
+    bake_i(o, "background_mode", Y.background_mode); bake_i(o, "extras", Y.extras); bake_i(o, "ablate", 0);
+    o += "#define GFW_BK_audit ((unsigned long long *)nullptr)\n";
+    char nm[48];
+    for (int i = 0; i < 2; ++i) { snprintf(nm, sizeof(nm), "f_%d", i); bake_f(o, nm, Y.f[i]); snprintf(nm, sizeof(nm), "c_%d", i); bake_f(o, nm, Y.c[i]);
+                                  snprintf(nm, sizeof(nm), "t2_%d", i); bake_f(o, nm, Y.t2[i]); }
+    for (int i = 0; i < 4; ++i) { snprintf(nm, sizeof(nm), "k_%d", i); bake_f(o, nm, Y.k[i]); }
+    bake_f(o, "r_limit_sq", Y.r_limit_sq);
+    const GfwMapConst *maps[4] = {&Y.map_lx, &Y.map_ly, &Y.map_cx, &Y.map_cy};
+    const char *mn[4] = {"map_lx", "map_ly", "map_cx", "map_cy"};
+    for (int i = 0; i < 4; ++i) {
+        snprintf(nm, sizeof(nm), "%s_mul", mn[i]); bake_f(o, nm, maps[i]->mul);
+        snprintf(nm, sizeof(nm), "%s_den", mn[i]); bake_f(o, nm, maps[i]->den);
+        snprintf(nm, sizeof(nm), "%s_rcp", mn[i]); bake_f(o, nm, maps[i]->rcp);
+    }
+    bake_f(o, "p1_f", Y.p1_f); bake_f(o, "p1_c", Y.p1_c);
+    for (int i = 0; i < 4; ++i) {
+        const GfwYuvPlane &P = Y.pl[i];
+        snprintf(nm, sizeof(nm), "pl%d_src_stride", i); bake_i(o, nm, P.src_stride);
+        snprintf(nm, sizeof(nm), "pl%d_dst_stride", i); bake_i(o, nm, P.dst_stride);
+        snprintf(nm, sizeof(nm), "pl%d_w", i); bake_i(o, nm, P.w);
+        snprintf(nm, sizeof(nm), "pl%d_h", i); bake_i(o, nm, P.h);
+        for (int ch = 0; ch < 4; ++ch) { snprintf(nm, sizeof(nm), "pl%d_bg_%d", i, ch); bake_f(o, nm, P.bg[ch]); }
+        snprintf(nm, sizeof(nm), "pl%d_limit", i); bake_f(o, nm, P.limit);
+    }
+    return o;
+}
+// Waves per SIMD the specialised instantiation is budgeted for (measured on C2: 6 -> 72.8, 7 -> 67.3, 8 -> 70.5 us with the table atanf)
+static int jit_waves(int taps) { return taps == 2 ? 7 : 6; }
+// The specialised kernel for this frame's arguments, or nullptr (not eligible / not wanted / not ready / failed): the caller then
+// launches the ahead-of-time kernel.
+static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps, int n0, int dw, int dh, bool interleaved, bool fast1, int *grid) {
+    if (c->jit_mode == 0 || c->kernel_variant != 0 || Y.model != GFW_MODEL_OPENCV_FISHEYE || Y.extras || Y.audit || Y.ablate) return nullptr;
+    if (!gfw_jit_available()) { c->jit_info.state = GFW_JIT_UNAVAILABLE; c->jit_info.log = "libhiprtc.so not found"; return nullptr; }
+    std::string hdr = bake_header(Y);
+    if (hdr == c->jit_header) { if (c->jit_seen < (1 << 30)) ++c->jit_seen; }
+    else { c->jit_header.swap(hdr); c->jit_seen = 1; }
+    if (c->jit_mode == 1 && c->jit_seen < gfw_ctx::kJitAfter) return nullptr;          // one or two frames are not a clip
+    const int waves = jit_waves(taps);
+    char b[64];
+    std::vector<std::string> defs;
+    snprintf(b, sizeof(b), "GFW_FRAME_KIND=%d", bps); defs.push_back(b);
+    snprintf(b, sizeof(b), "GFW_FRAME_TAPS=%d", taps); defs.push_back(b);
+    snprintf(b, sizeof(b), "GFW_JIT_WAVES=%d", waves); defs.push_back(b);
+    defs.push_back("GFW_JIT_MODEL=1");
+    defs.push_back(bps == 1 ? "GFW_JIT_T=uint8_t" : bps == 2 ? "GFW_JIT_T=uint16_t" : "GFW_JIT_T=float");
+    snprintf(b, sizeof(b), "GFW_JIT_N0=%d", n0); defs.push_back(b);
+    snprintf(b, sizeof(b), "GFW_JIT_DW=%d", dw); defs.push_back(b);
+    snprintf(b, sizeof(b), "GFW_JIT_DH=%d", dh); defs.push_back(b);
+    snprintf(b, sizeof(b), "GFW_JIT_IL=%d", interleaved ? 1 : 0); defs.push_back(b);
+    snprintf(b, sizeof(b), "GFW_JIT_RB=%d", gfw_yuv_rows_per_lane(fast1, 0)); defs.push_back(b);
+    snprintf(b, sizeof(b), "GFW_JIT_FAST1=%d", fast1 ? 1 : 0); defs.push_back(b);
+    hipFunction_t fn = gfw_jit_get(c->device, c->arch, defs, c->jit_header, c->jit_mode == 2, &c->jit_info);
+    if (!fn) return nullptr;
+    int g = c->tune_grid > 0 ? c->tune_grid : c->num_cus * waves;
+    const int per_xcd = (Y.tiles_x * Y.tiles_y + 7) >> 3;
+    if (g > per_xcd * 8) g = per_xcd * 8;
+    *grid = (g + 7) & ~7;
+    return fn;
+}
+
 static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params, const int *pixel_types,
-                      const float *matrices, int matrix_count, const float *mesh, size_t mesh_len) {
+                      const float *matrices, int matrix_count, const float *mesh, size_t mesh_len, ClipBatch *batch = nullptr) {
     if (!c) { set_error("null context"); return GFW_ERR_INVALID_ARGUMENT; }
     if (nplanes < 1 || nplanes > 8) { set_error("nplanes %d", nplanes); return GFW_ERR_INVALID_ARGUMENT; }
     HIP_TRY(select_device(c->device), GFW_ERR_HIP);
@@ -834,13 +891,41 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
     int bps = 0, n0 = 1, dw = 1, dh = 1; bool interleaved = false, fast1 = false;
     const bool fused = build_yuv_args(c, nplanes, planes, params, pixel_types, launches, c->matrices_on_device ? nullptr : matrices,
                                       matrix_count, mesh_len, Y, bps, n0, dw, dh, interleaved, fast1);
-    prof_begin(c);
     if (fused) {
         fill_common(c, &params[0], d_mat, (Y.extras & 32) ? d_mesh : nullptr, (Y.extras & 32) ? (int)mesh_len : 0, Y.common);
         Y.matrices = d_mat;
-        HIP_TRY(gfw_launch_yuv(Y, bps, params[0].interpolation, n0, dw, dh, interleaved, fast1, c->stream), GFW_ERR_HIP);
-        c->last_backend = Y.hot ? (fast1 ? "yuv_fused_p1_c2" : "yuv_fused_c2") : (fast1 ? "yuv_fused_p1" : "yuv_fused");
+        int jgrid = 0;
+        hipFunction_t jf = jit_for(c, Y, bps, params[0].interpolation, n0, dw, dh, interleaved, fast1, &jgrid);
+        bool all_device = c->matrices_on_device != 0;
+        for (int i = 0; i < nplanes; ++i) all_device = all_device && planes[i].input.kind != GFW_BUF_HOST && planes[i].output.kind != GFW_BUF_HOST;
+        if (jf && batch && all_device) {
+            // the frame joins the clip launch being assembled; a frame that does not share the pending ones' kernel or first-pass table goes out behind them
+            if (batch->n > 0 && (batch->fn != jf || batch->CA.Y.p1_table != Y.p1_table || batch->CA.Y.p1_rho_max != Y.p1_rho_max ||
+                                 batch->CA.Y.p1_rho_scale != Y.p1_rho_scale || batch->CA.Y.p1_eps != Y.p1_eps)) {
+                const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc;
+            }
+            if (batch->n == 0) { batch->CA.Y = Y; batch->fn = jf; batch->grid = jgrid; }
+            GfwFrameDyn &F = batch->CA.fr[batch->n++];
+            for (int i = 0; i < 4; ++i) { F.src[i] = Y.pl[i].src; F.dst[i] = Y.pl[i].dst; }
+            F.matrices = Y.matrices;
+            c->last_backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit";
+            if (batch->n == GFW_CLIP_MAX) { const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc; }
+            return GFW_OK;
+        }
+        if (batch) { const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc; }
+        prof_begin(c);
+        if (jf) {
+            GfwClipArgs CA;
+            CA.Y = Y; CA.n_frames = 1; CA.pad_ = 0;
+            HIP_TRY(gfw_jit_launch(jf, CA, jgrid, c->stream), GFW_ERR_HIP);
+            c->last_backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit";
+        } else {
+            HIP_TRY(gfw_launch_yuv(Y, bps, params[0].interpolation, n0, dw, dh, interleaved, fast1, c->stream), GFW_ERR_HIP);
+            c->last_backend = fast1 ? "yuv_fused_p1" : "yuv_fused";
+        }
     } else {
+        if (batch) { const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc; }
+        prof_begin(c);
         for (int i = 0; i < nplanes; ++i) {
             fill_common(c, &params[i], d_mat, d_mesh, (int)mesh_len, C);
             HIP_TRY(gfw_launch_plane(launches[i], C, c->stream), GFW_ERR_HIP);
@@ -883,6 +968,22 @@ int gfw_undistort_frame(gfw_ctx *c, int nplanes, const gfw_buffers *planes, cons
     return run_planes(c, nplanes, planes, params, pixel_types, matrices, matrix_count, mesh, mesh_len);
 }
 
+int gfw_undistort_clip(gfw_ctx *c, int n_frames, int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params,
+                       const int *pixel_types, const float *const *matrices, int matrix_count) {
+    if (!c) { set_error("null context"); return GFW_ERR_INVALID_ARGUMENT; }
+    if (n_frames < 0 || !planes || !params || !pixel_types || !matrices) { set_error("null clip arrays"); return GFW_ERR_INVALID_ARGUMENT; }
+    for (int i = 0; i < nplanes; ++i)
+        if (pixel_types[i] < 0 || pixel_types[i] >= GFW_PIX_COUNT) { set_error("plane %d: unknown pixel type %d", i, pixel_types[i]); return GFW_ERR_INVALID_ARGUMENT; }
+    // the frame loop of a render (rendering/mod.rs:487-547 calls process_pixels once per frame), here on the library side: frames that
+    // share the specialised kernel leave in launches of up to GFW_CLIP_MAX frames, everything else exactly as gfw_undistort_frame
+    ClipBatch batch;
+    for (int f = 0; f < n_frames; ++f) {
+        const int rc = run_planes(c, nplanes, planes + (size_t)f * nplanes, params, pixel_types, matrices[f], matrix_count, nullptr, 0, &batch);
+        if (rc != GFW_OK) { (void)clip_flush(c, &batch); return rc; }
+    }
+    return clip_flush(c, &batch);
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------ test hooks
@@ -919,6 +1020,24 @@ long long gfw_debug_selftest(int test, unsigned long long n, unsigned long long 
 // Verification helper of the frame-sharded clip run ("8 B checksum per frame"): adds the sum of the
 // buffer's u64 words (mod 2^64) to *d_out, in order on the context's stream.  `bytes` must be a multiple of 8 and the
 // buffer 16-byte aligned; d_out is a device pointer the caller zeroed.
+// Host-side build check of the run-time specialisation path (no device involved): compiles the embedded kernel source for `arch`
+// with the given ';'-separated -D definitions and bake header; returns the code object's size (optionally written to `out_path`).
+extern "C" long gfw_debug_jit_compile(const char *arch, const char *defines, const char *bake_header_text, const char *out_path, char *log, size_t cap) {
+    if (!arch || !defines || !bake_header_text) return GFW_ERR_INVALID_ARGUMENT;
+    std::vector<std::string> defs;
+    std::string cur;
+    for (const char *p = defines; ; ++p) {
+        if (*p == ';' || *p == 0) { if (!cur.empty()) defs.push_back(cur); cur.clear(); if (!*p) break; }
+        else cur += *p;
+    }
+    std::string lg;
+    std::vector<char> code;
+    const long n = gfw_jit_compile_only(arch, defs, bake_header_text, lg, &code);
+    if (log && cap) snprintf(log, cap, "%s", lg.c_str());
+    if (n > 0 && out_path && *out_path) { if (FILE *f = fopen(out_path, "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); } }
+    return n;
+}
+
 extern "C" int gfw_checksum64(gfw_ctx *c, const void *d_buf, size_t bytes, unsigned long long *d_out) {
     if (!c || !d_buf || !d_out || (bytes & 7) || ((uintptr_t)d_buf & 15)) { set_error("bad checksum arguments"); return GFW_ERR_INVALID_ARGUMENT; }
     HIP_TRY(gfw_launch_checksum64(d_buf, bytes, d_out, c->stream), GFW_ERR_HIP);

@@ -1,6 +1,8 @@
 // gfw_frame.h — argument block + launcher of the fused YUV frame kernel (gfw_frame.hip)
 #pragma once
+#if !defined(GFW_JIT) || !GFW_JIT
 #include <hip/hip_runtime.h>
+#endif
 #include "gfw_warp.h"
 #include "gfw_fastmath.h"
 
@@ -15,7 +17,7 @@ struct GfwYuvPlane {
     int32_t pad_;
 };
 
-#define GFW_P1_TABLE_N 8192      // intervals of the s(rho) table shared by the certified first and second passes (64 KB)
+#define GFW_P1_TABLE_N 8192      // intervals of the s(rho) table of the certified first pass (64 KB)
 #define GFW_YUV_RB_FAST 4         // luma block rows per lane with the certified first pass (tile = 64 x 16 lanes-rows)
 #define GFW_YUV_RB_EXACT 1
 
@@ -50,13 +52,18 @@ struct GfwYuvArgs {
     float p1_rho_max, p1_rho_scale;   // scale = N / rho_max
     float p1_eps;                     // E: bound on |approx - exact| of the projected row/column coordinate, pixels
     float p1_f, p1_c;                 // f[1], c[1] (f[0], c[0] for horizontal rolling shutter)
-    float p2_kappa;                   // certified second pass (gfw_hot_kernel): relative bound on |s~ - s_ref|
-    int32_t hot;                      // 1: launch gfw_hot_kernel (certified second pass + integer-dot taps)
     unsigned long long *audit;        // nullptr, or 8 words: certified, certified-but-wrong, queued, queue-overflow, max |approx-exact| (f32 bits),
                                       // [5] global addresses outside their buffer (audit mode range-checks every tap, store, matrix row and table entry)
     gfw_kernel_params kp;             // plane-0 params, for the non-specialised lens models
     GfwCommon common;
 };
 
+// Several frames of one clip in one launch (run-time-specialised kernel only): everything but these pointers is shared.
+#define GFW_CLIP_MAX 8
+struct GfwFrameDyn { const uint8_t *src[4]; uint8_t *dst[4]; const float *matrices; };
+struct GfwClipArgs { GfwYuvArgs Y; int32_t n_frames; int32_t pad_; GfwFrameDyn fr[GFW_CLIP_MAX]; };
+
+#if !defined(GFW_JIT) || !GFW_JIT
 int gfw_yuv_rows_per_lane(bool fast1, int tune_rb);
 hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int sample_kind, int taps, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s);
+#endif

@@ -1,0 +1,165 @@
+// gfw_jit.hip — per-clip specialisation of the fused frame kernel at run time.
+//
+// The reference compiles its OpenCL kernel per clip with the clip's constants substituted into the source
+// (src/core/gpu/opencl.rs:181-214: lens model functions, pixel type, interpolation, flags folded to true/false).  The MI355X
+// equivalent: gfw_frame.hip is embedded in the library as one amalgamated source text (tools/gen_jit_source.py, a build step) and
+// compiled by hiprtc into ONE instantiation whose clip-invariant arguments (lens, sizes, strides, map constants, flags) are
+// literals — GFW_BAKE_APPLY in the bake header gfw_api.hip generates.  Loads, uniform branches and the scalar registers they pin
+// disappear: 78.9 -> 67.3 us per 4K C2 frame on MI355X, bit-identical output (profiles/r03_ab_bake.txt).
+//
+// The ahead-of-time kernels remain the product's floor: a context warps with them until the specialised kernel is ready, and for
+// good if hiprtc is missing or the build fails (gfw_jit_status reports which).  Compilation runs on a worker thread (it needs no
+// device); the module is loaded by the first launch that finds the code object ready.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <atomic>
+#include <chrono>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "gfw_jit.h"
+#include "gfw_jit_source.inc"          // GFW_JIT_SOURCE (generated into the build directory)
+
+namespace {
+
+// hiprtc through dlopen: libgfwarp must load (and serve every frame ahead-of-time) on a box without it
+typedef struct _hiprtcProgram *rtcProgram;
+struct Rtc {
+    void *lib = nullptr;
+    int (*create)(rtcProgram *, const char *, const char *, int, const char **, const char **) = nullptr;
+    int (*compile)(rtcProgram, int, const char **) = nullptr;
+    int (*log_size)(rtcProgram, size_t *) = nullptr;
+    int (*log)(rtcProgram, char *) = nullptr;
+    int (*code_size)(rtcProgram, size_t *) = nullptr;
+    int (*code)(rtcProgram, char *) = nullptr;
+    int (*destroy)(rtcProgram *) = nullptr;
+    bool ok = false;
+    Rtc() {
+        for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6", "/opt/rocm/lib/libhiprtc.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) return;
+#define GFW_RTC_SYM(field, sym) field = reinterpret_cast<decltype(field)>(dlsym(lib, sym))
+        GFW_RTC_SYM(create, "hiprtcCreateProgram"); GFW_RTC_SYM(compile, "hiprtcCompileProgram");
+        GFW_RTC_SYM(log_size, "hiprtcGetProgramLogSize"); GFW_RTC_SYM(log, "hiprtcGetProgramLog");
+        GFW_RTC_SYM(code_size, "hiprtcGetCodeSize"); GFW_RTC_SYM(code, "hiprtcGetCode"); GFW_RTC_SYM(destroy, "hiprtcDestroyProgram");
+#undef GFW_RTC_SYM
+        ok = create && compile && log_size && log && code_size && code && destroy;
+    }
+};
+Rtc &rtc() { static Rtc r; return r; }
+
+enum { ST_COMPILING = 1, ST_COMPILED = 2, ST_LOADED = 3, ST_FAILED = -1 };
+
+struct Entry {
+    std::atomic<int> state{ST_COMPILING};
+    std::vector<char> code;
+    std::string log;
+    double compile_ms = 0.0;
+    std::thread worker;
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    ~Entry() { if (worker.joinable()) worker.join(); }
+};
+
+std::mutex g_mu;
+std::map<std::string, std::shared_ptr<Entry>> g_cache;       // key: device | arch | options | bake header
+
+void compile_entry(Entry *e, std::string source, std::vector<std::string> opts) {
+    const auto t0 = std::chrono::steady_clock::now();
+    Rtc &R = rtc();
+    rtcProgram prog = nullptr;
+    int rc = R.create(&prog, source.c_str(), "gfw_jit.hip", 0, nullptr, nullptr);
+    if (rc == 0) {
+        std::vector<const char *> o;
+        for (const std::string &s : opts) o.push_back(s.c_str());
+        rc = R.compile(prog, (int)o.size(), o.data());
+        size_t ls = 0;
+        if (R.log_size(prog, &ls) == 0 && ls > 1) { e->log.resize(ls); (void)R.log(prog, &e->log[0]); }
+        size_t cs = 0;
+        if (rc == 0 && R.code_size(prog, &cs) == 0 && cs > 0) { e->code.resize(cs); rc = R.code(prog, e->code.data()); }
+        else if (rc == 0) rc = -1;
+        (void)R.destroy(&prog);
+    }
+    e->compile_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rc != 0 && e->log.empty()) e->log = "hiprtc error " + std::to_string(rc);
+    e->state.store(rc == 0 ? ST_COMPILED : ST_FAILED, std::memory_order_release);
+}
+
+}  // namespace
+
+bool gfw_jit_available() { return rtc().ok; }
+
+// State of the specialised kernel for (device, options, header): starts the build on first sight.  wait: block until it is decided.
+// Returns the function once loaded on `device` (which must be the calling thread's current device), nullptr otherwise.
+hipFunction_t gfw_jit_get(int device, const std::string &arch, const std::vector<std::string> &defines, const std::string &bake_header,
+                          bool wait, GfwJitInfo *info) {
+    if (info) { info->state = GFW_JIT_UNAVAILABLE; info->compile_ms = 0.0; info->log.clear(); }
+    if (!rtc().ok) { if (info) info->log = "libhiprtc.so not found"; return nullptr; }
+    std::string key = std::to_string(device) + "|" + arch;
+    for (const std::string &d : defines) key += "|" + d;
+    key += "|" + bake_header;
+    std::shared_ptr<Entry> e;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_cache.find(key);
+        if (it == g_cache.end()) {
+            e = std::make_shared<Entry>();
+            std::vector<std::string> opts = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed",
+                                             "-Wno-cuda-compat", "-DGFW_JIT=1", "-DGFW_BAKE=1"};
+            for (const std::string &d : defines) opts.push_back("-D" + d);
+            std::string source = bake_header + "\n" + GFW_JIT_SOURCE;
+            e->worker = std::thread(compile_entry, e.get(), std::move(source), std::move(opts));
+            g_cache.emplace(key, e);
+        } else e = it->second;
+    }
+    if (wait && e->state.load(std::memory_order_acquire) == ST_COMPILING) {
+        std::lock_guard<std::mutex> lk(g_mu);            // one joiner
+        if (e->worker.joinable()) e->worker.join();
+    }
+    int st = e->state.load(std::memory_order_acquire);
+    if (st == ST_COMPILED) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (e->state.load() == ST_COMPILED) {
+            if (e->worker.joinable()) e->worker.join();
+            hipError_t err = hipModuleLoadData(&e->mod, e->code.data());
+            if (err == hipSuccess) err = hipModuleGetFunction(&e->fn, e->mod, "gfw_jit_kernel");
+            if (err != hipSuccess) { e->log += std::string("\nmodule load: ") + hipGetErrorString(err); e->state.store(ST_FAILED); }
+            else { e->code.clear(); e->code.shrink_to_fit(); e->state.store(ST_LOADED); }
+        }
+        st = e->state.load();
+    }
+    if (info) {
+        info->state = st == ST_LOADED ? GFW_JIT_READY : st == ST_FAILED ? GFW_JIT_FAILED : GFW_JIT_COMPILING;
+        if (st != ST_COMPILING) { info->compile_ms = e->compile_ms; info->log = e->log; }
+    }
+    return st == ST_LOADED ? e->fn : nullptr;
+}
+
+// Build only (no device needed): the code object's size in bytes, or -1 with the compiler's log.  Host-side check of the embedded
+// source and of the toolchain (tests/test_jit_host.py); `code_out` receives the code object when given.
+long gfw_jit_compile_only(const std::string &arch, const std::vector<std::string> &defines, const std::string &bake_header, std::string &log,
+                          std::vector<char> *code_out) {
+    if (!rtc().ok) { log = "libhiprtc.so not found"; return -2; }
+    Entry e;
+    std::vector<std::string> opts = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed", "-Wno-cuda-compat",
+                                     "-DGFW_JIT=1", "-DGFW_BAKE=1"};
+    for (const std::string &d : defines) opts.push_back("-D" + d);
+    compile_entry(&e, bake_header + "\n" + GFW_JIT_SOURCE, opts);
+    log = e.log;
+    if (e.state.load() != ST_COMPILED) return -1;
+    const long n = (long)e.code.size();
+    if (code_out) code_out->swap(e.code);
+    return n;
+}
+
+hipError_t gfw_jit_launch(hipFunction_t fn, const GfwClipArgs &C, int grid, hipStream_t s) {
+    size_t size = sizeof(GfwClipArgs);
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<GfwClipArgs *>(&C), HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 64, 4, 1, 0, s, nullptr, config);
+}

@@ -497,10 +497,9 @@ __device__ inline double bivariate(int n_x, int n_y, double size_x, double size_
 }  // namespace gfw_mesh
 
 // ----------------------------------------------------------------------------
-#if defined(GFW_STAGED_FUSED) && GFW_STAGED_FUSED
 // Sony lens-distortion mesh + focal-plane-distortion terms of rotate_and_distort (cpu_undistort.rs:169-214) on the distorted
-// point (u, v), after `+ c` and before the digital lens, for the fused kernel's staged generic path — a copy of the block inside
-// gfw_rotate_and_distort below (the per-plane kernels keep their validated code byte for byte until the staged path is promoted).
+// point (u, v), after `+ c` and before the digital lens, for the fused kernel's GFW_MODEL_GENERIC_EXTRA instantiation — the same operations as the
+// block inside gfw_rotate_and_distort below (per-plane kernels).
 __device__ __forceinline__ void gfw_mesh_apply(float &u, float &v, const gfw_kernel_params &P, const GfwCommon &C) {
     if (C.mesh_len > 0) {
         const float *md32 = C.mesh;
@@ -542,7 +541,6 @@ __device__ __forceinline__ void gfw_mesh_apply(float &u, float &v, const gfw_ker
         }
     }
 }
-#endif
 
 // rotate_and_distort: cpu_undistort.rs:133-228
 template <int MODEL>

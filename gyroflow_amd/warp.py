@@ -82,6 +82,19 @@ class Backend:
     def set_stream(self, stream_ptr):
         self._check(self.lib.gfw_set_stream(self.ctx, stream_ptr))
 
+    def jit_status(self):
+        """(state, compile milliseconds, compiler log) of the context's run-time specialised kernel; state 0 none / unavailable,
+        1 compiling, 2 ready, 3 failed (gfw_jit_status)."""
+        ms, log = C.c_double(0.0), C.create_string_buffer(4096)
+        st = self.lib.gfw_jit_status(self.ctx, C.byref(ms), log, 4096)
+        return st, ms.value, log.value.decode(errors="replace")
+
+    def get_profile_frames(self, reset=True):
+        """(kernel milliseconds, launches, frames those launches covered) since the last reset (needs OPT_PROFILE)."""
+        ms, n, f = C.c_double(0.0), C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.gfw_get_profile_frames(self.ctx, C.byref(ms), C.byref(n), C.byref(f), 1 if reset else 0))
+        return ms.value, n.value, f.value
+
     def get_profile(self, reset=True):
         """(kernel milliseconds, launches) accumulated since the last reset (needs OPT_PROFILE)."""
         ms, n = C.c_double(0.0), C.c_int64(0)
@@ -96,12 +109,12 @@ class Backend:
         return int(arr[0]), int(arr[1]), int(arr[2]), int(arr[3]), gap
 
     def get_audit_full(self, reset=False):
-        """All audit words by name (first pass + certified second pass + address audit)."""
+        """All audit words by name (first pass + address audit)."""
         arr = (C.c_ulonglong * 8)()
         self._check(self.lib.gfw_get_audit(self.ctx, C.byref(arr), 1 if reset else 0))
         gap = float(np.array([int(arr[4]) & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0])
         return {"certified1": int(arr[0]), "certified1_wrong": int(arr[1]), "queued1": int(arr[2]), "queue_overflow": int(arr[3]),
-                "pass1_gap_px": gap, "out_of_range": int(arr[5]), "certified2": int(arr[6]), "certified2_wrong": int(arr[7])}
+                "pass1_gap_px": gap, "out_of_range": int(arr[5])}
 
     def set_quaternion_tracks(self, org, smoothed):
         """Upload (timestamps_us int64, quaternions f64[n,4]) tracks once per clip (device matrix builder)."""
@@ -267,6 +280,35 @@ class FrameCall:
             self.be._check(rc)
 
 
+class ClipCall:
+    """Pre-marshalled ``gfw_undistort_clip`` call: ``frames`` is a list of per-frame plane lists (``Buffers``), ``matrices`` a list
+    of per-frame tables (device pointers, or numpy [rows][14] arrays), ``params`` / ``pixel_types`` are shared by all frames."""
+
+    def __init__(self, backend, frames, params, pixel_types, matrices, matrix_count=None):
+        nf, n = len(frames), len(frames[0])
+        self.be, self.nf, self.n = backend, nf, n
+        self.barr = (abi.Buffers * (nf * n))(*[b for fr in frames for b in fr])
+        self.parr = (abi.KernelParams * n)(*params)
+        self.tarr = (C.c_int * n)(*[abi.PIXEL_TYPES[t][0] if isinstance(t, str) else t for t in pixel_types])
+        self.keep, ptrs = [], []
+        for m in matrices:
+            if isinstance(m, np.ndarray):
+                m = np.ascontiguousarray(m, dtype=np.float32)
+                self.keep.append(m)
+                ptrs.append(m.ctypes.data)
+                matrix_count = m.shape[0]
+            else:
+                ptrs.append(m)
+        self.marr = (C.c_void_p * nf)(*ptrs)
+        self.mc = matrix_count
+        self.fn = backend.lib.gfw_undistort_clip
+
+    def __call__(self):
+        rc = self.fn(self.be.ctx, self.nf, self.n, self.barr, self.parr, self.tarr, self.marr, self.mc)
+        if rc != 0:
+            self.be._check(rc)
+
+
 def run_plane(src, in_size, dst, out_size, params, pixel_type, model, digital, matrices, mesh=None, **rects):
     """Convenience: create a backend, warp one HOST plane in place into ``dst``."""
     b = host_buffers(src, in_size, dst, out_size, **rects)
@@ -277,11 +319,12 @@ def run_plane(src, in_size, dst, out_size, params, pixel_type, model, digital, m
         be.close()
 
 
-def run_frame(frame, fused=True, per_plane=False, variant=None):
+def run_frame(frame, fused=True, per_plane=False, variant=None, jit=None):
     """Warp every plane of a ``synthetic.SyntheticFrame`` from HOST buffers; returns output copies.
 
     fused=False forces the generic per-plane kernel (GFW_OPT_KERNEL_VARIANT = 1); per_plane=True issues one
-    ``gfw_undistort_image`` per plane, the way the reference's render loop does."""
+    ``gfw_undistort_image`` per plane, the way the reference's render loop does; jit sets GFW_OPT_JIT (2: the frame waits
+    for its run-time specialised kernel)."""
     outs = [pl["dst"].copy() for pl in frame.planes]
     bufs = [host_buffers(pl["src"], pl["size"], o, pl["out_size"]) for pl, o in zip(frame.planes, outs)]
     params = [pl["params"] for pl in frame.planes]
@@ -302,6 +345,8 @@ def run_frame(frame, fused=True, per_plane=False, variant=None):
             be.set_option(abi.OPT_KERNEL_VARIANT, 1)
         elif variant is not None:
             be.set_option(abi.OPT_KERNEL_VARIANT, variant)
+        if jit is not None:
+            be.set_option(abi.OPT_JIT, jit)
         be.undistort_frame(bufs, params, types, frame.matrices)
     finally:
         be.close()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GFW_ABI_VERSION 1
+#define GFW_ABI_VERSION 2
 
 /* ---- KernelParams: byte-exact mirror of stabilization/mod.rs:101-150 ------
  * #[repr(C, packed(4))], 92 four-byte words = 368 bytes. */
@@ -246,6 +246,17 @@ int gfw_undistort_frame(gfw_ctx *ctx, int nplanes,
                         const int *pixel_types,
                         const float *matrices, int matrix_count,
                         const float *mesh, size_t mesh_len);
+/* The frame loop of a render on the library side (the reference drives process_pixels once per frame from
+ * rendering/mod.rs:487-547): n_frames frames of one clip — `planes` holds n_frames * nplanes descriptions, frame-major;
+ * `params` (nplanes entries) and `pixel_types` are shared by all frames; matrices[f] is frame f's table, with the meaning
+ * GFW_OPT_MATRICES_ON_DEVICE gives it.  Frames are warped in order on the context's stream with the results of
+ * gfw_undistort_frame; frames with HIP_DEVICE buffers and device-resident tables that share the context's run-time specialised
+ * kernel (GFW_OPT_JIT) leave in launches of up to 8 frames, so that the occupancy tail of one frame is filled by the next. */
+int gfw_undistort_clip(gfw_ctx *ctx, int n_frames, int nplanes,
+                       const gfw_buffers *planes,
+                       const gfw_kernel_params *params,
+                       const int *pixel_types,
+                       const float *const *matrices, int matrix_count);
 
 /* ---- options / stream ---------------------------------------------------*/
 enum {
@@ -259,13 +270,15 @@ enum {
                                         evaluated on the device with the host libm's own routines (gfw_math.h). */
     GFW_OPT_KERNEL_VARIANT     = 3,  /* 0 auto; 1 generic per-plane kernel; 2 fused kernel with the exact first pass;
                                         3 fused kernel, certified first pass in audit mode (see gfw_get_audit);
-                                        5 experimental gfw_hot_kernel (certified SECOND pass): bit-exact,
-                                        fewer instructions, measured slower than the default on MI355X; 6 = 5 in audit mode;
-                                        7 staging: settings whose fused path is written but not yet through the GPU parity suite
-                                        (background mode 3) run fused instead of per plane */
+                                        16 + bits: timing ablations of the fused kernel (wrong output by design) */
     GFW_OPT_PROFILE            = 4,  /* 1: bracket every warp-kernel launch with hipEvents on the context stream */
     GFW_OPT_TUNE_ROWS          = 5,  /* reserved (ignored) */
-    GFW_OPT_TUNE_GRID          = 6   /* tuning: persistent workgroups of the fused kernel (0 = 6 per CU) */
+    GFW_OPT_TUNE_GRID          = 6,  /* tuning: persistent workgroups of the fused kernel (0 = 6 per CU) */
+    GFW_OPT_JIT                = 7   /* per-clip specialised kernel, compiled at run time the way the reference compiles its OpenCL source per clip
+                                        (opencl.rs:181-214): 0 never; 1 (default) built in the background once the context has warped three
+                                        frames with the same clip constants, frames run ahead-of-time until it is ready; 2 built at the first
+                                        frame, which waits for it (~1 s).  Same results bit for bit; the environment variable GFW_JIT sets
+                                        the default of new contexts.  Without libhiprtc.so the option has no effect. */
 };
 int   gfw_set_option(gfw_ctx *ctx, int option, int64_t value);
 /* hipStream_t the context enqueues on (as void*); caller may substitute its
@@ -278,10 +291,15 @@ int   gfw_synchronize(gfw_ctx *ctx);
 /* Name of the kernel path the last call took ("plane_generic", "yuv_fused", ...):
  * the analogue of ProcessedInfo.backend (stabilization/mod.rs:194-200). */
 const char *gfw_last_backend(gfw_ctx *ctx);
+/* State of the context's run-time specialised kernel: 0 none / not available, 1 compiling, 2 ready (in use), 3 failed (frames keep
+ * running ahead-of-time).  compile_ms and the compiler log (truncated to cap) are optional outputs. */
+int   gfw_jit_status(gfw_ctx *ctx, double *compile_ms, char *log, size_t cap);
 
 /* With GFW_OPT_PROFILE on: accumulated warp-kernel time (ms, hipEventElapsedTime on the context stream)
  * and launch count since the last reset; synchronises the stream.  reset != 0 clears the accumulators. */
 int   gfw_get_profile(gfw_ctx *ctx, double *kernel_ms, int64_t *launches, int reset);
+/* the same, plus the number of frames the bracketed launches covered (a gfw_undistort_clip launch carries up to 8) */
+int   gfw_get_profile_frames(gfw_ctx *ctx, double *kernel_ms, int64_t *launches, int64_t *frames, int reset);
 
 /* Thread-local, human-readable description of the last failure. */
 const char *gfw_last_error(void);
@@ -390,6 +408,10 @@ int   gfw_undistort_points(gfw_ctx *ctx, const gfw_kernel_params *params, const 
  * max |approximate - exact| coordinate over certified pixels as f32 bits, 3 spare}.  Call with reset = 1 before
  * the frames to be audited. */
 int   gfw_get_audit(gfw_ctx *ctx, unsigned long long *counters8, int reset);
+/* Build check of the run-time specialisation path without a device: compiles the kernel source embedded in the library for `arch`
+ * ("gfx950") with ';'-separated definitions and a bake header; returns the code object's size in bytes (written to out_path when
+ * given), -1 on a compile error (log), -2 when libhiprtc.so is absent. */
+long  gfw_debug_jit_compile(const char *arch, const char *defines, const char *bake_header_text, const char *out_path, char *log, size_t cap);
 int   gfw_debug_math(int op, const float *a, const float *b, float *out, size_t n);
 long long gfw_debug_selftest(int test, unsigned long long n, unsigned long long seed);
 

@@ -33,7 +33,7 @@ def test_struct_layouts():
     assert kp.background.offset == 48 and kp.k.offset == 80 and kp.translation2d.offset == 168
     assert kp.source_rect.offset == 192 and kp.digital_lens_params.offset == 224 and kp.max_pixel_value.offset == 304
     assert kp.plane_index.offset == 324 and kp.ewa_coeffs_p.offset == 336
-    assert abi.load_library().gfw_abi_version() == 1
+    assert abi.load_library().gfw_abi_version() == 2
 
 
 def test_pixel_type_table_matches_reference_pixel_formats():

@@ -37,13 +37,25 @@ def test_driver_command_line():
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["launches"] >= 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert rf["algorithmic_bytes_per_launch"] == 66355200
+    # the steps leave as clip launches of the run-time specialised kernel (20 steps = calls of 8, 8 and 4 frames; every other launch bracketed)
+    assert out["config"]["jit"]["state"] == "ready" and out["config"]["backend"].endswith("_jit"), out["config"]
+    assert out["config"]["clip_frames_per_call"] == 8 and rf["frames_per_launch"] == 6.0, rf
+    assert rf["algorithmic_bytes_per_launch"] == 66355200 * 6
+    assert abs(rf["kernel_ms_per_frame"] * rf["frames_per_launch"] - rf["kernel_ms_per_launch"]) < 1e-3
+    assert out["config"]["preheat_ms"] >= 50.0
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert out["ms_per_step"] * out["steps"] / 1e3 < wall
     assert out["launcher"]["attempts"] == 1 and out["launcher"]["failures"] == []
     # the value is consistent with the step time
     assert abs(out["value"] - 3840 * 2160 / (out["ms_per_step"] * 1e-3) / 1e6) / out["value"] < 1e-3
+
+
+def test_ahead_of_time_kernels_frame_by_frame():
+    out, _ = run_bench(["--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--jit", "0", "--clip", "1"])
+    assert out["config"]["backend"] == "yuv_fused_p1" and out["config"]["jit"]["state"] == "none"
+    assert out["config"]["parity_vs_oracle"] == "bit-exact"
+    assert out["roofline"]["algorithmic_bytes_per_launch"] == 66355200 and out["roofline"]["frames_per_launch"] == 1.0
 
 
 def test_torchrun_style_environment_single_rank():

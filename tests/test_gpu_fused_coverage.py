@@ -1,34 +1,24 @@
-"""STAGING AREA — fused-kernel paths that are written but have not been through the GPU parity suite yet.
-
-The staged paths exist only in a library built with GFW_STAGED_FUSED=1 (`GFW_STAGED_FUSED=1 python -c "import __graft_entry__ as g;
-g.build_gfwarp(force=True)"`) and are taken only with GFW_OPT_KERNEL_VARIANT = 7; the shipped binary does not contain them (inside
-the generic-model instantiation they would cost its other users registers and scratch).  Run on the GPU box with
-`python -m pytest tests -m gpu_staged`; `-m gpu` (what the round-end driver runs) does not select these, and without a GPU or
-without a staging build they are skipped.  A test moves into the regular `-m gpu` files once it has passed there.
-
-Staged: background mode 3 "margin with feather" (cpu_undistort.rs:576-613) and the Sony mesh / focal-plane-distortion terms
-(:169-214) through the fused kernel's generic-model instantiation
-(two samples per plane + alpha blend; today the per-plane kernel serves it, bit-exact).
-"""
+"""Fused-kernel coverage of background mode 3 "margin with feather" (cpu_undistort.rs:576-613) and of the Sony lens-distortion mesh /
+focal-plane-distortion terms (:169-214): both run through the fused kernel's GFW_MODEL_GENERIC_EXTRA instantiation (two samples per
+plane + alpha blend; f64 mesh spline) and through the per-plane kernel, and both must equal the oracle bit for bit.  (Validated on
+MI355X in round 3 as a staging build — 31 / 31 — and promoted: gpurun_out/r03b/staged.log.)"""
 import pytest
 
 from gyroflow_amd import synthetic as S, warp
 import _oracle as O
 from test_gpu_parity import assert_plane_equal
 
-pytestmark = pytest.mark.gpu_staged
+pytestmark = pytest.mark.gpu
 
-STAGING_VARIANT = 7
 
 
 def check_staged(fr):
     ref = O.run_frame(fr)
-    got = warp.run_frame(fr, variant=STAGING_VARIANT)
-    if warp.last_backend() != "yuv_fused":
-        pytest.skip("libgfwarp.so built without GFW_STAGED_FUSED=1")
+    got = warp.run_frame(fr)
+    assert warp.last_backend() == "yuv_fused"
     for i, (a, b) in enumerate(zip(ref, got)):
         assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "fused background mode 3, plane %d" % i)
-    base = warp.run_frame(fr)                                     # the default route is untouched
+    base = warp.run_frame(fr, fused=False)                        # the per-plane kernel
     assert warp.last_backend() == "plane_generic"
     for i, (a, b) in enumerate(zip(ref, base)):
         assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "per-plane background mode 3, plane %d" % i)
@@ -88,12 +78,11 @@ def test_sony_mesh_and_focal_plane_distortion_fused(fmt, with_mesh, with_fpd, in
         dst = pl["dst"].copy()
         assert O.undistort_image(pl["src"], pl["size"], dst, pl["out_size"], pl["params"], pl["pixel_type"], fr.model, fr.digital, fr.matrices, mesh=mesh) == 1
         ref.append(dst)
-    got = run_frame_with_mesh(fr, mesh, STAGING_VARIANT)
-    if warp.last_backend() != "yuv_fused":
-        pytest.skip("libgfwarp.so built without GFW_STAGED_FUSED=1")
+    got = run_frame_with_mesh(fr, mesh, 0)
+    assert warp.last_backend() == "yuv_fused"
     for i, (a, b) in enumerate(zip(ref, got)):
         assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "fused mesh, plane %d" % i)
-    base = run_frame_with_mesh(fr, mesh, 0)                      # default route: per-plane kernel
+    base = run_frame_with_mesh(fr, mesh, 1)                      # forced per-plane kernel
     assert warp.last_backend() == "plane_generic"
     for i, (a, b) in enumerate(zip(ref, base)):
         assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "per-plane mesh, plane %d" % i)

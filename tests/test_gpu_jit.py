@@ -1,0 +1,146 @@
+"""The run-time specialised kernel (gfw_jit.hip: the fused kernel compiled per clip by hiprtc with the clip's constants baked in, the
+way the reference compiles its OpenCL source per clip, opencl.rs:181-214) and the clip entry point built on it: same bits as the
+oracle and as the ahead-of-time kernels, through every template family it can be asked for; the asynchronous hand-over; the
+multi-frame launches of gfw_undistort_clip."""
+import time
+
+import numpy as np
+import pytest
+
+from gyroflow_amd import abi, synthetic as S, warp
+import _oracle as O
+from test_gpu_parity import assert_plane_equal
+from test_gpu_fullsize import _View
+
+pytestmark = pytest.mark.gpu
+
+
+def check_jit(fr, what):
+    ref = O.run_frame(fr)
+    got = warp.run_frame(fr, jit=2)
+    assert warp.last_backend().endswith("_jit"), (what, warp.last_backend())
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "%s: specialised kernel, plane %d" % (what, i))
+    aot = warp.run_frame(fr, jit=0)
+    assert not warp.last_backend().endswith("_jit")
+    for i, (a, b) in enumerate(zip(ref, aot)):
+        assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "%s: ahead-of-time kernel, plane %d" % (what, i))
+
+
+@pytest.mark.parametrize("fmt", ["NV12", "P010", "P210", "YUV420P", "YUV420P10LE", "YUV422P16LE", "YUV444P16LE", "GBRAPF32LE", "RGBA", "RGBA64", "RGBAF32"])
+def test_formats(fmt):
+    check_jit(S.SyntheticFrame(fmt, 320, 192, seed=11), fmt)
+
+
+@pytest.mark.parametrize("interp", [2, 4, 8])
+@pytest.mark.parametrize("bg", [0, 1, 2])
+def test_samplers_and_background_modes(interp, bg):
+    fr = S.SyntheticFrame("YUV422P16LE", 322, 190, seed=40 + interp + bg, fov=2.2, interpolation=interp, base_overrides={"background_mode": bg},
+                          background_rgba=(0.25, 0.5, 0.75, 1.0))
+    check_jit(fr, "interpolation %d background mode %d" % (interp, bg))
+
+
+def test_geometry_variants():
+    check_jit(S.SyntheticFrame("YUV422P16LE", 256, 160, seed=23, readout_ms=0.0), "one matrix")
+    check_jit(S.SyntheticFrame("YUV422P16LE", 256, 160, seed=23, horizontal_rs=True), "horizontal rolling shutter")
+    check_jit(S.SyntheticFrame("NV12", 130, 66, seed=19, fov=3.0), "odd size, zoomed out")
+    lens = S.gopro_style_lens(320, 192)
+    lens["r_limit"] = 0.6
+    check_jit(S.SyntheticFrame("YUV422P16LE", 320, 192, seed=29, lens=lens, fov=1.5), "r_limit")
+    lens = S.gopro_style_lens(320, 192)
+    lens["k"] = [0.0] * 12
+    check_jit(S.SyntheticFrame("YUV422P16LE", 320, 192, seed=31, lens=lens, readout_ms=20.0), "all-zero k")
+    check_jit(S.SyntheticFrame("RGBAF32", 320, 192, seed=33, fov=0.82, base_overrides={"translation2d": (13.25, -7.5)}), "adaptive-zoom crop")
+
+
+def device_clip(frames, jit_mode, use_clip, reps=1):
+    """Frames through HIP_DEVICE buffers and device-resident tables on one context: frame by frame, or gfw_undistort_clip.
+    Returns (backend of the last call, jit status, outputs per frame)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    d_src = [fr.device_planes(dev) for fr in frames]
+    d_dst = [fr.device_outputs(dev) for fr in frames]
+    d_mat = [torch.from_numpy(warp.pack_matrices(fr.matrices)).to(dev) for fr in frames]
+    torch.cuda.synchronize(dev)
+    types = [pl["pixel_type"] for pl in frames[0].planes]
+    params = [pl["params"] for pl in frames[0].planes]
+    bufs = [[warp.device_buffers(d_src[j][p].data_ptr(), d_src[j][p].numel(), pl["size"], d_dst[j][p].data_ptr(), d_dst[j][p].numel(), pl["out_size"])
+             for p, pl in enumerate(fr.planes)] for j, fr in enumerate(frames)]
+    rows = frames[0].matrices.shape[0]
+    be = warp.Backend(params[0], types[0], frames[0].model, frames[0].digital, bufs[0][0])
+    try:
+        be.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        be.set_option(abi.OPT_SYNCHRONOUS, 0)
+        be.set_option(abi.OPT_MATRICES_ON_DEVICE, 2)
+        be.set_option(abi.OPT_JIT, jit_mode)
+        be.set_option(abi.OPT_PROFILE, 1)
+        for _ in range(reps):
+            if use_clip:
+                warp.ClipCall(be, bufs, params, types, [m.data_ptr() for m in d_mat], rows)()
+            else:
+                for j in range(len(frames)):
+                    warp.FrameCall(be, bufs[j], params, types, d_mat[j].data_ptr(), rows)()
+        be.synchronize()
+        backend, status = warp.last_backend(), be.jit_status()
+        prof = be.get_profile_frames()
+    finally:
+        be.close()
+    torch.cuda.synchronize(dev)
+    return backend, status, prof, [[t.cpu().numpy() for t in d_dst[j]] for j in range(len(frames))], [[t.cpu().numpy() for t in d_src[j]] for j in range(len(frames))]
+
+
+@pytest.mark.parametrize("fmt,n", [("YUV422P16LE", 11), ("NV12", 8), ("RGBA64", 3)])
+def test_clip_entry_point_matches_frame_by_frame_and_the_oracle(fmt, n):
+    frames = [S.SyntheticFrame(fmt, 320, 192, seed=0x9F10 + j, timestamp_ms=1000.0 + 33.3 * j, pixels=False) for j in range(n)]
+    backend, status, (ms, launches, covered), outs, srcs = device_clip(frames, 2, True)
+    assert backend.endswith("_jit") and status[0] == 2, (backend, status)
+    assert covered == n and launches == (n + 7) // 8, (launches, covered)          # launches of up to 8 frames
+    _, _, _, outs_fb, _ = device_clip(frames, 0, False)
+    for j, fr in enumerate(frames):
+        ref = O.run_frame(_View(fr, srcs[j]))
+        for p, (a, b, c) in enumerate(zip(ref, outs[j], outs_fb[j])):
+            assert_plane_equal(a, b, fr.planes[p]["pixel_type"], "clip launch, frame %d plane %d" % (j, p))
+            assert_plane_equal(a, c, fr.planes[p]["pixel_type"], "frame by frame, frame %d plane %d" % (j, p))
+
+
+def test_clip_entry_point_without_the_specialised_kernel_runs_frame_by_frame():
+    frames = [S.SyntheticFrame("YUV422P16LE", 320, 192, seed=0x9F10 + j, timestamp_ms=1000.0 + 33.3 * j, pixels=False) for j in range(5)]
+    backend, status, (ms, launches, covered), outs, srcs = device_clip(frames, 0, True)
+    assert backend == "yuv_fused_p1" and launches == 5 and covered == 5
+    for j, fr in enumerate(frames):
+        ref = O.run_frame(_View(fr, srcs[j]))
+        for p, (a, b) in enumerate(zip(ref, outs[j])):
+            assert_plane_equal(a, b, fr.planes[p]["pixel_type"], "frame %d plane %d" % (j, p))
+
+
+def test_background_build_takes_over_mid_clip():
+    """GFW_OPT_JIT = 1 (the default): the first frames run ahead-of-time while the specialised kernel is built on a worker thread;
+    once it is ready the same context switches to it.  Every frame, before and after, is the oracle's."""
+    import torch
+    frames = [S.SyntheticFrame("YUV422P16LE", 384, 216, seed=0x9F10 + 100 + j, timestamp_ms=500.0 + 33.3 * j, pixels=False) for j in range(4)]
+    backend, status, _, outs, srcs = device_clip(frames, 1, False)
+    assert backend in ("yuv_fused_p1", "yuv_fused_p1_jit")
+    # the build was started by the third frame of the clip; wait for the cache to hold it, then run the clip again
+    deadline = time.time() + 60.0
+    while time.time() < deadline:
+        backend2, status2, _, outs2, _ = device_clip(frames, 1, False)
+        if backend2.endswith("_jit"):
+            break
+        time.sleep(0.5)
+    assert backend2 == "yuv_fused_p1_jit" and status2[0] == 2, (backend2, status2)
+    for j, fr in enumerate(frames):
+        ref = O.run_frame(_View(fr, srcs[j]))
+        for p, (a, b, c) in enumerate(zip(ref, outs[j], outs2[j])):
+            assert_plane_equal(a, b, fr.planes[p]["pixel_type"], "before the hand-over, frame %d plane %d" % (j, p))
+            assert_plane_equal(a, c, fr.planes[p]["pixel_type"], "after the hand-over, frame %d plane %d" % (j, p))
+
+
+def test_full_size_c2_clip():
+    frames = [S.SyntheticFrame("YUV422P16LE", 3840, 2160, seed=0x9F10 + j, timestamp_ms=1000.0 + 33.3 * j, pixels=False) for j in (0, 17, 63)]
+    backend, status, (ms, launches, covered), outs, srcs = device_clip(frames, 2, True, reps=2)
+    assert backend == "yuv_fused_p1_jit" and covered == 6 and launches == 2
+    print("C2 clip launch of 3 frames: %.1f us per frame (compile %.0f ms)" % (1e3 * ms / covered, status[1]))
+    for j, fr in enumerate(frames):
+        ref = O.run_frame(_View(fr, srcs[j]))
+        for p, (a, b) in enumerate(zip(ref, outs[j])):
+            assert_plane_equal(a, b, fr.planes[p]["pixel_type"], "frame %d plane %d" % (j, p))

@@ -51,11 +51,6 @@ def check_frame(fr, expect_backend=None):
         assert warp.last_backend() == "yuv_fused"
         for i, (a, b) in enumerate(zip(ref, got3)):
             assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "yuv_fused(exact pass 1) plane %d" % i)
-    if backend.startswith("yuv_fused"):                 # the experimental kernel with the certified second pass, where it applies
-        got5 = warp.run_frame(fr, variant=5)
-        if warp.last_backend().endswith("_c2"):
-            for i, (a, b) in enumerate(zip(ref, got5)):
-                assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "%s plane %d" % (warp.last_backend(), i))
     if backend != "plane_generic":
         got2 = warp.run_frame(fr, fused=False)
         assert warp.last_backend() == "plane_generic"

@@ -18,7 +18,7 @@ def eps_of(fr):
 
 
 def audit(fr, variant=3):
-    """variant 3: the fused kernel's audit instantiation (first pass); 6: gfw_hot_kernel's (first and second pass)."""
+    """variant 3: the fused kernel's audit instantiation (first pass)."""
     outs = [pl["dst"].copy() for pl in fr.planes]
     bufs = [warp.host_buffers(pl["src"], pl["size"], o, pl["out_size"]) for pl, o in zip(fr.planes, outs)]
     params = [pl["params"] for pl in fr.planes]
@@ -30,10 +30,7 @@ def audit(fr, variant=3):
         be.undistort_frame(bufs, params, types, fr.matrices)
         assert warp.last_backend().startswith("yuv_fused_p1")
         full = be.get_audit_full()
-        # certified second pass (gfw_hot_kernel): every accepted pixel's bins were re-derived by the exact projection
-        assert full["certified2_wrong"] == 0 and full["out_of_range"] == 0, full
-        if warp.last_backend().endswith("_c2"):
-            assert full["certified2"] > 0.75 * fr.width * fr.height, full
+        assert full["out_of_range"] == 0, full
         return be.get_audit(), outs
     finally:
         be.close()
@@ -51,11 +48,6 @@ def test_certificates_never_disagree_with_the_exact_row(seed, size):
     assert queued + overflow < 0.15 * total, "certificate rejects too many pixels: %d of %d" % (queued + overflow, total)
     ref = O.run_frame(fr)
     for a, b in zip(ref, outs):
-        assert np.array_equal(a, b)
-    # the experimental kernel: its first-pass counters must tell the same story, and every certified second-pass bin is re-derived exactly
-    (c6, w6, q6, o6, _), outs6 = audit(fr, variant=6)
-    assert warp.last_backend() == "yuv_fused_p1_c2" and w6 == 0 and c6 + q6 + o6 == total
-    for a, b in zip(ref, outs6):
         assert np.array_equal(a, b)
 
 
@@ -100,6 +92,6 @@ def test_all_zero_k_with_rolling_shutter_keeps_the_certified_pass_exact():
         for a, b in zip(ref, outs):
             assert np.array_equal(a, b)
         got = warp.run_frame(fr)
-        assert warp.last_backend() == "yuv_fused_p1"          # all-zero k: the second pass has nothing to certify (no atan in the reference)
+        assert warp.last_backend() == "yuv_fused_p1"
         for a, b in zip(ref, got):
             assert np.array_equal(a, b)

@@ -1,0 +1,52 @@
+"""Host-side check of the run-time specialisation path (gfw_jit.hip): the kernel source embedded in libgfwarp.so compiles with hiprtc
+for gfx950 — no device needed — into one baked instantiation that keeps its register budget."""
+import ctypes as C
+import os
+import sys
+
+import pytest
+
+from gyroflow_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import kernel_resources as KR  # noqa: E402
+
+C2_DEFS = "GFW_FRAME_KIND=2;GFW_FRAME_TAPS=%d;GFW_JIT_WAVES=%d;GFW_JIT_MODEL=1;GFW_JIT_T=uint16_t;GFW_JIT_N0=1;GFW_JIT_DW=2;GFW_JIT_DH=1;GFW_JIT_IL=0;GFW_JIT_RB=4;GFW_JIT_FAST1=1"
+
+
+def compile_c2(tmp_path, taps, waves):
+    lib = abi.load_library()
+    header = open(os.path.join(ROOT, "tools", "bake_c2.h")).read()
+    out = str(tmp_path / "jit.co")
+    log = C.create_string_buffer(1 << 16)
+    n = lib.gfw_debug_jit_compile(b"gfx950", (C2_DEFS % (taps, waves)).encode(), header.encode(), out.encode(), log, len(log))
+    if n == -2:
+        pytest.skip("libhiprtc.so not available")
+    assert n > 0, log.value.decode(errors="replace")[-3000:]
+    ks = [k for k in KR.report(out) if k[".name"] == "gfw_jit_kernel"]
+    assert len(ks) == 1
+    return ks[0]
+
+
+def test_embedded_source_compiles_into_the_c2_instantiation(tmp_path):
+    k = compile_c2(tmp_path, 2, 7)
+    assert k[".vgpr_count"] <= 73 and k[".private_segment_fixed_size"] == 0, k          # seven waves per SIMD, no scratch
+    assert KR.workgroups_per_cu(k) >= 7, KR.workgroups_per_cu(k)
+    # the clip-invariant arguments are literals: far fewer scalar registers than the ahead-of-time kernel's 106
+    assert k[".sgpr_count"] <= 100, k[".sgpr_count"]
+
+
+@pytest.mark.parametrize("taps", [4, 8])
+def test_embedded_source_compiles_for_the_lut_samplers(tmp_path, taps):
+    k = compile_c2(tmp_path, taps, 6)
+    assert k[".vgpr_count"] <= 85 and k[".private_segment_fixed_size"] <= 512, (k[".vgpr_count"], k[".private_segment_fixed_size"])
+
+
+def test_a_broken_bake_header_is_reported_not_fatal(tmp_path):
+    lib = abi.load_library()
+    log = C.create_string_buffer(1 << 14)
+    n = lib.gfw_debug_jit_compile(b"gfx950", (C2_DEFS % (2, 7)).encode(), b"#define GFW_BAKE_APPLY(A) do { A.no_such_field = 1; } while (0)\n", b"", log, len(log))
+    if n == -2:
+        pytest.skip("libhiprtc.so not available")
+    assert n == -1 and b"no_such_field" in log.value

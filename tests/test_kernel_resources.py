@@ -51,14 +51,18 @@ def test_specialised_fisheye_instantiations_keep_six_workgroups_per_cu(kernels, 
     assert KR.workgroups_per_cu(k) >= (4 if dh_lds_limited else 6), (name, KR.workgroups_per_cu(k))
 
 
-def test_generic_model_instantiations_run_three_waves_per_simd(kernels):
-    gen = [k for n, k in kernels.items() if "gfw_yuv_kernelILin1E" in n]
-    assert len(gen) >= 30
-    for k in gen:
-        assert KR.workgroups_per_cu(k) >= 3, (k[".name"], k[".vgpr_count"], k[".group_segment_fixed_size"])
-        assert k[".private_segment_fixed_size"] <= 512, (k[".name"], k[".private_segment_fixed_size"])
-    # only the instantiations the dispatcher can reach are built: the certified first pass exists for the fisheye model alone
-    assert not [k for k in gen if "ELi4ELb1ELb" in k[".name"]]
+def test_generic_model_instantiations_keep_their_register_budget(kernels):
+    """-1: every other lens model / digital lens / refraction / IBIS / blend; -2: the same plus background mode 3 and the Sony mesh."""
+    for tag in ("gfw_yuv_kernelILin1E", "gfw_yuv_kernelILin2E"):
+        gen = [k for n, k in kernels.items() if tag in n]
+        assert len(gen) >= 30, (tag, len(gen))
+        for k in gen:
+            bilinear = "ELi2ELi" in k[".name"].split(tag)[1][:24]
+            assert KR.workgroups_per_cu(k) >= 3, (k[".name"], k[".vgpr_count"], k[".group_segment_fixed_size"])
+            # six waves per SIMD (measured faster on a digital-lens clip) cost the bilinear ones up to ~1.5 KB of scratch per lane
+            assert k[".private_segment_fixed_size"] <= (2048 if bilinear else 640 if tag.endswith("n1E") else 1024), (k[".name"], k[".private_segment_fixed_size"])
+        # only the instantiations the dispatcher can reach are built: the certified first pass exists for the fisheye model alone
+        assert not [k for k in gen if "ELi4ELb1ELb" in k[".name"]]
 
 
 def test_no_kernel_is_left_with_one_wave_per_simd(kernels):

@@ -8,7 +8,7 @@ set -e
 cd /root/repo
 mkdir -p build/variants variants
 HIPCC=/opt/rocm/bin/hipcc
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-result -Wno-pass-failed -Iinclude -DGFW_FRAME_KIND=2 -DGFW_FRAME_TAPS=${GFW_VARIANT_TAPS:-2} -DGFW_HOT_ONLY=$([ -n "$GFW_VARIANT_FULL$GFW_VARIANT_TAPS" ] && echo 0 || echo 1)"
+FLAGS="$GFW_VARIANT_EXTRA --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-result -Wno-pass-failed -Iinclude -DGFW_FRAME_KIND=2 -DGFW_FRAME_TAPS=${GFW_VARIANT_TAPS:-2} -DGFW_HOT_ONLY=$([ -n "$GFW_VARIANT_FULL$GFW_VARIANT_TAPS" ] && echo 0 || echo 1)"
 [ build/variants/stubs.o -nt tools/variant_stubs.cpp ] || $HIPCC --offload-arch=gfx950 -O2 -std=c++17 -fPIC -Iinclude -c tools/variant_stubs.cpp -o build/variants/stubs.o
 build() { name=$1; shift
   $HIPCC $FLAGS "$@" -c gyroflow_amd/csrc/gfw_frame.hip -o build/variants/frame_$name.o 2>build/variants/frame_$name.log || { cat build/variants/frame_$name.log; exit 1; }
