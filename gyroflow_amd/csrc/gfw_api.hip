@@ -810,6 +810,10 @@ static int jit_waves(int taps) { return taps == 2 ? 7 : 6; }
 // launches the ahead-of-time kernel.
 static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps, int n0, int dw, int dh, bool interleaved, bool fast1, int *grid) {
     if (c->jit_mode == 0 || c->kernel_variant != 0 || Y.model != GFW_MODEL_OPENCV_FISHEYE || Y.extras || Y.audit || Y.ablate) return nullptr;
+    // bilinear only for now: the baked bicubic / Lanczos4 instantiations measured SLOWER than the ahead-of-time ones on MI355X (C2: 329 against
+    // ~125 us, 394 against 203 us: gpurun_out/r03c) — GFW_JIT_LUT=1 builds them all the same, for the investigation
+    static const bool jit_lut = getenv("GFW_JIT_LUT") != nullptr;
+    if (taps != 2 && !jit_lut) return nullptr;
     if (!gfw_jit_available()) { c->jit_info.state = GFW_JIT_UNAVAILABLE; c->jit_info.log = "libhiprtc.so not found"; return nullptr; }
     std::string hdr = bake_header(Y);
     if (hdr == c->jit_header) { if (c->jit_seen < (1 << 30)) ++c->jit_seen; }

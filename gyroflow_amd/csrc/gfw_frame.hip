@@ -156,6 +156,20 @@ __device__ __forceinline__ float map_c(float x, float mul, float den, float rcp)
     return __builtin_fmaf(r0, rcp, q0);
 }
 
+// The chroma plane's source_rect map of a coordinate x whose luma map l = map_c(x, mul_l, den, rcp) is already known (baked builds: the
+// multipliers are literals, the branches fold).  Same multiplier (4:2:2's rows, 4:4:4): the same operations, l itself.  Half the
+// multiplier (a subsampled axis): every operation of map_c scales exactly by 1/2 — power-of-two scaling commutes with round-to-nearest
+// while nothing underflows — so the result is l/2; coordinates below 2^-100 (where the residual of the division could go subnormal)
+// send the whole wave through the full evaluation.
+__device__ __forceinline__ float chroma_from_luma(float l, float x, float mul_c, float mul_l, float den, float rcp) {
+    if (mul_c == mul_l) return l;
+    if (2.0f * mul_c == mul_l) {
+        const bool tiny = fabsf(l) < 0x1p-100f && l != 0.0f;
+        if (__builtin_expect(!__any(tiny), 1)) return 0.5f * l;
+    }
+    return map_c<false>(x, mul_c, den, rcp);
+}
+
 // opencv_fisheye.rs:72-95 on (X/W, Y/W); then *f, +c (cpu_undistort.rs:155,167)
 template <class Ops>
 __device__ __forceinline__ void fisheye_project(float X, float Y, float W, const Lens &L, bool k_all_zero, float &u, float &v) {
@@ -227,7 +241,7 @@ __device__ __forceinline__ GfwPt rd(float px, float py, const float4 ma, const f
 }
 template <int MODEL>
 __device__ __forceinline__ GfwPt rd_row(float px, float py, int idx, const float *matrices, const Lens &L, const GfwYuvArgs &A) {
-    const float *m = matrices + (size_t)idx * GFW_MAT_STRIDE;
+    const float *m = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(matrices) + (uint32_t)idx * (uint32_t)(GFW_MAT_STRIDE * sizeof(float)));   // idx >= 0
     return rd<MODEL>(px, py, *reinterpret_cast<const float4 *>(m), *reinterpret_cast<const float4 *>(m + 4), m[8], m + 8, L, A);
 }
 
@@ -243,6 +257,9 @@ __device__ __forceinline__ int round_i32(float x) {
 __device__ __forceinline__ float min_limit(float v, float limit) {
     float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(v), "s"(limit)); return r;
 }
+
+// `as u32` of a float known to be finite or NaN: v_cvt_u32_f32 (truncate; negative and NaN -> 0; saturating)
+__device__ __forceinline__ uint32_t gfw_f2u_trunc(float v) { uint32_t r; asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(v)); return r; }
 
 // ---- LUT taps (cpu_undistort.rs:371-418): I = 2 bilinear, 4 bicubic, 8 Lanczos4 --------------------------------
 // The I x-weights and I y-weights of a sample stay in the LDS copy of the table (32 phases x I floats per filter); a
@@ -334,15 +351,15 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
         };
         if ((stride & 3) == 0) {
             // the usual case (row pitch a multiple of 4 bytes): the misalignment is the same for every tap row of the sample
-            const uint8_t *rp0 = src + (int64_t)off0;
+            const uint8_t *rp0 = src + (uint32_t)off0;
             const unsigned mis = (unsigned)(uintptr_t)rp0 & 3u, sh = mis * 8u;
             const uint8_t *ap = rp0 - mis;
             #pragma unroll (I >= 8 ? GFW_TAP_ROW_UNROLL8 : GFW_TAP_ROW_UNROLL)
-            for (int yp = 0; yp < I; ++yp) row(reinterpret_cast<const uint32_t *>(ap + (int64_t)yp * stride), mis, sh, b.ty[yp]);
+            for (int yp = 0; yp < I; ++yp) row(reinterpret_cast<const uint32_t *>(ap + (uint32_t)(yp * stride)), mis, sh, b.ty[yp]);
         } else {
             #pragma unroll 1
             for (int yp = 0; yp < I; ++yp) {
-                const uint8_t *rp = src + (int64_t)(off0 + yp * stride);
+                const uint8_t *rp = src + (uint32_t)(off0 + yp * stride);
                 const unsigned mis = (unsigned)(uintptr_t)rp & 3u;
                 row(reinterpret_cast<const uint32_t *>(rp - mis), mis, mis * 8u, b.ty[yp]);
             }
@@ -355,7 +372,7 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
     for (int c = 0; c < N; ++c) sum[c] = 0.0f;
     #pragma unroll
     for (int yp = 0; yp < I; ++yp) {
-        const T *row = reinterpret_cast<const T *>(src + (int64_t)(off0 + yp * stride));
+        const T *row = reinterpret_cast<const T *>(src + (uint32_t)(off0 + yp * stride));
         float xs[N];
         #pragma unroll
         for (int c = 0; c < N; ++c) xs[c] = 0.0f;
@@ -377,13 +394,28 @@ __device__ __forceinline__ bool bins_inside(const Bins<I> &b, int w, int h) {
     constexpr int TAP_MARGIN = (N == 1 && !is_f32<T>::value && I > 2) ? (4 / (int)sizeof(T) - 1) : 0;
     return w >= I + TAP_MARGIN && h >= I && (unsigned)b.sx <= (unsigned)(w - I - TAP_MARGIN) && (unsigned)b.sy <= (unsigned)(h - I);
 }
+// Does the saturating `as u8/u16` cast need its upper clamp?  Every value a sample can take is min(sum, limit) or bg[c]; when both are
+// clip constants no larger than the type's maximum the truncating conversion alone is the cast (negative and NaN -> 0 in hardware).
+// Decidable at compile time in a baked build only; elsewhere the clamp stays.
+template <typename T>
+__device__ __forceinline__ bool px_needs_sat(const float *bg, int n, float limit) {
+#if GFW_BAKE
+    const float top = sizeof(T) == 1 ? 255.0f : 65535.0f;
+    bool fits = limit <= top;
+    for (int c = 0; c < n; ++c) fits = fits && bg[c] <= top;
+    return !fits;
+#else
+    (void)bg; (void)n; (void)limit;
+    return true;
+#endif
+}
 template <typename T, int N>
-__device__ __forceinline__ void store_px(uint8_t *dst, int off, const float *v) {
-    T *d = reinterpret_cast<T *>(dst + (int64_t)off);
+__device__ __forceinline__ void store_px(uint8_t *dst, int off, const float *v, bool sat = true) {
+    T *d = reinterpret_cast<T *>(dst + (uint32_t)off);          // off >= 0: a zero-extended lane offset on the uniform plane base
     #pragma unroll
     for (int c = 0; c < N; ++c) {
         if (is_f32<T>::value) d[c] = (T)v[c];                                   // f32 pixels pass through (pixel_formats.rs:247,296)
-        else d[c] = (T)gfw_f2u_sat(v[c], sizeof(T) == 1 ? 255.0f : 65535.0f);    // `as u8/u16`
+        else d[c] = sat ? (T)gfw_f2u_sat(v[c], sizeof(T) == 1 ? 255.0f : 65535.0f) : (T)gfw_f2u_trunc(v[c]);    // `as u8/u16`
     }
 }
 // One plane.  32-bit byte offsets from the uniform plane base (planes are < 2 GiB, checked on the host).
@@ -399,7 +431,7 @@ __device__ __forceinline__ void sample_store(float u, float v, bool ok, const Gf
         else
             taps_edge<T, N, I>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
     }
-    store_px<T, N>(P.dst, oy * P.dst_stride + ox * (int)(N * sizeof(T)), out);
+    store_px<T, N>(P.dst, oy * P.dst_stride + ox * (int)(N * sizeof(T)), out, px_needs_sat<T>(bg, N, limit));
 }
 // Planar planes of identical geometry (U and V; or G,B,R,A of a planar float frame): one set of bins / weights /
 // offsets, one gather set per plane.
@@ -493,8 +525,12 @@ __device__ __forceinline__ void taps_edge2(const uint8_t *src, int stride, const
 // (xsum = 0 + p*c, sum = 0 + xs*cy) are exact identities and are dropped; for f32 pixels (-0, negative values) they stay.
 template <typename T, int N>
 __device__ __forceinline__ void taps_inside2(const uint8_t *src, int off0, int stride, const Bins2 &b, float limit, float *out) {
-    const T *row0 = reinterpret_cast<const T *>(src + (int64_t)off0);
-    const T *row1 = reinterpret_cast<const T *>(src + (int64_t)(off0 + stride));
+    // all four taps inside: off0 >= 0 and the plane is < 2 GiB (host-checked), so both rows are zero-extended 32-bit lane offsets on the
+    // uniform plane base — the saddr + voffset form of global_load, one address instruction per row instead of a 64-bit add chain
+    const T *row0 = reinterpret_cast<const T *>(src + (uint32_t)off0);
+    uint32_t off1 = (uint32_t)off0 + (uint32_t)stride;
+    asm("" : "+v"(off1));             // opaque: keeps the second row a 32-bit lane offset too (a pitch beyond the 12-bit immediate otherwise becomes a 64-bit add chain)
+    const T *row1 = reinterpret_cast<const T *>(src + off1);
     #pragma unroll
     for (int c = 0; c < N; ++c) {
         if (is_f32<T>::value) {
@@ -559,7 +595,7 @@ __device__ __forceinline__ void sample_store2(float u, float v, bool ok, const G
             taps_edge2<T, N>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
     }
     const int doff = oy * P.dst_stride + ox * (int)(N * sizeof(T));
-    if (range_ok(aud, doff, N * sizeof(T), P.dst_len)) store_px<T, N>(P.dst, doff, out);
+    if (range_ok(aud, doff, N * sizeof(T), P.dst_len)) store_px<T, N>(P.dst, doff, out, px_needs_sat<T>(bg, N, limit));
 }
 // Planar planes of identical geometry (U and V; or G,B,R,A of a planar float frame): one set of bins / weights /
 // offsets, one gather pair per plane.
@@ -620,8 +656,8 @@ __device__ __forceinline__ void sample_store_uv2(float u, float v, bool ok, cons
     }
     const int doff = oy * PU.dst_stride + ox * (int)sizeof(T);
     if (!range_ok(aud, doff, sizeof(T), PU.dst_len < PV.dst_len ? PU.dst_len : PV.dst_len)) return;
-    store_px<T, 1>(PU.dst, doff, &ou);
-    store_px<T, 1>(PV.dst, doff, &ov);
+    store_px<T, 1>(PU.dst, doff, &ou, px_needs_sat<T>(&bg_u, 1, lim_u));
+    store_px<T, 1>(PV.dst, doff, &ov, px_needs_sat<T>(&bg_v, 1, lim_v));
 }
 
 // ---- background mode 3 ("margin with feather", cpu_undistort.rs:576-613) ----------------------------------------------------
@@ -715,17 +751,19 @@ __device__ __forceinline__ bool pass1_fast(float ax, float ay, float aw, float o
         const float lhs = __builtin_fmaf(X, X, Y * Y), rhs = rl2 * W;
         good = good & (lhs < rhs * 0.9999f);
     }
-    const float tpos = fminf(fmaxf(rho, 0.0f), Q.rho_max) * Q.rho_scale;   // clamped: a rejected lane still indexes the table
-    const float ti = floorf(tpos);
-    if (aud && !((int)ti >= 0 && (int)ti <= GFW_P1_TABLE_N)) atomicAdd(&aud[5], 1ull);
-    const float2 e = tab[(int)ti];
-    const float s = __builtin_fmaf(tpos - ti, e.y, e.x);
+    // table position, clamped so that a rejected lane still indexes the table: rho is a sum of squares (>= +0, or NaN, which the
+    // hardware minimum turns into rho_max); the interval index is the truncated position and v_fract_f32 its exact remainder
+    const float tpos = min_limit(rho, Q.rho_max) * Q.rho_scale;
+    const uint32_t ti = gfw_f2u_trunc(tpos);
+    if (aud && !(ti <= (uint32_t)GFW_P1_TABLE_N)) atomicAdd(&aud[5], 1ull);
+    const float2 e = *reinterpret_cast<const float2 *>(reinterpret_cast<const uint8_t *>(tab) + ti * 8u);
+    const float s = __builtin_fmaf(__builtin_amdgcn_fractf(tpos), e.y, e.x);
     const float v = __builtin_fmaf((hrs ? a : b) * s, Q.f, Q.c);
     v_out = v;
     const float g = v - 0.5f;
     const float dist = fabsf(g - rintf(g));                        // distance of v to the nearest half-integer
-    const bool outside = !(v > -0.25f) | !(v < Q.lim + 0.25f);     // there the clamp decides and ties cannot matter
-    good = good & (outside | (dist > Q.eps)) & (v == v);
+    const bool outside = (v <= -0.25f) | (v >= Q.lim + 0.25f);     // there the clamp decides and ties cannot matter (false for NaN)
+    good = good & (outside | (dist > Q.eps));                      // a NaN fails both comparisons
     sy = max(min(gfw_f2i(rintf(v)), (int)Q.lim), 0);
     return good;
 }
@@ -926,7 +964,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
 #endif
                 const int cy = cy0 + r;
                 if (cy >= AF(ch)) break;
-                float u0 = 0.0f, v0 = 0.0f; bool ok0 = false;
+                float u0 = 0.0f, v0 = 0.0f, lu0 = 0.0f, lv0 = 0.0f; bool ok0 = false;
                 #pragma unroll (NPX <= 2 ? NPX : 1)
                 for (int k = 0; k < NPX; ++k) {
                     const int i = k % DW, j = k / DW;
@@ -963,6 +1001,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     }
                     const float lu = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(p.x, MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(p.y, MP.mul_ly, MP.den_y, MP.rcp_y);   // cpu_undistort.rs:511-514
                     if (AF(ablate) & 2) { if (lane == 99) PL0.dst[0] = (uint8_t)(lu + lv); continue; }  // timing ablation only
+                    if (k == 0) { lu0 = lu; lv0 = lv; }
                     if (I == 2) sample_store2<T, N0>(lu, lv, p.ok, PL0, bg_y, lim_y, lx, ly, AUDIT ? AF(audit) : nullptr);
                     else sample_store<T, N0, I>(lu, lv, p.ok, PL0, bg_y, lim_y, lx, ly, s_lut);
                 }
@@ -973,7 +1012,15 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                         feather_store<T, 1, I, true>(u0, v0, f, A_in.pl[pi], A_in.pl[pi].bg, A_in.pl[pi].limit, MP.mul_cx, MP.mul_cy, MP, cx, cy, s_lut);
                 } else
                 if (AF(nplanes) > 1 && !(AF(ablate) & 4)) {
-                    const float cu = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(u0, MP.mul_cx, MP.den_x, MP.rcp_x), cv = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(v0, MP.mul_cy, MP.den_y, MP.rcp_y);
+                    float cu, cv;
+                    if (GFW_BAKE && MODEL == GFW_MODEL_OPENCV_FISHEYE) {
+                        // the chroma site's coordinate from the luma pixel's that shares it (chroma_from_luma): nothing for 4:2:2's rows, one multiply for a halved axis
+                        cu = chroma_from_luma(lu0, u0, MP.mul_cx, MP.mul_lx, MP.den_x, MP.rcp_x);
+                        cv = chroma_from_luma(lv0, v0, MP.mul_cy, MP.mul_ly, MP.den_y, MP.rcp_y);
+                    } else {
+                        cu = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(u0, MP.mul_cx, MP.den_x, MP.rcp_x);
+                        cv = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(v0, MP.mul_cy, MP.den_y, MP.rcp_y);
+                    }
                     if (I == 2) {
                         if (INTERLEAVED_UV) sample_store2<T, 2>(cu, cv, ok0, PL1, bg_c, lim_u, cx, cy, AUDIT ? AF(audit) : nullptr);
                         else if (AF(nplanes) == 3) sample_store_uv2<T>(cu, cv, ok0, PL1, PL2, bg_c[0], bg_v, lim_u, lim_v, cx, cy, AUDIT ? AF(audit) : nullptr);

@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 def check_jit(fr, what):
     ref = O.run_frame(fr)
     got = warp.run_frame(fr, jit=2)
-    assert warp.last_backend().endswith("_jit"), (what, warp.last_backend())
+    if fr.planes[0]["params"].interpolation == 2:            # bicubic / Lanczos4 stay ahead-of-time unless GFW_JIT_LUT is set (measured slower baked)
+        assert warp.last_backend().endswith("_jit"), (what, warp.last_backend())
     for i, (a, b) in enumerate(zip(ref, got)):
         assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "%s: specialised kernel, plane %d" % (what, i))
     aot = warp.run_frame(fr, jit=0)

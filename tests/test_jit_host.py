@@ -46,7 +46,7 @@ def test_embedded_source_compiles_for_the_lut_samplers(tmp_path, taps):
 def test_a_broken_bake_header_is_reported_not_fatal(tmp_path):
     lib = abi.load_library()
     log = C.create_string_buffer(1 << 14)
-    n = lib.gfw_debug_jit_compile(b"gfx950", (C2_DEFS % (2, 7)).encode(), b"#define GFW_BAKE_APPLY(A) do { A.no_such_field = 1; } while (0)\n", b"", log, len(log))
+    n = lib.gfw_debug_jit_compile(b"gfx950", (C2_DEFS % (2, 7)).encode(), b"// a bake header that defines nothing\n", b"", log, len(log))
     if n == -2:
         pytest.skip("libhiprtc.so not available")
-    assert n == -1 and b"no_such_field" in log.value
+    assert n == -1 and b"GFW_BK_" in log.value

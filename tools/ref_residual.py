@@ -7,7 +7,9 @@ differ is classified from the ORACLE's coordinates:
         by a few ulp, and the GPU twin rounds with convert_int_sat_rtz(0.5 + x): SURVEY.md section 8a)
   row   the first-pass coordinate that picks the rolling-shutter row lies within TAU_ROW of a half-integer (the neighbouring row's
         matrix moves the sample by up to a few 1/32 px)
-  edge  a tap of the sample falls outside the source rect (the twins treat the border differently)
+  neg   a coordinate is negative: the twin rounds with convert_int_sat_rtz(0.5 + x) (.cl:355), which for x < 0 lands one 1/32-px bin
+        above Rust's round-half-away
+  edge  (otherwise) a tap of the sample falls outside the source rect (the twins treat the border differently)
   none  unexplained
 Prints one line per configuration and the unexplained pixels; writes gpurun_out/ref_residual.json."""
 import ctypes as C
@@ -61,10 +63,10 @@ def classify(fr, ref, got, interp, taus=(5e-5, 1e-4, 2e-4, 4e-4, 1e-3), tau_row=
         return out
     cs = coords_of(fr, list(zip(xs.tolist(), ys.tolist())))
     off = {2: 0.0, 4: 1.0, 8: 3.0}[interp]
-    cls = {"row": 0, "edge": 0}
+    cls = {"row": 0, "neg": 0, "edge": 0}
     for t in taus:
         cls["bin@%g" % t] = 0
-    unexplained = []
+    unexplained, edge_examples = [], []
     for (x, y), (ok, u, v, ok1, u1, v1) in zip(zip(xs.tolist(), ys.tolist()), cs):
         def edge_dist(c):
             t = (np.float32(c) - np.float32(off)) * np.float32(32.0)
@@ -85,13 +87,18 @@ def classify(fr, ref, got, interp, taus=(5e-5, 1e-4, 2e-4, 4e-4, 1e-3), tau_row=
         if not hit:
             if drow <= tau_row and p.matrix_count > 1:
                 cls["row"] += 1
+            elif ok and ((u - off) < 0.0 or (v - off) < 0.0):
+                cls["neg"] += 1
             elif is_edge:
                 cls["edge"] += 1
+                if len(edge_examples) < 8:
+                    edge_examples.append({"x": x, "y": y, "ok": bool(ok), "u": u, "v": v, "ref": a[y, x].tolist(), "got": b[y, x].tolist()})
             else:
                 unexplained.append({"x": x, "y": y, "u": u, "v": v, "bin_dist": float(d), "row_dist": float(drow), "ref": a[y, x].tolist(), "got": b[y, x].tolist()})
     out["classes"] = cls
     out["unexplained"] = len(unexplained)
     out["unexplained_examples"] = unexplained[:12]
+    out["edge_examples"] = edge_examples
     return out
 
 
@@ -121,7 +128,9 @@ def main():
         except BaseException as e:      # pytest.skip raises a BaseException subclass
             r = {"error": repr(e)}
         results[name] = r
-        print(name, json.dumps({k: v for k, v in r.items() if k != "unexplained_examples"}))
+        print(name, json.dumps({k: v for k, v in r.items() if k not in ("unexplained_examples", "edge_examples")}))
+        for ex in r.get("edge_examples", []):
+            print("    edge", ex)
         for ex in r.get("unexplained_examples", []):
             print("    unexplained", ex)
         sys.stdout.flush()
