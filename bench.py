@@ -6,9 +6,9 @@
 A "step" is one pass of the hot path over one synthetic frame: all planes of a 4K (3840x2160) u16 4:2:2 frame
 (BASELINE.json configs[1], "C2": planar YUV422P16LE = 3 x Luma16, GoPro-style opencv_fisheye lens, per-row
 rolling-shutter matrices) warped through libgfwarp's C ABI from buffers already resident in HBM.  The steps go to the
-library the way a render loop hands it a clip: `gfw_undistort_clip` calls of `--clip` frames each (default 8; exactly K
+library the way a render loop hands it a clip: `gfw_undistort_clip` calls of `--clip` frames each (default 32; exactly K
 frames are warped in the timed region), served by the context's run-time specialised kernel (GFW_OPT_JIT = 2: built
-during the warm-up, `config.jit` reports the build) in launches of up to 8 frames.
+during the warm-up, `config.jit` reports the build) in launches of up to 32 frames.
 
 Process model.  Started plainly, this file is a *launcher*: it spawns one worker process per GPU (RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* in the environment, rendezvous on 127.0.0.1), relays rank 0's JSON line and exits with the
@@ -48,7 +48,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FMT, WIDTH, HEIGHT = "YUV422P16LE", 3840, 2160
 N_RESIDENT = 64                  # distinct source frames + per-row matrix tables resident in HBM, cycled by the steps
                                  # (SURVEY.md 8d "64 distinct resident source frames cycled": 2.1 GB, far beyond L2 + MALL)
-N_DST = 8                        # destination frame sets written round-robin (the frames of one clip launch are in flight together: one set each)
+N_DST = 32                       # destination frame sets written round-robin (the frames of one clip launch are in flight together: one set each)
 N_CHECK = 3                      # frames of the timed region compared with the oracle afterwards
 TRAFFIC_FILE = os.path.join("profiles", "r03_c2_traffic.json")
 
@@ -66,7 +66,7 @@ def parse_args(argv):
     ap.add_argument("--no-retry", action="store_true", help=argparse.SUPPRESS)      # the default since round 3
     ap.add_argument("--jit", type=int, default=2, choices=(0, 1, 2),
                     help="GFW_OPT_JIT of the contexts: 2 (default) the per-clip specialised kernel is built during the warm-up; 0 ahead-of-time kernels only")
-    ap.add_argument("--clip", type=int, default=8,
+    ap.add_argument("--clip", type=int, default=32,
                     help="frames per gfw_undistort_clip call (resident-matrices workloads); 1 = one gfw_undistort_frame call per frame")
     ap.add_argument("--preheat-ms", type=float, default=60.0,
                     help="untimed launches of the same workload for this long right before the timed region (declared in config.preheat_ms): "
@@ -344,7 +344,7 @@ def worker(args):
 
     # ---- clip mode: the steps reach the library as gfw_undistort_clip calls of `clip_n` frames (the frames of one call use distinct
     # destination sets: the specialised kernel takes up to 8 of them in one launch)
-    clip_n = max(1, min(args.clip, N_DST))
+    clip_n = max(1, min(args.clip, N_DST) if device_built else min(args.clip, N_DST, NR))
     if args.upload_matrices or args.host_buffers or n_streams > 1 or (device_built and not args.c5) or (NR % clip_n and not device_built):
         clip_n = 1
     if args.c5 and BATCH % clip_n:
@@ -537,9 +537,9 @@ def worker(args):
         traffic, tsrc = None, None
         tpath = os.path.join(ROOT, TRAFFIC_FILE)
         if (W, H, args.fmt, args.interp, args.crop, args.variant, args.host_buffers, bool(args.digital)) == (WIDTH, HEIGHT, FMT, 2, False, 0, False, False) and os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            traffic = int((tj["fetch_size_kib"] * tj["fetch_correction"] + tj["write_size_kib"]) * 1024)
-            tsrc = "%s (stored rocprofv3 PMC passes of this workload, not measured in this run)" % TRAFFIC_FILE
+            tj = json.load(open(tpath))                  # per frame; a launch carries fpl of them
+            traffic = int((tj["fetch_size_kib_per_frame"] * tj["fetch_correction"] + tj["write_size_kib_per_frame"]) * 1024 * fpl)
+            tsrc = "%s (stored rocprofv3 PMC passes of this workload and library, not measured in this run)" % TRAFFIC_FILE
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                            "kernel": warp.last_backend(), "kernel_ms_per_launch": round(per_launch_ms, 5),

@@ -88,6 +88,7 @@ struct gfw_ctx {
     const char *last_backend = "";
     // certified first pass of the fused kernel: s(rho) table cache
     DevBuf d_p1_table, d_audit;
+    float p1_eps_last = 0.0f;                      // certificate half-width of the last frame set up (reported in gfw_get_audit's word 6)
     float p1_k[4] = {0, 0, 0, 0}; float p1_rho_max = 0.0f; double p1_etab = 0.0; double p1_smax = 1.0; bool p1_valid = false;
     DevBuf d_pts_in, d_pts_out, d_pts_rot, d_pts_shift, d_pts_mesh;   // gfw_undistort_points staging
     DevBuf d_tracks;                              // quaternion tracks
@@ -105,7 +106,12 @@ struct gfw_ctx {
     BuiltSlot bslots[kBuiltSlots];
     int bslot_next = 0, bslot_cur = -1;
     GfwTracks tracks = {nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, 1.0};
-    DevBuf d_offsets, d_stab;                      // sync offsets of the clip; IBIS/OIS control points of the frame being built
+    DevBuf d_offsets;                              // sync offsets of the clip
+    // IBIS/OIS control points of the frames being built: a ring of (pinned host, device) pairs, copied on the stream that builds, so that
+    // a clip with stabiliser data keeps the asynchronous table ring (build N+1 while N warps)
+    struct StabSlot { DevBuf d; void *h = nullptr; size_t hcap = 0; hipEvent_t done = nullptr; bool used = false; };
+    static constexpr int kStabSlots = 4;
+    StabSlot sslots[kStabSlots]; int sslot_next = 0;
     // run-time specialised kernel (gfw_jit.hip): 0 off; 1 build in the background once the context has seen kJitAfter frames of one
     // clip, warp ahead-of-time meanwhile; 2 build at the first frame and wait for it
     int jit_mode = 1;
@@ -260,7 +266,7 @@ void gfw_destroy(gfw_ctx *c) {
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &b : c->stage_src) b.release();
     for (auto &b : c->stage_dst) b.release();
-    c->d_mesh.release(); c->d_p1_table.release(); c->d_audit.release(); c->d_tracks.release(); c->d_offsets.release(); c->d_stab.release(); c->d_prefix.release(); c->d_timings.release(); c->d_batch[0].release(); c->d_batch[1].release();
+    c->d_mesh.release(); c->d_p1_table.release(); c->d_audit.release(); c->d_tracks.release(); c->d_offsets.release(); for (auto &ss : c->sslots) { ss.d.release(); if (ss.h) (void)hipHostFree(ss.h); if (ss.done) (void)hipEventDestroy(ss.done); } c->d_prefix.release(); c->d_timings.release(); c->d_batch[0].release(); c->d_batch[1].release();
     if (c->h_timings) (void)hipHostFree(c->h_timings);
     for (auto &e : c->timing_copied) if (e) (void)hipEventDestroy(e);
     for (auto &b : c->bslots) { b.buf.release(); if (b.built) (void)hipEventDestroy(b.built); if (b.consumed) (void)hipEventDestroy(b.consumed); }
@@ -321,6 +327,7 @@ int gfw_get_audit(gfw_ctx *c, unsigned long long *counters8, int reset) {
     if (fresh) HIP_TRY(hipMemsetAsync(c->d_audit.ptr, 0, 8 * sizeof(unsigned long long), c->stream), GFW_ERR_HIP);
     HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
     HIP_TRY(hipMemcpy(counters8, c->d_audit.ptr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost), GFW_ERR_HIP);
+    { uint32_t bits; memcpy(&bits, &c->p1_eps_last, 4); counters8[6] = bits; }      // E of the last frame, f32 bits
     if (reset) HIP_TRY(hipMemset(c->d_audit.ptr, 0, 8 * sizeof(unsigned long long)), GFW_ERR_HIP);
     return GFW_OK;
 }
@@ -580,6 +587,7 @@ static bool p1_setup(gfw_ctx *c, const gfw_kernel_params &p0, const float *h_mat
     Y.p1_table = (const float2 *)c->d_p1_table.ptr;
     Y.p1_rho_max = c->p1_rho_max; Y.p1_rho_scale = (float)(GFW_P1_TABLE_N / (double)c->p1_rho_max);
     Y.p1_eps = (float)eps;
+    c->p1_eps_last = (float)eps;
     Y.p1_f = hrs ? p0.f[0] : p0.f[1]; Y.p1_c = hrs ? p0.c[0] : p0.c[1];
     table_ok = true;
     if (c->kernel_variant == 3) {                               // audit mode: count certificates and check each one
@@ -805,7 +813,11 @@ static std::string bake_header(const GfwYuvArgs &Y) {
     return o;
 }
 // Waves per SIMD the specialised instantiation is budgeted for (measured on C2: 6 -> 72.8, 7 -> 67.3, 8 -> 70.5 us with the table atanf)
-static int jit_waves(int taps) { return taps == 2 ? 7 : 6; }
+static int jit_waves(int taps) {
+    static const int forced = getenv("GFW_JIT_WAVES") ? atoi(getenv("GFW_JIT_WAVES")) : 0;      // experiments
+    if (forced >= 1 && forced <= 8) return forced;
+    return taps == 2 ? 7 : 6;
+}
 // The specialised kernel for this frame's arguments, or nullptr (not eligible / not wanted / not ready / failed): the caller then
 // launches the ahead-of-time kernel.
 static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps, int n0, int dw, int dh, bool interleaved, bool fast1, int *grid) {
@@ -979,7 +991,7 @@ int gfw_undistort_clip(gfw_ctx *c, int n_frames, int nplanes, const gfw_buffers 
     for (int i = 0; i < nplanes; ++i)
         if (pixel_types[i] < 0 || pixel_types[i] >= GFW_PIX_COUNT) { set_error("plane %d: unknown pixel type %d", i, pixel_types[i]); return GFW_ERR_INVALID_ARGUMENT; }
     // the frame loop of a render (rendering/mod.rs:487-547 calls process_pixels once per frame), here on the library side: frames that
-    // share the specialised kernel leave in launches of up to GFW_CLIP_MAX frames, everything else exactly as gfw_undistort_frame
+    // share the specialised kernel leave in launches of up to GFW_CLIP_MAX (32) frames, everything else exactly as gfw_undistort_frame
     ClipBatch batch;
     for (int f = 0; f < n_frames; ++f) {
         const int rc = run_planes(c, nplanes, planes + (size_t)f * nplanes, params, pixel_types, matrices[f], matrix_count, nullptr, 0, &batch);
@@ -1111,16 +1123,17 @@ static int stage_timings(gfw_ctx *c, const gfw_frame_timing *t, int count, hipSt
     *d_out = d;
     return GFW_OK;
 }
-static bool timing_ok(const gfw_frame_timing *t) { return t->rows >= 1 && t->readout_dim >= 1; }
+static bool timing_ok(const gfw_frame_timing *t) { return t->rows >= 1 && t->readout_dim >= 1 && t->suppress_rotation >= 0 && t->suppress_rotation <= 2; }
 
 int gfw_build_matrices(gfw_ctx *c, const gfw_frame_timing *t, float *rows16_out, float **out_ptr) {
     return gfw_build_matrices_stab(c, t, nullptr, rows16_out, out_ptr);
 }
 int gfw_build_matrices_stab(gfw_ctx *c, const gfw_frame_timing *t, const gfw_frame_stab *stab, float *rows16_out, float **out_ptr) {
     if (!c || !t) { set_error("null context/timing"); return GFW_ERR_INVALID_ARGUMENT; }
-    if (!timing_ok(t)) { set_error("rows %d, readout_dim %d", t->rows, t->readout_dim); return GFW_ERR_INVALID_ARGUMENT; }
+    if (!timing_ok(t)) { set_error("rows %d, readout_dim %d, suppress_rotation %d", t->rows, t->readout_dim, t->suppress_rotation); return GFW_ERR_INVALID_ARGUMENT; }
     HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
     GfwStab S, *Sp = nullptr;
+    gfw_ctx::StabSlot *stab_slot = nullptr; size_t stab_bytes = 0;
     if (stab) {
         if (stab->ibis_count < 0 || stab->ois_count < 0 || (stab->ibis_count && !stab->ibis) || (stab->ois_count && !stab->ois) ||
             !(stab->crop_area[2] != 0.0) || !(stab->crop_area[3] != 0.0) || !(stab->pixel_pitch[0] != 0.0) || !(stab->pixel_pitch[1] != 0.0)) {
@@ -1129,13 +1142,23 @@ int gfw_build_matrices_stab(gfw_ctx *c, const gfw_frame_timing *t, const gfw_fra
         for (int i = 1; i < stab->ibis_count; ++i) if (!(stab->ibis[i * 4] >= stab->ibis[(i - 1) * 4])) { set_error("IBIS spline positions must ascend"); return GFW_ERR_INVALID_ARGUMENT; }
         for (int i = 1; i < stab->ois_count; ++i) if (!(stab->ois[i * 4] >= stab->ois[(i - 1) * 4])) { set_error("OIS spline positions must ascend"); return GFW_ERR_INVALID_ARGUMENT; }
         const size_t nb0 = (size_t)stab->ibis_count * 32, nb1 = (size_t)stab->ois_count * 32;
-        // the control points of the previous build may still be read: builds with stabiliser data are serialised on both streams
-        HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
-        if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream), GFW_ERR_HIP);
-        HIP_TRY(c->d_stab.ensure(nb0 + nb1 + 64), GFW_ERR_HIP);
-        char *base = (char *)c->d_stab.ptr;
-        if (nb0) HIP_TRY(hipMemcpy(base, stab->ibis, nb0, hipMemcpyHostToDevice), GFW_ERR_HIP);
-        if (nb1) HIP_TRY(hipMemcpy(base + nb0, stab->ois, nb1, hipMemcpyHostToDevice), GFW_ERR_HIP);
+        // next pair of the ring; the build that last read it (four builds ago) has normally long finished
+        gfw_ctx::StabSlot &ss = c->sslots[c->sslot_next];
+        c->sslot_next = (c->sslot_next + 1) % gfw_ctx::kStabSlots;
+        if (!ss.done) HIP_TRY(hipEventCreateWithFlags(&ss.done, hipEventDisableTiming), GFW_ERR_HIP);
+        if (ss.used) HIP_TRY(hipEventSynchronize(ss.done), GFW_ERR_HIP);
+        HIP_TRY(ss.d.ensure(nb0 + nb1 + 64), GFW_ERR_HIP);
+        if (ss.hcap < nb0 + nb1 + 64) {
+            if (ss.h) (void)hipHostFree(ss.h);
+            ss.h = nullptr; ss.hcap = 0;
+            HIP_TRY(hipHostMalloc(&ss.h, nb0 + nb1 + 64), GFW_ERR_HIP);
+            ss.hcap = nb0 + nb1 + 64;
+        }
+        stab_slot = &ss;
+        char *base = (char *)ss.d.ptr;
+        if (nb0) memcpy(ss.h, stab->ibis, nb0);
+        if (nb1) memcpy((char *)ss.h + nb0, stab->ois, nb1);
+        stab_bytes = nb0 + nb1;
         const double inv = t->framebuffer_inverted ? -1.0 : 1.0;
         S.offset = stab->offset; S.sensor_h = stab->sensor_size[1]; S.crop_y = stab->crop_area[1]; S.crop_h = stab->crop_area[3];
         S.scale_x = stab->width / stab->crop_area[2] / stab->pixel_pitch[0];                       // frame_transform.rs:234-241
@@ -1149,7 +1172,9 @@ int gfw_build_matrices_stab(gfw_ctx *c, const gfw_frame_timing *t, const gfw_fra
     if (rows16_out) {                                        // caller-owned table: built in order on the context's stream
         HIP_TRY(c->d_prefix.ensure(4 * sizeof(double)), GFW_ERR_HIP);
         { const int rc = stage_timings(c, t, 1, c->stream, &d_t); if (rc != GFW_OK) return rc; }
+        if (stab_slot && stab_bytes) HIP_TRY(hipMemcpyAsync(stab_slot->d.ptr, stab_slot->h, stab_bytes, hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
         HIP_TRY(gfw_launch_build_matrices(c->tracks, d_t, 1, t->rows, (double *)c->d_prefix.ptr, rows16_out, table_floats, c->stream, Sp), GFW_ERR_HIP);
+        if (stab_slot) { HIP_TRY(hipEventRecord(stab_slot->done, c->stream), GFW_ERR_HIP); stab_slot->used = true; }
         if (out_ptr) *out_ptr = rows16_out;
         if (c->synchronous) HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
         return GFW_OK;
@@ -1162,8 +1187,10 @@ int gfw_build_matrices_stab(gfw_ctx *c, const gfw_frame_timing *t, const gfw_fra
     if (!b.built) { HIP_TRY(hipEventCreateWithFlags(&b.built, hipEventDisableTiming), GFW_ERR_HIP); HIP_TRY(hipEventCreateWithFlags(&b.consumed, hipEventDisableTiming), GFW_ERR_HIP); }
     if (b.used) HIP_TRY(hipStreamWaitEvent(c->copy_stream, b.consumed, 0), GFW_ERR_HIP);   // the warp that read this slot is done
     { const int rc = stage_timings(c, t, 1, c->copy_stream, &d_t); if (rc != GFW_OK) return rc; }
+    if (stab_slot && stab_bytes) HIP_TRY(hipMemcpyAsync(stab_slot->d.ptr, stab_slot->h, stab_bytes, hipMemcpyHostToDevice, c->copy_stream), GFW_ERR_HIP);
     HIP_TRY(gfw_launch_build_matrices(c->tracks, d_t, 1, t->rows, (double *)((char *)b.buf.ptr + table_bytes), (float *)b.buf.ptr, table_floats, c->copy_stream, Sp), GFW_ERR_HIP);
     HIP_TRY(hipEventRecord(b.built, c->copy_stream), GFW_ERR_HIP);
+    if (stab_slot) { HIP_TRY(hipEventRecord(stab_slot->done, c->copy_stream), GFW_ERR_HIP); stab_slot->used = true; }
     if (out_ptr) *out_ptr = (float *)b.buf.ptr;
     if (c->synchronous) HIP_TRY(hipStreamSynchronize(c->copy_stream), GFW_ERR_HIP);
     return GFW_OK;
@@ -1174,7 +1201,7 @@ int gfw_build_matrices_batch(gfw_ctx *c, const gfw_frame_timing *t, int count, f
     if (!c || !t || !out_ptrs || count < 1 || count > gfw_ctx::kMaxBatch) { set_error("bad batch arguments (1 <= count <= %d)", gfw_ctx::kMaxBatch); return GFW_ERR_INVALID_ARGUMENT; }
     int max_rows = 0;
     for (int i = 0; i < count; ++i) {
-        if (!timing_ok(&t[i])) { set_error("frame %d: rows %d, readout_dim %d", i, t[i].rows, t[i].readout_dim); return GFW_ERR_INVALID_ARGUMENT; }
+        if (!timing_ok(&t[i])) { set_error("frame %d: rows %d, readout_dim %d, suppress_rotation %d", i, t[i].rows, t[i].readout_dim, t[i].suppress_rotation); return GFW_ERR_INVALID_ARGUMENT; }
         if (t[i].rows > max_rows) max_rows = t[i].rows;
     }
     HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);

@@ -458,6 +458,33 @@ __device__ __forceinline__ void sample_store_shared(float u, float v, bool ok, c
         store_px<T, 1>(pl[pi].dst, doff, &o);
     }
 }
+// The same over named planes (baked builds: the planes are separate objects, never an array — an array indexed by a loop counter would
+// live in scratch and turn the plane pointers into flat addresses).  n = 1..3 planes Pa, Pb, Pc.
+template <typename T, int I>
+__device__ __forceinline__ void sample_store_shared_refs(float u, float v, bool ok, const GfwYuvPlane &Pa, const GfwYuvPlane &Pb, const GfwYuvPlane &Pc, int n,
+                                                         int ox, int oy, const float *lut) {
+    Bins<I> b;
+    b.sx = 0; b.sy = 0; b.tx = lut; b.ty = lut;
+    bool inside = false;
+    int off0 = 0;
+    if (ok) {
+        b = make_bins<I>(u, v, lut);
+        inside = bins_inside<T, 1, I>(b, Pa.w, Pa.h);
+        off0 = b.sy * Pa.src_stride + b.sx * (int)sizeof(T);
+    }
+    const int doff = oy * Pa.dst_stride + ox * (int)sizeof(T);
+    auto one = [&](const GfwYuvPlane &P) {
+        float o = P.bg[0];
+        if (ok) {
+            if (__builtin_expect(inside, 1)) taps_inside<T, 1, I>(P.src, off0, Pa.src_stride, b, P.limit, &o);
+            else taps_edge<T, 1, I>(P.src, Pa.src_stride, b, Pa.w, Pa.h, P.bg, P.limit, &o);
+        }
+        store_px<T, 1>(P.dst, doff, &o, px_needs_sat<T>(P.bg, 1, P.limit));
+    };
+    one(Pa);
+    if (n > 1) one(Pb);
+    if (n > 2) one(Pc);
+}
 
 // ---- integer-dot taps for 8/16-bit planes ---------------------------------------------------------------------------------
 // A bilinear sample of an integer plane is sum = RN(RN(xs0*cy0) + RN(xs1*cy1)) with xs = p0*(1-k/32) + p1*k/32 exact
@@ -620,6 +647,29 @@ __device__ __forceinline__ void sample_store_shared2(float u, float v, bool ok, 
         }
         store_px<T, 1>(pl[pi].dst, doff, &o);
     }
+}
+template <typename T>
+__device__ __forceinline__ void sample_store_shared2_refs(float u, float v, bool ok, const GfwYuvPlane &Pa, const GfwYuvPlane &Pb, const GfwYuvPlane &Pc, int n, int ox, int oy) {
+    Bins2 b = {0, 0, 0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u};
+    bool inside = false;
+    int off0 = 0;
+    if (ok) {
+        b = make_bins2(u, v);
+        inside = (unsigned)b.sx < (unsigned)(Pa.w - 1) && (unsigned)b.sy < (unsigned)(Pa.h - 1);
+        off0 = b.sy * Pa.src_stride + b.sx * (int)sizeof(T);
+    }
+    const int doff = oy * Pa.dst_stride + ox * (int)sizeof(T);
+    auto one = [&](const GfwYuvPlane &P) {
+        float o = P.bg[0];
+        if (ok) {
+            if (__builtin_expect(inside, 1)) taps_inside2<T, 1>(P.src, off0, Pa.src_stride, b, P.limit, &o);
+            else taps_edge2<T, 1>(P.src, Pa.src_stride, b, Pa.w, Pa.h, P.bg, P.limit, &o);
+        }
+        store_px<T, 1>(P.dst, doff, &o, px_needs_sat<T>(P.bg, 1, P.limit));
+    };
+    one(Pa);
+    if (n > 1) one(Pb);
+    if (n > 2) one(Pc);
 }
 
 // Two planar chroma planes of identical geometry (U, V) — the C2 hot path: one set of bins / weights / offsets,
@@ -798,12 +848,6 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     (void)PL3;
 #endif
     const float *matrices = A_in.matrices;             // the current frame's table
-    // the loops over planes of identical geometry (planar f32, 4:4:4) index an array: built where they run, so that the 4:2:x paths never see one
-#if GFW_BAKE
-#define GFW_PLANE_ARRAY(name) const GfwYuvPlane name##_v[4] = {PL0, PL1, PL2, PL3}; const GfwYuvPlane *name = name##_v
-#else
-#define GFW_PLANE_ARRAY(name) const GfwYuvPlane *name = A.pl
-#endif
     // tile = 64 x 4 lanes; each lane owns RB vertically stacked DW x DH luma blocks (+ their chroma sites).
     constexpr int NPX = DW * DH;
     constexpr int QCAP = 128 * NPX;                  // a wave adds at most 64*NPX entries per row; flushed at half full
@@ -1024,10 +1068,12 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     if (I == 2) {
                         if (INTERLEAVED_UV) sample_store2<T, 2>(cu, cv, ok0, PL1, bg_c, lim_u, cx, cy, AUDIT ? AF(audit) : nullptr);
                         else if (AF(nplanes) == 3) sample_store_uv2<T>(cu, cv, ok0, PL1, PL2, bg_c[0], bg_v, lim_u, lim_v, cx, cy, AUDIT ? AF(audit) : nullptr);
-                        else { GFW_PLANE_ARRAY(plp); sample_store_shared2<T>(cu, cv, ok0, plp, 1, AF(nplanes) - 1, cx, cy); }
+                        else if (GFW_BAKE) sample_store_shared2_refs<T>(cu, cv, ok0, PL1, PL2, PL3, AF(nplanes) - 1, cx, cy);
+                        else sample_store_shared2<T>(cu, cv, ok0, A_in.pl, 1, AF(nplanes) - 1, cx, cy);
                     } else {
                         if (INTERLEAVED_UV) sample_store<T, 2, I>(cu, cv, ok0, PL1, bg_c, lim_u, cx, cy, s_lut);
-                        else { GFW_PLANE_ARRAY(plp); sample_store_shared<T, I>(cu, cv, ok0, plp, 1, AF(nplanes) - 1, cx, cy, s_lut); }
+                        else if (GFW_BAKE) sample_store_shared_refs<T, I>(cu, cv, ok0, PL1, PL2, PL3, AF(nplanes) - 1, cx, cy, s_lut);
+                        else sample_store_shared<T, I>(cu, cv, ok0, A_in.pl, 1, AF(nplanes) - 1, cx, cy, s_lut);
                     }
                 }
             }
@@ -1048,7 +1094,6 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     }
 #endif
 #undef GFW_XCD_TILE
-#undef GFW_PLANE_ARRAY
 }
 
 #if GFW_JIT

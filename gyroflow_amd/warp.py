@@ -114,7 +114,8 @@ class Backend:
         self._check(self.lib.gfw_get_audit(self.ctx, C.byref(arr), 1 if reset else 0))
         gap = float(np.array([int(arr[4]) & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0])
         return {"certified1": int(arr[0]), "certified1_wrong": int(arr[1]), "queued1": int(arr[2]), "queue_overflow": int(arr[3]),
-                "pass1_gap_px": gap, "out_of_range": int(arr[5])}
+                "pass1_gap_px": gap, "out_of_range": int(arr[5]),
+                "pass1_eps_px": float(np.array([int(arr[6]) & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0])}
 
     def set_quaternion_tracks(self, org, smoothed):
         """Upload (timestamps_us int64, quaternions f64[n,4]) tracks once per clip (device matrix builder)."""

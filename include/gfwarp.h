@@ -251,7 +251,8 @@ int gfw_undistort_frame(gfw_ctx *ctx, int nplanes,
  * `params` (nplanes entries) and `pixel_types` are shared by all frames; matrices[f] is frame f's table, with the meaning
  * GFW_OPT_MATRICES_ON_DEVICE gives it.  Frames are warped in order on the context's stream with the results of
  * gfw_undistort_frame; frames with HIP_DEVICE buffers and device-resident tables that share the context's run-time specialised
- * kernel (GFW_OPT_JIT) leave in launches of up to 8 frames, so that the occupancy tail of one frame is filled by the next. */
+ * kernel (GFW_OPT_JIT) leave in launches of up to 32 frames, so that the occupancy tail of one frame is filled by the next
+ * (the frames of one launch are in flight together: their destination buffers must be distinct). */
 int gfw_undistort_clip(gfw_ctx *ctx, int n_frames, int nplanes,
                        const gfw_buffers *planes,
                        const gfw_kernel_params *params,
@@ -298,7 +299,7 @@ int   gfw_jit_status(gfw_ctx *ctx, double *compile_ms, char *log, size_t cap);
 /* With GFW_OPT_PROFILE on: accumulated warp-kernel time (ms, hipEventElapsedTime on the context stream)
  * and launch count since the last reset; synchronises the stream.  reset != 0 clears the accumulators. */
 int   gfw_get_profile(gfw_ctx *ctx, double *kernel_ms, int64_t *launches, int reset);
-/* the same, plus the number of frames the bracketed launches covered (a gfw_undistort_clip launch carries up to 8) */
+/* the same, plus the number of frames the bracketed launches covered (a gfw_undistort_clip launch carries up to 32) */
 int   gfw_get_profile_frames(gfw_ctx *ctx, double *kernel_ms, int64_t *launches, int64_t *frames, int reset);
 
 /* Thread-local, human-readable description of the last failure. */
@@ -334,7 +335,9 @@ typedef struct gfw_frame_timing {
     int32_t readout_dim;               /* divisor of the row readout time: height, or width for horizontal readout */
     int32_t framebuffer_inverted;
     int32_t suppress_rotation;         /* 0; 1 = params.suppress_rotation (R = identity, frame_transform.rs:291-296);
-                                          2 = the same with params.frame_readout_time == 0.0 (the IBIS/OIS terms are zeroed too) */
+                                          2 = the same with params.frame_readout_time == 0.0 (the IBIS/OIS terms are zeroed too).
+                                          MUST be set (zero-initialise the struct): until GFW_ABI_VERSION 1 this slot was padding;
+                                          any other value is rejected with GFW_ERR_INVALID_ARGUMENT */
 } gfw_frame_timing;
 /* file_metadata.camera_stab_data[frame] (gyro_source/file_metadata.rs:41-48): in-body / optical stabiliser positions along the
  * sensor readout, as two Catmull-Rom splines of the sensor row.  frame_transform.rs:234-241 and :270-289 turn them into
@@ -405,7 +408,8 @@ int   gfw_undistort_points(gfw_ctx *ctx, const gfw_kernel_params *params, const 
  *   when n == 0) and returns the number of mismatching results (0 expected), or a negative GFW_ERR_*. */
 /* First-pass audit of the fused kernel (GFW_OPT_KERNEL_VARIANT = 3): counters8 = {certified pixels,
  * certified-but-different-from-exact (must stay 0), queued to the exact path, queue overflows,
- * max |approximate - exact| coordinate over certified pixels as f32 bits, 3 spare}.  Call with reset = 1 before
+ * max |approximate - exact| coordinate over certified pixels as f32 bits, addresses outside their buffer (audit mode range-checks),
+ * the certificate half-width E of the last frame as f32 bits, 1 spare}.  Call with reset = 1 before
  * the frames to be audited. */
 int   gfw_get_audit(gfw_ctx *ctx, unsigned long long *counters8, int reset);
 /* Build check of the run-time specialisation path without a device: compiles the kernel source embedded in the library for `arch`

@@ -257,6 +257,49 @@ def test_suppress_rotation(mode):
         assert ulps(dev[:, 9:14], host[:, 9:14], np.full((h, 1), 1e-6)).max() <= 1.0
 
 
+def test_suppress_rotation_outside_its_values_is_rejected():
+    # the slot was padding until ABI version 1: a caller that leaves it uninitialised must hear about it, not get R = identity
+    w, h = 320, 192
+    fr = S.SyntheticFrame("YUV422P16LE", w, h, seed=3)
+    nk = S.new_k(fr.lens, 1.0, w, h)
+
+    def run(be):
+        be.set_quaternion_tracks(S.sampled_track(11, 0.0, 2000.0, 1000.0), S.sampled_track(12, 0.0, 2000.0, 200.0, scale=0.25))
+        for bad in (3, -1, 0x5A5A5A5A):
+            with pytest.raises(warp.GfwError) as e:
+                be.build_matrices(nk, 1000.3, 16.0, h, h, suppress_rotation=bad)
+            assert e.value.code == abi.ERR_INVALID_ARGUMENT and "suppress_rotation" in str(e.value)
+        return None
+    _rows(fr, run)
+
+
+def test_stabiliser_builds_stay_asynchronous_and_ordered():
+    """Six consecutive frames with different IBIS/OIS control points on one context: each table must carry ITS frame's terms (the
+    control points travel through a ring of pinned / device buffers on the building stream, no stream-wide synchronisation)."""
+    w, h = 640, 360
+    fr = S.SyntheticFrame("YUV422P16LE", w, h, seed=3)
+    org = S.sampled_track(11, 0.0, 2000.0, 1000.0)
+    sm = S.sampled_track(12, 0.0, 2000.0, 200.0, scale=0.25)
+    nk = S.new_k(fr.lens, 1.0, w, h)
+    stabs = []
+    for j in range(6):
+        st = _stab(w, h)
+        st["ibis"] = np.asarray(st["ibis"], dtype=np.float64).copy()
+        st["ibis"][:, 1:] *= (1.0 + 0.37 * j)
+        stabs.append(st)
+
+    def run(be):
+        be.set_quaternion_tracks(org, sm)
+        be.set_option(abi.OPT_SYNCHRONOUS, 0)
+        ptrs = [be.build_matrices(nk, 1000.3 + 33.3 * j, 16.0, h, h, stab=stabs[j]) for j in range(4)]      # the ring holds four tables
+        be.synchronize()
+        return [fetch_rows(p, h) for p in ptrs]
+    devs = _rows(fr, run)
+    for j, dev in enumerate(devs):
+        host = HS.row_matrices_from_tracks(org, sm, nk, 1000.3 + 33.3 * j, 16.0, h, h, stab=stabs[j])
+        assert ulps(dev[:, 9:14], host[:, 9:14], np.full((h, 1), 1e-6)).max() <= 1.0, j
+
+
 def test_warp_with_device_built_ibis_rows_is_bit_exact_against_the_oracle():
     w, h = 640, 360
     fr = S.SyntheticFrame("YUV422P16LE", w, h, seed=9, flags=abi.FLAG_HAS_IBIS_DATA)

@@ -1,0 +1,94 @@
+"""Fuzz audit of the certified first pass (gfw_frame.hip pass1_fast): 200 seeded random clips — lens coefficients, focal length,
+principal point, field of view 0.5-3, camera rotation up to 15 degrees per axis, readout time +-30 ms at up to 250 deg/s, vertical and
+horizontal rolling shutter, sizes up to 8K — through the kernel's audit instantiation, which recomputes the exact rolling-shutter row
+of EVERY certified pixel (cpu_undistort.rs:465-482): not one certificate may be wrong, and the measured |approximate - exact| gap must
+stay inside half of the certificate half-width E the host derived (gfw_api.hip p1_setup).  The pixels' content is irrelevant here
+(zero planes on the device); parity of the outputs is the other tests' business."""
+import math
+
+import numpy as np
+import pytest
+
+from gyroflow_amd import abi, synthetic as S, warp
+
+pytestmark = pytest.mark.gpu
+
+
+def rot(ax, ay, az):
+    cx, sx, cy, sy, cz, sz = math.cos(ax), math.sin(ax), math.cos(ay), math.sin(ay), math.cos(az), math.sin(az)
+    rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return rz @ ry @ rx
+
+
+def random_clip(rng, w, h):
+    lens = S.gopro_style_lens(w, h)
+    f = rng.uniform(0.3, 1.2) * w
+    lens["f"] = (f, f * rng.uniform(0.98, 1.02))
+    lens["c"] = (w * rng.uniform(0.45, 0.55), h * rng.uniform(0.45, 0.55))
+    lens["k"] = [rng.uniform(-0.05, 0.3), rng.uniform(-0.1, 0.1), rng.uniform(-0.05, 0.05), rng.uniform(-0.02, 0.02)] + [0.0] * 8
+    fov = rng.uniform(0.5, 3.0)
+    hrs = bool(rng.integers(0, 4) == 0)
+    readout = rng.uniform(-30.0, 30.0)
+    if abs(readout) < 0.5:
+        readout = 8.0
+    fr = S.SyntheticFrame("YUV422P16LE" if rng.integers(0, 2) else "NV12", w, h, seed=int(rng.integers(1, 1 << 30)), lens=lens, fov=fov,
+                          readout_ms=readout, horizontal_rs=hrs, pixels=False)
+    # the per-row matrices: base orientation up to 15 degrees per axis, angular rates up to 250 deg/s over the readout
+    rows = fr.matrices.shape[0]
+    base = np.radians(rng.uniform(-15.0, 15.0, 3))
+    rate = np.radians(rng.uniform(-250.0, 250.0, 3)) * (readout / 1000.0)
+    nk = S.new_k(lens, fov, w, h)
+    t = (np.arange(rows) / max(rows - 1, 1)) - 0.5
+    m = np.zeros((rows, 14), dtype=np.float32)
+    for y in range(rows):
+        r = rot(*(base + rate * t[y]))
+        r[0, 1] *= -1.0; r[0, 2] *= -1.0; r[1, 0] *= -1.0; r[2, 0] *= -1.0
+        m[y, :9] = np.linalg.inv(nk @ r).reshape(9).astype(np.float32)
+    fr.matrices = m
+    return fr
+
+
+def audit_device(fr):
+    import torch
+    dev = torch.device("cuda", 0)
+    src = [torch.zeros(pl["size"][2] * pl["size"][1], dtype=torch.uint8, device=dev) for pl in fr.planes]
+    dst = [torch.zeros(pl["out_size"][2] * pl["out_size"][1], dtype=torch.uint8, device=dev) for pl in fr.planes]
+    bufs = [warp.device_buffers(s.data_ptr(), s.numel(), pl["size"], d.data_ptr(), d.numel(), pl["out_size"]) for s, d, pl in zip(src, dst, fr.planes)]
+    params = [pl["params"] for pl in fr.planes]
+    types = [pl["pixel_type"] for pl in fr.planes]
+    be = warp.Backend(params[0], types[0], fr.model, fr.digital, bufs[0])
+    try:
+        be.set_option(abi.OPT_KERNEL_VARIANT, 3)
+        be.get_audit(reset=True)
+        be.undistort_frame(bufs, params, types, fr.matrices)
+        be.synchronize()
+        return warp.last_backend(), be.get_audit_full()
+    finally:
+        be.close()
+
+
+SIZES = [(320, 180), (640, 360), (960, 540), (1280, 720), (1920, 1080)]
+
+
+def test_two_hundred_random_clips_never_produce_a_wrong_certificate():
+    rng = np.random.default_rng(0x9F10)
+    served, skipped, worst_ratio, pixels, certified = 0, 0, 0.0, 0, 0
+    for i in range(200):
+        w, h = (7680, 4320) if i == 57 else (3840, 2160) if i in (11, 101, 151) else SIZES[int(rng.integers(0, len(SIZES)))]
+        fr = random_clip(rng, w, h)
+        backend, a = audit_device(fr)
+        if backend != "yuv_fused_p1":                       # the host declined the certified pass (ray range beyond the table, E too wide): exact first pass
+            skipped += 1
+            continue
+        served += 1
+        assert a["certified1_wrong"] == 0 and a["out_of_range"] == 0, (i, w, h, a)
+        assert a["certified1"] + a["queued1"] + a["queue_overflow"] == w * h, (i, a)
+        assert a["pass1_eps_px"] > 0.0 and a["pass1_gap_px"] < 0.5 * a["pass1_eps_px"], (i, w, h, a)
+        worst_ratio = max(worst_ratio, a["pass1_gap_px"] / a["pass1_eps_px"])
+        pixels += w * h
+        certified += a["certified1"]
+    print("certified first pass: %d clips served (%d declined by the host), %.1f %% of %d pixels certified, 0 wrong; worst gap / E = %.3f"
+          % (served, skipped, 100.0 * certified / max(pixels, 1), pixels, worst_ratio))
+    assert served >= 120, (served, skipped)
