@@ -6,9 +6,9 @@
 A "step" is one pass of the hot path over one synthetic frame: all planes of a 4K (3840x2160) u16 4:2:2 frame
 (BASELINE.json configs[1], "C2": planar YUV422P16LE = 3 x Luma16, GoPro-style opencv_fisheye lens, per-row
 rolling-shutter matrices) warped through libgfwarp's C ABI from buffers already resident in HBM.  The steps go to the
-library the way a render loop hands it a clip: `gfw_undistort_clip` calls of `--clip` frames each (default 32; exactly K
+library the way a render loop hands it a clip: `gfw_undistort_clip` calls of `--clip` frames each (default 8; exactly K
 frames are warped in the timed region), served by the context's run-time specialised kernel (GFW_OPT_JIT = 2: built
-during the warm-up, `config.jit` reports the build) in launches of up to 32 frames.
+during the warm-up, `config.jit` reports the build) in launches of up to 8 frames.
 
 Process model.  Started plainly, this file is a *launcher*: it spawns one worker process per GPU (RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* in the environment, rendezvous on 127.0.0.1), relays rank 0's JSON line and exits with the
@@ -48,7 +48,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FMT, WIDTH, HEIGHT = "YUV422P16LE", 3840, 2160
 N_RESIDENT = 64                  # distinct source frames + per-row matrix tables resident in HBM, cycled by the steps
                                  # (SURVEY.md 8d "64 distinct resident source frames cycled": 2.1 GB, far beyond L2 + MALL)
-N_DST = 32                       # destination frame sets written round-robin (the frames of one clip launch are in flight together: one set each)
+N_DST = 8                        # destination frame sets written round-robin (the frames of one clip launch are in flight together: one set each)
 N_CHECK = 3                      # frames of the timed region compared with the oracle afterwards
 TRAFFIC_FILE = os.path.join("profiles", "r03_c2_traffic.json")
 
@@ -66,7 +66,7 @@ def parse_args(argv):
     ap.add_argument("--no-retry", action="store_true", help=argparse.SUPPRESS)      # the default since round 3
     ap.add_argument("--jit", type=int, default=2, choices=(0, 1, 2),
                     help="GFW_OPT_JIT of the contexts: 2 (default) the per-clip specialised kernel is built during the warm-up; 0 ahead-of-time kernels only")
-    ap.add_argument("--clip", type=int, default=32,
+    ap.add_argument("--clip", type=int, default=8,
                     help="frames per gfw_undistort_clip call (resident-matrices workloads); 1 = one gfw_undistort_frame call per frame")
     ap.add_argument("--preheat-ms", type=float, default=60.0,
                     help="untimed launches of the same workload for this long right before the timed region (declared in config.preheat_ms): "
@@ -423,12 +423,18 @@ def worker(args):
         else:
             calls[j]()
 
+    ENQ_WINDOW = 256                                   # steps over which the host's own enqueue cost is read: beyond a few hundred frames in flight
+    enq_mark = [None, 0]                               # the runtime's bounded rings make the host wait for the GPU, which is not host work
+
     def run_steps(n, bracket_every=0):
         """steps 0 .. n-1 of the workload, as clip calls or frame by frame; every bracket_every-th launch has its kernel time taken"""
         set_opt, ctxps = be.lib.gfw_set_option, [b.ctx for b in all_bes]
+        enq_mark[0], enq_mark[1] = None, 0
         if clip_n > 1:
             for c, k0 in enumerate(range(0, n, clip_n)):
                 ln = min(clip_n, n - k0)
+                if enq_mark[0] is None and k0 >= ENQ_WINDOW:
+                    enq_mark[0], enq_mark[1] = time.perf_counter(), k0
                 if bracket_every and c % 2 == 0:        # a launch carries clip_n frames: every other one is bracketed
                     set_opt(ctxps[0], abi.OPT_PROFILE, 1)
                     clip_step(k0, ln)
@@ -437,6 +443,8 @@ def worker(args):
                     clip_step(k0, ln)
         elif bracket_every > 1:
             for k in range(n):
+                if enq_mark[0] is None and k >= ENQ_WINDOW:
+                    enq_mark[0], enq_mark[1] = time.perf_counter(), k
                 if k % bracket_every == 0:
                     ctxp2 = ctxps[k % n_streams]
                     set_opt(ctxp2, abi.OPT_PROFILE, 1)
@@ -470,6 +478,9 @@ def worker(args):
     t0 = time.perf_counter()
     run_steps(n_steps, pe)
     t_enq = time.perf_counter() - t0                 # host time to enqueue the steps (the GPU runs behind it)
+    enq_steps = n_steps
+    if enq_mark[0] is not None:                      # long runs: the first ENQ_WINDOW steps, before the queues fill and the host starts waiting for the GPU
+        t_enq, enq_steps = enq_mark[0] - t0, enq_mark[1]
     torch.cuda.synchronize(dev)
     shard.barrier(dist)
     t1 = time.perf_counter()
@@ -523,7 +534,7 @@ def worker(args):
         "config": {"workload": workload + ("" if n_streams == 1 else "; frames dealt to %d contexts / HIP streams in turn (bracketed kernel times overlap their neighbours)" % n_streams),
                    "streams_per_rank": n_streams, "frames_per_rank": n_steps, "frames_total": frames_done, "parallelism": "frame-sharded x%d" % world,
                    "backend": warp.last_backend(), "checksum": crc, "rank_checksums": rank_crcs,
-                   "host_enqueue_ms_per_step": round(t_enq / max(n_steps, 1) * 1e3, 5),
+                   "host_enqueue_ms_per_step": round(t_enq / max(enq_steps, 1) * 1e3, 5),
                    "clip_frames_per_call": clip_n, "preheat_ms": round(preheat_ms, 1),
                    "jit": {"mode": args.jit, "state": {0: "none", 1: "compiling", 2: "ready", 3: "failed"}.get(jit_state[0], str(jit_state[0])),
                            "compile_ms": round(jit_state[1], 1), "log": jit_state[2][-300:] if jit_state[0] == 3 else ""},

@@ -668,6 +668,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
         if ((bytes_per_sample == 2) && ((p.stride | b.output.stride) & 1)) return false;
         if ((bytes_per_sample == 4) && ((p.stride | b.output.stride) & 3)) return false;
         if ((int64_t)b.input.height * p.stride >= (1ll << 31) || (int64_t)b.output.height * b.output.stride >= (1ll << 31)) return false;   // 32-bit offsets
+        if (p.stride >= (1 << 23) || b.output.stride >= (1 << 23) || b.input.height >= (1 << 23) || b.output.height >= (1 << 23)) return false;   // 24-bit row-offset multiplies
     }
     // stretch divisions (cpu_undistort.rs:222-223) other than "skipped" (<= 0.001) or the identity x/1 go the generic way
     if ((p0.input_horizontal_stretch > 0.001f && p0.input_horizontal_stretch != 1.0f) ||
@@ -758,7 +759,24 @@ struct ClipBatch {
     GfwClipArgs CA;
     hipFunction_t fn = nullptr;
     int grid = 0, n = 0;
+    const gfw_buffers *first = nullptr;          // planes of the frame that opened the pending launch (fully validated by run_planes)
+    const char *backend = "";
 };
+static bool clip_same_shape(const gfw_buffers *a, const gfw_buffers *b, int nplanes) {
+    for (int i = 0; i < nplanes; ++i) {
+        const gfw_buffer_desc *x[2] = {&a[i].input, &a[i].output}, *y[2] = {&b[i].input, &b[i].output};
+        for (int k = 0; k < 2; ++k) {
+            if (x[k]->width != y[k]->width || x[k]->height != y[k]->height || x[k]->stride != y[k]->stride || x[k]->kind != y[k]->kind ||
+                x[k]->len != y[k]->len || x[k]->has_rect != y[k]->has_rect || x[k]->has_rotation != y[k]->has_rotation ||
+                memcmp(x[k]->rect, y[k]->rect, sizeof(x[k]->rect)) || x[k]->rotation != y[k]->rotation || !y[k]->data) return false;
+        }
+    }
+    return true;
+}
+static bool clip_ring_table(gfw_ctx *c, const float *m) {          // a table of gfw_build_matrices' cross-stream ring (ordered by events)
+    for (int i = 0; i < gfw_ctx::kBuiltSlots; ++i) if (c->bslots[i].buf.ptr == (const void *)m && c->bslots[i].built) return true;
+    return false;
+}
 static int clip_flush(gfw_ctx *c, ClipBatch *b) {
     if (!b || b->n == 0) return GFW_OK;
     b->CA.n_frames = b->n; b->CA.pad_ = 0;
@@ -812,20 +830,18 @@ static std::string bake_header(const GfwYuvArgs &Y) {
     }
     return o;
 }
-// Waves per SIMD the specialised instantiation is budgeted for (measured on C2: 6 -> 72.8, 7 -> 67.3, 8 -> 70.5 us with the table atanf)
+// Waves per SIMD the specialised instantiation is budgeted for.  Measured on C2 (us per frame; gpurun_out/r03b, r03e): bilinear 6 -> 65.4,
+// 7 -> 63.2, 8 -> 64.7; Lanczos4 6 -> 202.9, 7 -> 190.1; bicubic 6 -> 104.4, 7 -> 105.3
 static int jit_waves(int taps) {
     static const int forced = getenv("GFW_JIT_WAVES") ? atoi(getenv("GFW_JIT_WAVES")) : 0;      // experiments
     if (forced >= 1 && forced <= 8) return forced;
-    return taps == 2 ? 7 : 6;
+    (void)taps;
+    return 7;
 }
 // The specialised kernel for this frame's arguments, or nullptr (not eligible / not wanted / not ready / failed): the caller then
 // launches the ahead-of-time kernel.
 static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps, int n0, int dw, int dh, bool interleaved, bool fast1, int *grid) {
     if (c->jit_mode == 0 || c->kernel_variant != 0 || Y.model != GFW_MODEL_OPENCV_FISHEYE || Y.extras || Y.audit || Y.ablate) return nullptr;
-    // bilinear only for now: the baked bicubic / Lanczos4 instantiations measured SLOWER than the ahead-of-time ones on MI355X (C2: 329 against
-    // ~125 us, 394 against 203 us: gpurun_out/r03c) — GFW_JIT_LUT=1 builds them all the same, for the investigation
-    static const bool jit_lut = getenv("GFW_JIT_LUT") != nullptr;
-    if (taps != 2 && !jit_lut) return nullptr;
     if (!gfw_jit_available()) { c->jit_info.state = GFW_JIT_UNAVAILABLE; c->jit_info.log = "libhiprtc.so not found"; return nullptr; }
     std::string hdr = bake_header(Y);
     if (hdr == c->jit_header) { if (c->jit_seen < (1 << 30)) ++c->jit_seen; }
@@ -914,13 +930,13 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
         hipFunction_t jf = jit_for(c, Y, bps, params[0].interpolation, n0, dw, dh, interleaved, fast1, &jgrid);
         bool all_device = c->matrices_on_device != 0;
         for (int i = 0; i < nplanes; ++i) all_device = all_device && planes[i].input.kind != GFW_BUF_HOST && planes[i].output.kind != GFW_BUF_HOST;
-        if (jf && batch && all_device) {
+        if (jf && batch && all_device && c->bslot_cur < 0 && c->mslot_cur < 0) {      // (a table of the cross-stream ring is ordered by events: frame by frame)
             // the frame joins the clip launch being assembled; a frame that does not share the pending ones' kernel or first-pass table goes out behind them
             if (batch->n > 0 && (batch->fn != jf || batch->CA.Y.p1_table != Y.p1_table || batch->CA.Y.p1_rho_max != Y.p1_rho_max ||
                                  batch->CA.Y.p1_rho_scale != Y.p1_rho_scale || batch->CA.Y.p1_eps != Y.p1_eps)) {
                 const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc;
             }
-            if (batch->n == 0) { batch->CA.Y = Y; batch->fn = jf; batch->grid = jgrid; }
+            if (batch->n == 0) { batch->CA.Y = Y; batch->fn = jf; batch->grid = jgrid; batch->first = planes; batch->backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit"; }
             GfwFrameDyn &F = batch->CA.fr[batch->n++];
             for (int i = 0; i < 4; ++i) { F.src[i] = Y.pl[i].src; F.dst[i] = Y.pl[i].dst; }
             F.matrices = Y.matrices;
@@ -991,9 +1007,23 @@ int gfw_undistort_clip(gfw_ctx *c, int n_frames, int nplanes, const gfw_buffers 
     for (int i = 0; i < nplanes; ++i)
         if (pixel_types[i] < 0 || pixel_types[i] >= GFW_PIX_COUNT) { set_error("plane %d: unknown pixel type %d", i, pixel_types[i]); return GFW_ERR_INVALID_ARGUMENT; }
     // the frame loop of a render (rendering/mod.rs:487-547 calls process_pixels once per frame), here on the library side: frames that
-    // share the specialised kernel leave in launches of up to GFW_CLIP_MAX (32) frames, everything else exactly as gfw_undistort_frame
+    // share the specialised kernel leave in launches of up to GFW_CLIP_MAX (8) frames, everything else exactly as gfw_undistort_frame
     ClipBatch batch;
     for (int f = 0; f < n_frames; ++f) {
+        // A frame shaped exactly like the one that opened the pending launch (same descriptions but for the pointers; the parameters are
+        // shared by construction) needs none of the per-frame validation again: its pointers join the launch.  ~10 us -> < 1 us of host time.
+        if (batch.n > 0 && batch.n < GFW_CLIP_MAX && c->matrices_on_device == 2 && matrices[f] && clip_same_shape(batch.first, planes + (size_t)f * nplanes, nplanes) &&
+            !clip_ring_table(c, matrices[f])) {
+            GfwFrameDyn &F = batch.CA.fr[batch.n++];
+            for (int i = 0; i < 4; ++i) {
+                F.src[i] = i < nplanes ? (const uint8_t *)planes[(size_t)f * nplanes + i].input.data : nullptr;
+                F.dst[i] = i < nplanes ? (uint8_t *)planes[(size_t)f * nplanes + i].output.data : nullptr;
+            }
+            F.matrices = matrices[f];
+            c->last_backend = batch.backend;
+            if (batch.n == GFW_CLIP_MAX) { const int frc = clip_flush(c, &batch); if (frc != GFW_OK) return frc; }
+            continue;
+        }
         const int rc = run_planes(c, nplanes, planes + (size_t)f * nplanes, params, pixel_types, matrices[f], matrix_count, nullptr, 0, &batch);
         if (rc != GFW_OK) { (void)clip_flush(c, &batch); return rc; }
     }

@@ -36,8 +36,9 @@ __device__ __forceinline__ float gfw_div_prepared(float a, const GfwRcp &d) {
 }
 __device__ __forceinline__ float gfw_div_lean(float a, float b) { return gfw_div_prepared(a, gfw_rcp_prepare(b)); }
 
-// RN(sqrt(x)) for x == 0 or x in [2^-80, 2^80]: hardware sqrt (<= 1 ulp) then pick between s-1ulp, s, s+1ulp by
-// the sign of the exact residuals x - s_down*s and x - s_up*s (the test the generic lowering uses).
+// RN(sqrt(x)) for x == +-0 or x in [2^-80, 2^80]: hardware sqrt (<= 1 ulp) then pick between s-1ulp, s, s+1ulp by
+// the sign of the exact residuals x - s_down*s and x - s_up*s (the test the generic lowering uses).  Zero needs no case of its own:
+// s = +-0, its lower neighbour's bit pattern is a NaN (both comparisons fail) and the upper neighbour's residual is a signed zero.
 __device__ __forceinline__ float gfw_sqrt_lean(float x) {
     const float s = gfw_hw_sqrt(x);
     const float s_dn = gfw_u2f(gfw_f2u(s) - 1u);
@@ -46,7 +47,7 @@ __device__ __forceinline__ float gfw_sqrt_lean(float x) {
     const float vs = __builtin_fmaf(-s_up, s, x);
     float r = (vp <= 0.0f) ? s_dn : s;
     r = (vs > 0.0f) ? s_up : r;
-    return (x == 0.0f) ? x : r;
+    return r;
 }
 
 // glibc-2.35 atanf (gfw_math.h: gfw_atanf) for x >= 0 (or NaN), select-based: one division, no branches.

@@ -117,7 +117,7 @@ struct LeanOps {
     }
     static __device__ __forceinline__ float div(float a, float b) { return gfw_div_lean(a, b); }
     static __device__ __forceinline__ float sqrt(float x) {
-        if (__builtin_expect(x < 8.271806125530277e-25f && x != 0.0f, 0)) return sqrtf(x);    // below 2^-80: generic path
+        if (__builtin_expect(x < 8.271806125530277e-25f, 0)) return sqrtf(x);    // below 2^-80 (zero included: the optical centre): generic path
         return gfw_sqrt_lean(x);
     }
     // glibc atanf, wave-specialised: when every active lane is below 0.4375 the reduction (and its division)
@@ -195,15 +195,22 @@ __device__ __forceinline__ GfwPt rd(float px, float py, const float4 ma, const f
     const float Y = (px * ma.w) + (py * mb.x) + mb.y;
     const float W = (px * mb.z) + (py * mb.w) + m8;
     GfwPt o{0.0f, 0.0f, false};
-    if (!(W > 0.0f)) return o;
-    if (L.rl2 > 0.0f && (X * X + Y * Y) > L.rl2 * W) return o;
-    o.ok = true;
     if (MODEL == GFW_MODEL_OPENCV_FISHEYE) {
-        // proven operand range of the lean divide: |X|,|Y| <= 2^19, W in [2^-20, 2^20]  (=> |a|,|b| <= 2^39)
+        // proven operand range of the lean divide: |X|,|Y| <= 2^19, W in [2^-20, 2^20]  (=> |a|,|b| <= 2^39).  The range test subsumes the
+        // reference's `w > 0` (:137), so the usual pixel pays one test; everything else — non-positive or tiny W, huge operands, NaN —
+        // takes the side branch with the reference's own order of tests and the generic IEEE expansions.
         const float mag = fmaxf(fmaxf(fabsf(X), fabsf(Y)), W);
         const bool lean = (mag <= 524288.0f) && (W >= 9.5367431640625e-07f);
-        if (__builtin_expect(lean, 1)) fisheye_project<LeanOps>(X, Y, W, L, AF(k_all_zero) != 0, o.x, o.y);
-        else fisheye_project<IeeeOps>(X, Y, W, L, AF(k_all_zero) != 0, o.x, o.y);      // generic IEEE expansions
+        if (__builtin_expect(lean, 1)) {
+            if (L.rl2 > 0.0f && (X * X + Y * Y) > L.rl2 * W) return o;
+            o.ok = true;
+            fisheye_project<LeanOps>(X, Y, W, L, AF(k_all_zero) != 0, o.x, o.y);
+        } else {
+            if (!(W > 0.0f)) return o;
+            if (L.rl2 > 0.0f && (X * X + Y * Y) > L.rl2 * W) return o;
+            o.ok = true;
+            fisheye_project<IeeeOps>(X, Y, W, L, AF(k_all_zero) != 0, o.x, o.y);      // generic IEEE expansions
+        }
     } else {
         // every lens model through the generic IEEE routines, plus the optional stages of rotate_and_distort in the
         // reference's order: refraction (:143-152), model, *f, IBIS/OIS rotate + shift (:157-165), +c, digital lens (:216-220)
@@ -258,6 +265,14 @@ __device__ __forceinline__ float min_limit(float v, float limit) {
     float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(v), "s"(limit)); return r;
 }
 
+// Byte offset of a row: 24-bit multiply (v_mul_i32_i24 / v_mad_i32_i24, full rate) — the 32-bit v_mul_lo_u32 is a quarter-rate instruction and
+// sat in every sample's address.  Row indices and pitches of the planes this kernel serves are below 2^23 (host-checked); a sample far
+// outside the plane may wrap here, but such a sample never passes the interior test that guards the use of the offset.
+__device__ __forceinline__ int row_off(int y, int stride) {
+    int r;                                     // spelled out: the compiler turns the mul24 intrinsic back into a 32-bit multiply where it cannot prove the range
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(y), "s"(stride));
+    return r;
+}
 // `as u32` of a float known to be finite or NaN: v_cvt_u32_f32 (truncate; negative and NaN -> 0; saturating)
 __device__ __forceinline__ uint32_t gfw_f2u_trunc(float v) { uint32_t r; asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(v)); return r; }
 
@@ -427,11 +442,11 @@ __device__ __forceinline__ void sample_store(float u, float v, bool ok, const Gf
     if (ok) {
         const Bins<I> b = make_bins<I>(u, v, lut);
         if (__builtin_expect((bins_inside<T, N, I>(b, P.w, P.h)), 1))
-            taps_inside<T, N, I>(P.src, b.sy * P.src_stride + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
+            taps_inside<T, N, I>(P.src, row_off(b.sy, P.src_stride) + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
         else
             taps_edge<T, N, I>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
     }
-    store_px<T, N>(P.dst, oy * P.dst_stride + ox * (int)(N * sizeof(T)), out, px_needs_sat<T>(bg, N, limit));
+    store_px<T, N>(P.dst, row_off(oy, P.dst_stride) + ox * (int)(N * sizeof(T)), out, px_needs_sat<T>(bg, N, limit));
 }
 // Planar planes of identical geometry (U and V; or G,B,R,A of a planar float frame): one set of bins / weights /
 // offsets, one gather set per plane.
@@ -445,9 +460,9 @@ __device__ __forceinline__ void sample_store_shared(float u, float v, bool ok, c
     if (ok) {
         b = make_bins<I>(u, v, lut);
         inside = bins_inside<T, 1, I>(b, P0.w, P0.h);
-        off0 = b.sy * P0.src_stride + b.sx * (int)sizeof(T);
+        off0 = row_off(b.sy, P0.src_stride) + b.sx * (int)sizeof(T);
     }
-    const int doff = oy * P0.dst_stride + ox * (int)sizeof(T);
+    const int doff = row_off(oy, P0.dst_stride) + ox * (int)sizeof(T);
     #pragma unroll 1
     for (int pi = first; pi <= last; ++pi) {
         float o = pl[pi].bg[0];
@@ -470,9 +485,9 @@ __device__ __forceinline__ void sample_store_shared_refs(float u, float v, bool 
     if (ok) {
         b = make_bins<I>(u, v, lut);
         inside = bins_inside<T, 1, I>(b, Pa.w, Pa.h);
-        off0 = b.sy * Pa.src_stride + b.sx * (int)sizeof(T);
+        off0 = row_off(b.sy, Pa.src_stride) + b.sx * (int)sizeof(T);
     }
-    const int doff = oy * Pa.dst_stride + ox * (int)sizeof(T);
+    const int doff = row_off(oy, Pa.dst_stride) + ox * (int)sizeof(T);
     auto one = [&](const GfwYuvPlane &P) {
         float o = P.bg[0];
         if (ok) {
@@ -592,7 +607,7 @@ __device__ __forceinline__ void sample_store2(float u, float v, bool ok, const G
     if (ok) {
         const Bins2 b = make_bins2(u, v);
         if (__builtin_expect((unsigned)b.sx < (unsigned)(P.w - 1) && (unsigned)b.sy < (unsigned)(P.h - 1), 1)) {
-            const int off0 = b.sy * P.src_stride + b.sx * (int)(N * sizeof(T));
+            const int off0 = row_off(b.sy, P.src_stride) + b.sx * (int)(N * sizeof(T));
             if (range_ok(aud, off0, 2 * N * sizeof(T), P.src_len) && range_ok(aud, (int64_t)off0 + P.src_stride, 2 * N * sizeof(T), P.src_len)) {
                 if constexpr (!is_f32<T>::value && (N == 1 || N == 2) && sizeof(T) == 1) {
                     // integer-dot taps: the pixel value comes out as an integer; store it and leave
@@ -621,7 +636,7 @@ __device__ __forceinline__ void sample_store2(float u, float v, bool ok, const G
         } else
             taps_edge2<T, N>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
     }
-    const int doff = oy * P.dst_stride + ox * (int)(N * sizeof(T));
+    const int doff = row_off(oy, P.dst_stride) + ox * (int)(N * sizeof(T));
     if (range_ok(aud, doff, N * sizeof(T), P.dst_len)) store_px<T, N>(P.dst, doff, out, px_needs_sat<T>(bg, N, limit));
 }
 // Planar planes of identical geometry (U and V; or G,B,R,A of a planar float frame): one set of bins / weights /
@@ -635,9 +650,9 @@ __device__ __forceinline__ void sample_store_shared2(float u, float v, bool ok, 
     if (ok) {
         b = make_bins2(u, v);
         inside = (unsigned)b.sx < (unsigned)(P0.w - 1) && (unsigned)b.sy < (unsigned)(P0.h - 1);
-        off0 = b.sy * P0.src_stride + b.sx * (int)sizeof(T);
+        off0 = row_off(b.sy, P0.src_stride) + b.sx * (int)sizeof(T);
     }
-    const int doff = oy * P0.dst_stride + ox * (int)sizeof(T);
+    const int doff = row_off(oy, P0.dst_stride) + ox * (int)sizeof(T);
     #pragma unroll 1
     for (int pi = first; pi <= last; ++pi) {
         float o = pl[pi].bg[0];
@@ -656,9 +671,9 @@ __device__ __forceinline__ void sample_store_shared2_refs(float u, float v, bool
     if (ok) {
         b = make_bins2(u, v);
         inside = (unsigned)b.sx < (unsigned)(Pa.w - 1) && (unsigned)b.sy < (unsigned)(Pa.h - 1);
-        off0 = b.sy * Pa.src_stride + b.sx * (int)sizeof(T);
+        off0 = row_off(b.sy, Pa.src_stride) + b.sx * (int)sizeof(T);
     }
-    const int doff = oy * Pa.dst_stride + ox * (int)sizeof(T);
+    const int doff = row_off(oy, Pa.dst_stride) + ox * (int)sizeof(T);
     auto one = [&](const GfwYuvPlane &P) {
         float o = P.bg[0];
         if (ok) {
@@ -681,7 +696,7 @@ __device__ __forceinline__ void sample_store_uv2(float u, float v, bool ok, cons
     if (ok) {
         const Bins2 b = make_bins2(u, v);
         if (__builtin_expect((unsigned)b.sx < (unsigned)(PU.w - 1) && (unsigned)b.sy < (unsigned)(PU.h - 1), 1)) {
-            const int off0 = b.sy * PU.src_stride + b.sx * (int)sizeof(T);
+            const int off0 = row_off(b.sy, PU.src_stride) + b.sx * (int)sizeof(T);
             const int top = PU.src_len < PV.src_len ? PU.src_len : PV.src_len;
             if (range_ok(aud, off0, 2 * sizeof(T), top) && range_ok(aud, (int64_t)off0 + PU.src_stride, 2 * sizeof(T), top)) {
                 if constexpr (!is_f32<T>::value && sizeof(T) == 1) {
@@ -704,7 +719,7 @@ __device__ __forceinline__ void sample_store_uv2(float u, float v, bool ok, cons
             taps_edge2<T, 1>(PV.src, PU.src_stride, b, PU.w, PU.h, &bg_v, lim_v, &ov);
         }
     }
-    const int doff = oy * PU.dst_stride + ox * (int)sizeof(T);
+    const int doff = row_off(oy, PU.dst_stride) + ox * (int)sizeof(T);
     if (!range_ok(aud, doff, sizeof(T), PU.dst_len < PV.dst_len ? PU.dst_len : PV.dst_len)) return;
     store_px<T, 1>(PU.dst, doff, &ou, px_needs_sat<T>(&bg_u, 1, lim_u));
     store_px<T, 1>(PV.dst, doff, &ov, px_needs_sat<T>(&bg_v, 1, lim_v));
@@ -736,13 +751,13 @@ __device__ __forceinline__ void sample_only(float u, float v, const GfwYuvPlane 
     if (I == 2) {
         const Bins2 b = make_bins2(u, v);
         if ((unsigned)b.sx < (unsigned)(P.w - 1) && (unsigned)b.sy < (unsigned)(P.h - 1))
-            taps_inside2<T, N>(P.src, b.sy * P.src_stride + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
+            taps_inside2<T, N>(P.src, row_off(b.sy, P.src_stride) + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
         else
             taps_edge2<T, N>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
     } else {
         const Bins<I> b = make_bins<I>(u, v, lut);
         if (bins_inside<T, N, I>(b, P.w, P.h))
-            taps_inside<T, N, I>(P.src, b.sy * P.src_stride + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
+            taps_inside<T, N, I>(P.src, row_off(b.sy, P.src_stride) + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
         else
             taps_edge<T, N, I>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
     }
@@ -756,7 +771,7 @@ __device__ __forceinline__ void feather_store(float ux, float uy, const Feather 
     sample_only<T, N, I>(map_c<INF_SAFE>(f.x2, mul_x, MP.den_x, MP.rcp_x), map_c<INF_SAFE>(f.y2, mul_y, MP.den_y, MP.rcp_y), P, bg, limit, lut, c2);
     #pragma unroll
     for (int c = 0; c < N; ++c) px[c] = c1[c] * f.alpha + c2[c] * (1.0f - f.alpha);
-    store_px<T, N>(P.dst, oy * P.dst_stride + ox * (int)(N * sizeof(T)), px);
+    store_px<T, N>(P.dst, row_off(oy, P.dst_stride) + ox * (int)(N * sizeof(T)), px);
 }
 
 

@@ -251,7 +251,7 @@ int gfw_undistort_frame(gfw_ctx *ctx, int nplanes,
  * `params` (nplanes entries) and `pixel_types` are shared by all frames; matrices[f] is frame f's table, with the meaning
  * GFW_OPT_MATRICES_ON_DEVICE gives it.  Frames are warped in order on the context's stream with the results of
  * gfw_undistort_frame; frames with HIP_DEVICE buffers and device-resident tables that share the context's run-time specialised
- * kernel (GFW_OPT_JIT) leave in launches of up to 32 frames, so that the occupancy tail of one frame is filled by the next
+ * kernel (GFW_OPT_JIT) leave in launches of up to 8 frames, so that the occupancy tail of one frame is filled by the next
  * (the frames of one launch are in flight together: their destination buffers must be distinct). */
 int gfw_undistort_clip(gfw_ctx *ctx, int n_frames, int nplanes,
                        const gfw_buffers *planes,
@@ -299,7 +299,7 @@ int   gfw_jit_status(gfw_ctx *ctx, double *compile_ms, char *log, size_t cap);
 /* With GFW_OPT_PROFILE on: accumulated warp-kernel time (ms, hipEventElapsedTime on the context stream)
  * and launch count since the last reset; synchronises the stream.  reset != 0 clears the accumulators. */
 int   gfw_get_profile(gfw_ctx *ctx, double *kernel_ms, int64_t *launches, int reset);
-/* the same, plus the number of frames the bracketed launches covered (a gfw_undistort_clip launch carries up to 32) */
+/* the same, plus the number of frames the bracketed launches covered (a gfw_undistort_clip launch carries up to 8) */
 int   gfw_get_profile_frames(gfw_ctx *ctx, double *kernel_ms, int64_t *launches, int64_t *frames, int reset);
 
 /* Thread-local, human-readable description of the last failure. */

@@ -102,7 +102,7 @@ def classify(fr, ref, got, interp, taus=(5e-5, 1e-4, 2e-4, 4e-4, 1e-3), tau_row=
     else:
         with np.errstate(all="ignore"):
             out["max_abs_diff"] = float(np.nanmax(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if len(xs) else 0.0
-    if len(xs) > 6000:
+    if len(xs) > 40000:
         out["note"] = "too many differing pixels to classify"
         return out
     cs = coords_of(fr, list(zip(xs.tolist(), ys.tolist())))

@@ -60,7 +60,7 @@ def test_generic_model_instantiations_keep_their_register_budget(kernels):
             bilinear = "ELi2ELi" in k[".name"].split(tag)[1][:24]
             assert KR.workgroups_per_cu(k) >= 3, (k[".name"], k[".vgpr_count"], k[".group_segment_fixed_size"])
             # six waves per SIMD (measured faster on a digital-lens clip) cost the bilinear ones up to ~1.5 KB of scratch per lane
-            assert k[".private_segment_fixed_size"] <= (2048 if bilinear else 640 if tag.endswith("n1E") else 1024), (k[".name"], k[".private_segment_fixed_size"])
+            assert k[".private_segment_fixed_size"] <= (2048 if bilinear or tag.endswith("n2E") else 768), (k[".name"], k[".private_segment_fixed_size"])
         # only the instantiations the dispatcher can reach are built: the certified first pass exists for the fisheye model alone
         assert not [k for k in gen if "ELi4ELb1ELb" in k[".name"]]
 
