@@ -212,6 +212,9 @@ __device__ __forceinline__ GfwPt rd(float px, float py, const float4 ma, const f
             fisheye_project<IeeeOps>(X, Y, W, L, AF(k_all_zero) != 0, o.x, o.y);      // generic IEEE expansions
         }
     } else {
+        if (!(W > 0.0f)) return o;                                                   // :137
+        if (L.rl2 > 0.0f && (X * X + Y * Y) > L.rl2 * W) return o;                   // :139
+        o.ok = true;
         // every lens model through the generic IEEE routines, plus the optional stages of rotate_and_distort in the
         // reference's order: refraction (:143-152), model, *f, IBIS/OIS rotate + shift (:157-165), +c, digital lens (:216-220)
         float Wd = W;

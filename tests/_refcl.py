@@ -1,7 +1,7 @@
 """Shared helpers of the reference-OpenCL second opinion (tests/test_gpu_ref_opencl.py, tools/ref_residual.py): run the reference's own
 kernel (oracle/_ref/*.co, built by oracle/build_ref_cl.py from /root/reference) through the HIP module API, and classify every pixel on
 which it differs from the oracle by WHY the reference's GPU twin may differ from its CPU path there:
-  bin   the source coordinate (x or y) lies within tau px of a 1/32-px bin edge — OpenCL's atan / pow / native divide are not glibc's,
+  bin   the source coordinate (x or y) lies within max(tau, 4 ulp) px of a 1/32-px bin edge — OpenCL's atan / pow / native divide are not glibc's,
         and the twin rounds the sub-pixel index with convert_int_sat_rtz(0.5 + x) (.cl:355), so a coordinate a few ulp away lands in
         the neighbouring bin
   row   the first-pass coordinate that picks the rolling-shutter row lies within tau_row of a half-integer: the neighbouring row's

@@ -10,8 +10,6 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "gpu_staged: needs a real MI355X; paths written but not yet validated there (tests/test_staged_*.py); "
-                                       "not part of -m gpu")
 
 
 def _have_gpu():
@@ -28,5 +26,5 @@ def pytest_collection_modifyitems(config, items):
         return
     skip = pytest.mark.skip(reason="no GPU visible")
     for item in items:
-        if "gpu" in item.keywords or "gpu_staged" in item.keywords:
+        if "gpu" in item.keywords:
             item.add_marker(skip)
