@@ -1,7 +1,7 @@
 """Shared helpers of the reference-OpenCL second opinion (tests/test_gpu_ref_opencl.py, tools/ref_residual.py): run the reference's own
 kernel (oracle/_ref/*.co, built by oracle/build_ref_cl.py from /root/reference) through the HIP module API, and classify every pixel on
 which it differs from the oracle by WHY the reference's GPU twin may differ from its CPU path there:
-  bin   the source coordinate (x or y) lies within max(tau, 4 ulp) px of a 1/32-px bin edge — OpenCL's atan / pow / native divide are not glibc's,
+  bin   the source coordinate (x or y) lies within max(tau, 4 ulp, 1e-6 of its distance from the principal point) px of a 1/32-px bin edge — OpenCL's atan / pow / native divide are not glibc's,
         and the twin rounds the sub-pixel index with convert_int_sat_rtz(0.5 + x) (.cl:355), so a coordinate a few ulp away lands in
         the neighbouring bin
   row   the first-pass coordinate that picks the rolling-shutter row lies within tau_row of a half-integer: the neighbouring row's
@@ -112,14 +112,16 @@ def classify(fr, ref, got, interp, taus=(5e-5, 1e-4, 2e-4, 4e-4, 1e-3), tau_row=
         cls["bin@%g" % t] = 0
     unexplained = []
     for (x, y), (ok, u, v, ok1, u1, v1) in zip(zip(xs.tolist(), ys.tolist()), cs):
-        def edge_dist(c):
+        def edge_dist(c, centre):
+            """distance of coordinate c to the nearest 1/32-px bin edge, less what the coordinate's magnitude adds to the tolerance's floor:
+            the tolerance is max(tau, 4 ulp(c), 1e-6 |c - centre|) — the twins' builtins (OpenCL atan / sqrt / divide against glibc's) differ
+            by a few ulp RELATIVE to the ray, i.e. in proportion to the distance from the principal point, and a coordinate beyond 1024
+            has an ulp of 1.2e-4 px by itself"""
             t = (np.float32(c) - np.float32(off)) * np.float32(32.0)
             fr_ = float(t) - np.floor(float(t))
-            return abs(fr_ - 0.5) / 32.0
-        if not ok:                                   # the oracle rejects the ray (w <= 0, r_limit): the twin's r-limit test is a different formula
-            cls["invalid"] += 1                      # (cpu_undistort.rs:139 `x^2+y^2 > r_limit^2 * w` against `length(xy / w) > r_limit`, .cl:402)
-            continue
-        d = min(edge_dist(u), edge_dist(v))
+            extra = max(4.0 * float(np.spacing(np.float32(abs(c)))), 1e-6 * abs(float(c) - centre))
+            return abs(fr_ - 0.5) / 32.0 - max(0.0, extra - min(taus))
+        d = min(edge_dist(u, float(pl["params"].c[0])), edge_dist(v, float(pl["params"].c[1])))
         p = pl["params"]
         hrs = bool(p.flags & 16)
         pv = u1 if hrs else v1
