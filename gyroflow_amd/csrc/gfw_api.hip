@@ -21,7 +21,6 @@
 #include "gfw_matrices.h"
 #include "gfw_jit.h"
 #include <stdlib.h>
-#include <algorithm>
 #include <map>
 #include <mutex>
 
@@ -113,8 +112,6 @@ struct gfw_ctx {
     struct StabSlot { DevBuf d; void *h = nullptr; size_t hcap = 0; hipEvent_t done = nullptr; bool used = false; };
     static constexpr int kStabSlots = 4;
     StabSlot sslots[kStabSlots]; int sslot_next = 0;
-    // f32 copies of 8/16-bit source planes for the Lanczos4 sampler of the specialised kernel: one set per frame a clip launch can hold
-    DevBuf f32src[GFW_CLIP_MAX][4]; int f32_next = 0;
     // run-time specialised kernel (gfw_jit.hip): 0 off; 1 build in the background once the context has seen kJitAfter frames of one
     // clip, warp ahead-of-time meanwhile; 2 build at the first frame and wait for it
     int jit_mode = 1;
@@ -269,8 +266,7 @@ void gfw_destroy(gfw_ctx *c) {
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &b : c->stage_src) b.release();
     for (auto &b : c->stage_dst) b.release();
-    c->d_mesh.release(); c->d_p1_table.release(); c->d_audit.release(); c->d_tracks.release(); for (auto &fs : c->f32src) for (auto &fb : fs) fb.release();
-    c->d_offsets.release(); for (auto &ss : c->sslots) { ss.d.release(); if (ss.h) (void)hipHostFree(ss.h); if (ss.done) (void)hipEventDestroy(ss.done); } c->d_prefix.release(); c->d_timings.release(); c->d_batch[0].release(); c->d_batch[1].release();
+    c->d_mesh.release(); c->d_p1_table.release(); c->d_audit.release(); c->d_tracks.release(); c->d_offsets.release(); for (auto &ss : c->sslots) { ss.d.release(); if (ss.h) (void)hipHostFree(ss.h); if (ss.done) (void)hipEventDestroy(ss.done); } c->d_prefix.release(); c->d_timings.release(); c->d_batch[0].release(); c->d_batch[1].release();
     if (c->h_timings) (void)hipHostFree(c->h_timings);
     for (auto &e : c->timing_copied) if (e) (void)hipEventDestroy(e);
     for (auto &b : c->bslots) { b.buf.release(); if (b.built) (void)hipEventDestroy(b.built); if (b.consumed) (void)hipEventDestroy(b.consumed); }
@@ -765,7 +761,6 @@ struct ClipBatch {
     int grid = 0, n = 0;
     const gfw_buffers *first = nullptr;          // planes of the frame that opened the pending launch (fully validated by run_planes)
     const char *backend = "";
-    bool plain = true;                             // the frames' source pointers are the caller's own (no f32 copies): same-shaped frames may join by pointer
 };
 static bool clip_same_shape(const gfw_buffers *a, const gfw_buffers *b, int nplanes) {
     for (int i = 0; i < nplanes; ++i) {
@@ -810,6 +805,7 @@ static std::string bake_header(const GfwYuvArgs &Y) {
     bake_i(o, "cw", Y.cw); bake_i(o, "ch", Y.ch); bake_i(o, "tiles_x", Y.tiles_x); bake_i(o, "tiles_y", Y.tiles_y); bake_i(o, "matrix_count", Y.matrix_count);
     bake_i(o, "hrs", Y.hrs); bake_i(o, "model", Y.model); bake_i(o, "k_all_zero", Y.k_all_zero);
     bake_i(o, "background_mode", Y.background_mode); bake_i(o, "extras", Y.extras); bake_i(o, "ablate", 0);
+    bake_i(o, "digital", (Y.extras & 2) ? Y.common.digital : 0);
     o += "#define GFW_BK_audit ((unsigned long long *)nullptr)\n";
     char nm[48];
     for (int i = 0; i < 2; ++i) { snprintf(nm, sizeof(nm), "f_%d", i); bake_f(o, nm, Y.f[i]); snprintf(nm, sizeof(nm), "c_%d", i); bake_f(o, nm, Y.c[i]);
@@ -845,8 +841,9 @@ static int jit_waves(int taps) {
 }
 // The specialised kernel for this frame's arguments, or nullptr (not eligible / not wanted / not ready / failed): the caller then
 // launches the ahead-of-time kernel.
-static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps, int n0, int dw, int dh, bool interleaved, bool fast1, bool f32src, int *grid) {
-    if (c->jit_mode == 0 || c->kernel_variant != 0 || Y.model != GFW_MODEL_OPENCV_FISHEYE || Y.extras || Y.audit || Y.ablate) return nullptr;
+static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps, int n0, int dw, int dh, bool interleaved, bool fast1, int *grid) {
+    // the specialised instantiation serves the fisheye model, alone or under a digital lens (extras == 2); other extras stay ahead of time
+    if (c->jit_mode == 0 || c->kernel_variant != 0 || Y.model != GFW_MODEL_OPENCV_FISHEYE || (Y.extras & ~2) || Y.audit || Y.ablate) return nullptr;
     if (!gfw_jit_available()) { c->jit_info.state = GFW_JIT_UNAVAILABLE; c->jit_info.log = "libhiprtc.so not found"; return nullptr; }
     std::string hdr = bake_header(Y);
     if (hdr == c->jit_header) { if (c->jit_seen < (1 << 30)) ++c->jit_seen; }
@@ -866,7 +863,6 @@ static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps,
     snprintf(b, sizeof(b), "GFW_JIT_IL=%d", interleaved ? 1 : 0); defs.push_back(b);
     snprintf(b, sizeof(b), "GFW_JIT_RB=%d", gfw_yuv_rows_per_lane(fast1, 0)); defs.push_back(b);
     snprintf(b, sizeof(b), "GFW_JIT_FAST1=%d", fast1 ? 1 : 0); defs.push_back(b);
-    if (f32src) defs.push_back("GFW_JIT_TS=float");                                      // the planes' `src` are f32 copies (run_planes)
     hipFunction_t fn = gfw_jit_get(c->device, c->arch, defs, c->jit_header, c->jit_mode == 2, &c->jit_info);
     if (!fn) return nullptr;
     int g = c->tune_grid > 0 ? c->tune_grid : c->num_cus * waves;
@@ -933,38 +929,7 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
         fill_common(c, &params[0], d_mat, (Y.extras & 32) ? d_mesh : nullptr, (Y.extras & 32) ? (int)mesh_len : 0, Y.common);
         Y.matrices = d_mat;
         int jgrid = 0;
-        // Lanczos4 on 8/16-bit planes through the specialised kernel: the planes are sampled from f32 copies made once per frame
-        // (gfw_to_f32_kernel: 64 conversions + funnel shifts per sample leave the tap loop; same values, same operation order).  Bicubic's 16
-        // taps do not repay the HBM pass; the ahead-of-time kernels keep sampling the planes as they are.
-        const bool f32src = params[0].interpolation == 8 && (bps == 1 || bps == 2) && n0 == 1;
-        GfwYuvArgs Yf;
-        if (f32src) {
-            Yf = Y;
-            for (int i = 0; i < nplanes; ++i) {
-                const int ch = (interleaved && i == 1) ? 2 : 1;
-                Yf.pl[i].src_stride = (int32_t)(((size_t)Y.pl[i].w * ch * sizeof(float) + 255) & ~(size_t)255);
-            }
-        }
-        hipFunction_t jf = jit_for(c, f32src ? Yf : Y, bps, params[0].interpolation, n0, dw, dh, interleaved, fast1, f32src, &jgrid);
-        if (jf && f32src) {
-            DevBuf *ring = c->f32src[c->f32_next];
-            c->f32_next = (c->f32_next + 1) % GFW_CLIP_MAX;
-            GfwToF32Args T;
-            memset(&T, 0, sizeof(T));
-            for (int i = 0; i < nplanes; ++i) {
-                const int ch = (interleaved && i == 1) ? 2 : 1;
-                HIP_TRY(ring[i].ensure((size_t)Yf.pl[i].src_stride * Y.pl[i].h), GFW_ERR_HIP);
-                T.pl[i].src = Y.pl[i].src; T.pl[i].dst = (uint8_t *)ring[i].ptr;
-                T.pl[i].src_stride = Y.pl[i].src_stride; T.pl[i].dst_stride = Yf.pl[i].src_stride;
-                T.pl[i].rows = Y.pl[i].h; T.pl[i].samples = Y.pl[i].w * ch;
-                T.pl[i].vec_ok = (((uintptr_t)Y.pl[i].src | (uintptr_t)Y.pl[i].src_stride) & 15u) == 0;
-                Yf.pl[i].src = (const uint8_t *)ring[i].ptr;
-                Yf.pl[i].src_len = (int32_t)std::min<size_t>((size_t)Yf.pl[i].src_stride * Y.pl[i].h, 0x7fffffffull);
-            }
-            HIP_TRY(gfw_launch_to_f32(T, nplanes, bps, c->stream), GFW_ERR_HIP);
-            Yf.matrices = Y.matrices;
-            Y = Yf;                                          // what the specialised kernel is launched with
-        }
+        hipFunction_t jf = jit_for(c, Y, bps, params[0].interpolation, n0, dw, dh, interleaved, fast1, &jgrid);
         bool all_device = c->matrices_on_device != 0;
         for (int i = 0; i < nplanes; ++i) all_device = all_device && planes[i].input.kind != GFW_BUF_HOST && planes[i].output.kind != GFW_BUF_HOST;
         if (jf && batch && all_device && c->bslot_cur < 0 && c->mslot_cur < 0) {      // (a table of the cross-stream ring is ordered by events: frame by frame)
@@ -973,7 +938,7 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
                                  batch->CA.Y.p1_rho_scale != Y.p1_rho_scale || batch->CA.Y.p1_eps != Y.p1_eps)) {
                 const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc;
             }
-            if (batch->n == 0) { batch->CA.Y = Y; batch->fn = jf; batch->grid = jgrid; batch->first = planes; batch->backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit"; batch->plain = !f32src; }
+            if (batch->n == 0) { batch->CA.Y = Y; batch->fn = jf; batch->grid = jgrid; batch->first = planes; batch->backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit"; }
             GfwFrameDyn &F = batch->CA.fr[batch->n++];
             for (int i = 0; i < 4; ++i) { F.src[i] = Y.pl[i].src; F.dst[i] = Y.pl[i].dst; }
             F.matrices = Y.matrices;
@@ -1049,7 +1014,7 @@ int gfw_undistort_clip(gfw_ctx *c, int n_frames, int nplanes, const gfw_buffers 
     for (int f = 0; f < n_frames; ++f) {
         // A frame shaped exactly like the one that opened the pending launch (same descriptions but for the pointers; the parameters are
         // shared by construction) needs none of the per-frame validation again: its pointers join the launch.  ~10 us -> < 1 us of host time.
-        if (batch.n > 0 && batch.plain && batch.n < GFW_CLIP_MAX && c->matrices_on_device == 2 && matrices[f] && clip_same_shape(batch.first, planes + (size_t)f * nplanes, nplanes) &&
+        if (batch.n > 0 && batch.n < GFW_CLIP_MAX && c->matrices_on_device == 2 && matrices[f] && clip_same_shape(batch.first, planes + (size_t)f * nplanes, nplanes) &&
             !clip_ring_table(c, matrices[f])) {
             GfwFrameDyn &F = batch.CA.fr[batch.n++];
             for (int i = 0; i < 4; ++i) {

@@ -211,6 +211,16 @@ __device__ __forceinline__ GfwPt rd(float px, float py, const float4 ma, const f
             o.ok = true;
             fisheye_project<IeeeOps>(X, Y, W, L, AF(k_all_zero) != 0, o.x, o.y);      // generic IEEE expansions
         }
+#if GFW_BAKE
+        // a digital lens on top of the fisheye (GoPro SuperView / HyperView clips, flags & 2: cpu_undistort.rs:216-220) in a baked build:
+        // the lens is a literal, so the specialised projection above serves these clips too (ahead of time they take the generic-model
+        // instantiation); same position in the chain — after `+ c` — and the reference's own arithmetic (gfw_warp.h)
+        if (AF(extras) & 2) {
+            float d0, d1;
+            gfw_lens::distort<GFW_BK_digital>(GFW_BK_digital, o.x, o.y, 1.0f, A.kp, A.common, d0, d1);
+            o.x = d0; o.y = d1;
+        }
+#endif
     } else {
         if (!(W > 0.0f)) return o;                                                   // :137
         if (L.rl2 > 0.0f && (X * X + Y * Y) > L.rl2 * W) return o;                   // :139
@@ -385,25 +395,6 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
         out[0] = fminf(s1, limit);
         return;
     }
-    if (N == 1 && is_f32<T>::value && I > 2) {
-        // single-channel f32 planes (an EXR frame's planes, or the f32 copy of an 8/16-bit plane the host made for Lanczos4: §3.2c): the I taps
-        // of a row are I consecutive dwords — no funnel shift, no conversion — fetched a row (two for bicubic) at a time like the integer path,
-        // in the reference's order (xs = xs + p*cx over the row, sum = sum + xs*cy over the rows; the zero-adds stay: f32 pixels may be -0)
-        float s1 = 0.0f;
-        #pragma unroll (I >= 8 ? GFW_TAP_ROW_UNROLL8 : GFW_TAP_ROW_UNROLL)
-        for (int yp = 0; yp < I; ++yp) {
-            const float *row = reinterpret_cast<const float *>(src + (uint32_t)(off0 + yp * stride));
-            float p[I];
-            #pragma unroll
-            for (int i = 0; i < I; ++i) p[i] = row[i];
-            float xs = 0.0f;
-            #pragma unroll
-            for (int i = 0; i < I; ++i) xs = xs + p[i] * cx[i];
-            s1 = s1 + xs * b.ty[yp];
-        }
-        out[0] = fminf(s1, limit);
-        return;
-    }
     float sum[N];
     #pragma unroll
     for (int c = 0; c < N; ++c) sum[c] = 0.0f;
@@ -456,24 +447,23 @@ __device__ __forceinline__ void store_px(uint8_t *dst, int off, const float *v, 
     }
 }
 // One plane.  32-bit byte offsets from the uniform plane base (planes are < 2 GiB, checked on the host).
-// TS: the type the source plane is SAMPLED as — T itself, or float when the host handed the kernel an f32 copy of the plane.
-template <typename T, int N, int I, typename TS = T>
+template <typename T, int N, int I>
 __device__ __forceinline__ void sample_store(float u, float v, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy, const float *lut) {
     float out[N];
     #pragma unroll
     for (int c = 0; c < N; ++c) out[c] = bg[c];
     if (ok) {
         const Bins<I> b = make_bins<I>(u, v, lut);
-        if (__builtin_expect((bins_inside<TS, N, I>(b, P.w, P.h)), 1))
-            taps_inside<TS, N, I>(P.src, row_off(b.sy, P.src_stride) + b.sx * (int)(N * sizeof(TS)), P.src_stride, b, limit, out);
+        if (__builtin_expect((bins_inside<T, N, I>(b, P.w, P.h)), 1))
+            taps_inside<T, N, I>(P.src, row_off(b.sy, P.src_stride) + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
         else
-            taps_edge<TS, N, I>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
+            taps_edge<T, N, I>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
     }
     store_px<T, N>(P.dst, row_off(oy, P.dst_stride) + ox * (int)(N * sizeof(T)), out, px_needs_sat<T>(bg, N, limit));
 }
 // Planar planes of identical geometry (U and V; or G,B,R,A of a planar float frame): one set of bins / weights /
 // offsets, one gather set per plane.
-template <typename T, int I, typename TS = T>
+template <typename T, int I>
 __device__ __forceinline__ void sample_store_shared(float u, float v, bool ok, const GfwYuvPlane *pl, int first, int last, int ox, int oy, const float *lut) {
     const GfwYuvPlane &P0 = pl[first];
     Bins<I> b;
@@ -482,23 +472,23 @@ __device__ __forceinline__ void sample_store_shared(float u, float v, bool ok, c
     int off0 = 0;
     if (ok) {
         b = make_bins<I>(u, v, lut);
-        inside = bins_inside<TS, 1, I>(b, P0.w, P0.h);
-        off0 = row_off(b.sy, P0.src_stride) + b.sx * (int)sizeof(TS);
+        inside = bins_inside<T, 1, I>(b, P0.w, P0.h);
+        off0 = row_off(b.sy, P0.src_stride) + b.sx * (int)sizeof(T);
     }
     const int doff = row_off(oy, P0.dst_stride) + ox * (int)sizeof(T);
     #pragma unroll 1
     for (int pi = first; pi <= last; ++pi) {
         float o = pl[pi].bg[0];
         if (ok) {
-            if (__builtin_expect(inside, 1)) taps_inside<TS, 1, I>(pl[pi].src, off0, P0.src_stride, b, pl[pi].limit, &o);
-            else taps_edge<TS, 1, I>(pl[pi].src, P0.src_stride, b, P0.w, P0.h, pl[pi].bg, pl[pi].limit, &o);
+            if (__builtin_expect(inside, 1)) taps_inside<T, 1, I>(pl[pi].src, off0, P0.src_stride, b, pl[pi].limit, &o);
+            else taps_edge<T, 1, I>(pl[pi].src, P0.src_stride, b, P0.w, P0.h, pl[pi].bg, pl[pi].limit, &o);
         }
         store_px<T, 1>(pl[pi].dst, doff, &o);
     }
 }
 // The same over named planes (baked builds: the planes are separate objects, never an array — an array indexed by a loop counter would
 // live in scratch and turn the plane pointers into flat addresses).  n = 1..3 planes Pa, Pb, Pc.
-template <typename T, int I, typename TS = T>
+template <typename T, int I>
 __device__ __forceinline__ void sample_store_shared_refs(float u, float v, bool ok, const GfwYuvPlane &Pa, const GfwYuvPlane &Pb, const GfwYuvPlane &Pc, int n,
                                                          int ox, int oy, const float *lut) {
     Bins<I> b;
@@ -507,15 +497,15 @@ __device__ __forceinline__ void sample_store_shared_refs(float u, float v, bool 
     int off0 = 0;
     if (ok) {
         b = make_bins<I>(u, v, lut);
-        inside = bins_inside<TS, 1, I>(b, Pa.w, Pa.h);
-        off0 = row_off(b.sy, Pa.src_stride) + b.sx * (int)sizeof(TS);
+        inside = bins_inside<T, 1, I>(b, Pa.w, Pa.h);
+        off0 = row_off(b.sy, Pa.src_stride) + b.sx * (int)sizeof(T);
     }
     const int doff = row_off(oy, Pa.dst_stride) + ox * (int)sizeof(T);
     auto one = [&](const GfwYuvPlane &P) {
         float o = P.bg[0];
         if (ok) {
-            if (__builtin_expect(inside, 1)) taps_inside<TS, 1, I>(P.src, off0, Pa.src_stride, b, P.limit, &o);
-            else taps_edge<TS, 1, I>(P.src, Pa.src_stride, b, Pa.w, Pa.h, P.bg, P.limit, &o);
+            if (__builtin_expect(inside, 1)) taps_inside<T, 1, I>(P.src, off0, Pa.src_stride, b, P.limit, &o);
+            else taps_edge<T, 1, I>(P.src, Pa.src_stride, b, Pa.w, Pa.h, P.bg, P.limit, &o);
         }
         store_px<T, 1>(P.dst, doff, &o, px_needs_sat<T>(P.bg, 1, P.limit));
     };
@@ -862,9 +852,8 @@ __device__ unsigned long long gfw_tl[8192 * 8];
 // The kernel body.  `clip` (baked builds only): the per-frame pointers of the frames of one launch — the frames of a clip share every
 // other argument, so a launch can carry several of them and the occupancy tail of one frame is filled by the next (the effect two
 // HIP streams showed: 79.3 -> 71.7 us per C2 frame, profiles/r03_ab_northstar.txt) without a second stream or a second launch.
-template <int MODEL, typename T, int N0, int I, int DW, int DH, bool INTERLEAVED_UV, int RB, bool FAST1, bool AUDIT, typename TS = T>
+template <int MODEL, typename T, int N0, int I, int DW, int DH, bool INTERLEAVED_UV, int RB, bool FAST1, bool AUDIT>
 __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwClipArgs *clip) {
-    static_assert(sizeof(TS) == sizeof(T) || I != 2, "an f32 copy of the source serves the bicubic / Lanczos4 samplers only");
     // A baked build (run time, gfw_jit.hip) reads every clip-invariant argument as a literal from the bake header (AF(x) = GFW_BK_x): the
     // loads, the uniform branches and the scalar registers they pin disappear — the reference bakes its per-clip constants into the
     // OpenCL source it compiles per clip the same way (opencl.rs:181-214).  Pointers and the per-frame fields stay arguments.
@@ -1086,7 +1075,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     if (AF(ablate) & 2) { if (lane == 99) PL0.dst[0] = (uint8_t)(lu + lv); continue; }  // timing ablation only
                     if (k == 0) { lu0 = lu; lv0 = lv; }
                     if (I == 2) sample_store2<T, N0>(lu, lv, p.ok, PL0, bg_y, lim_y, lx, ly, AUDIT ? AF(audit) : nullptr);
-                    else sample_store<T, N0, I, TS>(lu, lv, p.ok, PL0, bg_y, lim_y, lx, ly, s_lut);
+                    else sample_store<T, N0, I>(lu, lv, p.ok, PL0, bg_y, lim_y, lx, ly, s_lut);
                 }
                 if (MODEL == GFW_MODEL_GENERIC_EXTRA && (AF(extras) & 16) && ok0 && AF(nplanes) > 1) {  // background mode 3 for the chroma site
                     const Feather f = feather_of(u0, v0, A);
@@ -1110,9 +1099,9 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                         else if (GFW_BAKE) sample_store_shared2_refs<T>(cu, cv, ok0, PL1, PL2, PL3, AF(nplanes) - 1, cx, cy);
                         else sample_store_shared2<T>(cu, cv, ok0, A_in.pl, 1, AF(nplanes) - 1, cx, cy);
                     } else {
-                        if (INTERLEAVED_UV) sample_store<T, 2, I, TS>(cu, cv, ok0, PL1, bg_c, lim_u, cx, cy, s_lut);
-                        else if (GFW_BAKE) sample_store_shared_refs<T, I, TS>(cu, cv, ok0, PL1, PL2, PL3, AF(nplanes) - 1, cx, cy, s_lut);
-                        else sample_store_shared<T, I, TS>(cu, cv, ok0, A_in.pl, 1, AF(nplanes) - 1, cx, cy, s_lut);
+                        if (INTERLEAVED_UV) sample_store<T, 2, I>(cu, cv, ok0, PL1, bg_c, lim_u, cx, cy, s_lut);
+                        else if (GFW_BAKE) sample_store_shared_refs<T, I>(cu, cv, ok0, PL1, PL2, PL3, AF(nplanes) - 1, cx, cy, s_lut);
+                        else sample_store_shared<T, I>(cu, cv, ok0, A_in.pl, 1, AF(nplanes) - 1, cx, cy, s_lut);
                     }
                 }
             }
@@ -1136,13 +1125,10 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
 }
 
 #if GFW_JIT
-#ifndef GFW_JIT_TS
-#define GFW_JIT_TS GFW_JIT_T          // float: the planes' `src` are f32 copies of the 8/16-bit source (gfw_api.hip: Lanczos4)
-#endif
 }  // namespace
 // The one instantiation a run-time build contains: template arguments and the bake header come from gfw_jit.hip.
 extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFW_JIT_WAVES, 8))) void gfw_jit_kernel(const GfwClipArgs C) {
-    gfw_yuv_body<GFW_JIT_MODEL, GFW_JIT_T, GFW_JIT_N0, GFW_FRAME_TAPS, GFW_JIT_DW, GFW_JIT_DH, (GFW_JIT_IL != 0), GFW_JIT_RB, (GFW_JIT_FAST1 != 0), false, GFW_JIT_TS>(C.Y, &C);
+    gfw_yuv_body<GFW_JIT_MODEL, GFW_JIT_T, GFW_JIT_N0, GFW_FRAME_TAPS, GFW_JIT_DW, GFW_JIT_DH, (GFW_JIT_IL != 0), GFW_JIT_RB, (GFW_JIT_FAST1 != 0), false>(C.Y, &C);
 }
 #else
 // Register budget: the specialised-fisheye instantiations are held to GFW_WAVES_PER_EU waves per SIMD; the generic-model ones (every

@@ -233,43 +233,6 @@ __global__ void gfw_repack_matrices_kernel(const float *in, float *out, int rows
     if (v[9] != 0.0f || v[10] != 0.0f || v[11] != 0.0f || v[12] != 0.0f || v[13] != 0.0f) { cs = gfw_cosf(-v[11]); sn = gfw_sinf(-v[11]); }
     o[14] = cs; o[15] = sn;
 }
-// ---- f32 copy of 8/16-bit source planes (Lanczos4 through the run-time specialised kernel) ---------------------------------------
-// A Lanczos4 sample converts 64 source pixels to f32 (`to_float`, pixel_formats.rs:75,93), and neighbouring samples convert the same
-// pixels again and again: 128 conversions + funnel shifts per luma pixel for a 4:2:2 frame, a third of the kernel's issue slots.  The
-// conversion is exact and depends on nothing but the pixel, so it is done ONCE per source pixel here — an HBM-bound pass (C2: 33 MB
-// read, 66 MB written) — and the warp samples the f32 planes: same values, same operation order, no conversion in the tap loop.
-template <typename T>
-__global__ __launch_bounds__(256) void gfw_to_f32_kernel(GfwToF32Args A) {
-    const GfwToF32Plane &P = A.pl[blockIdx.z];
-    const int row = blockIdx.y;
-    if (row >= P.rows) return;
-    const T *src = reinterpret_cast<const T *>(P.src + (size_t)row * P.src_stride);
-    float *dst = reinterpret_cast<float *>(P.dst + (size_t)row * P.dst_stride);
-    constexpr int V = 16 / (int)sizeof(T);                                      // samples per 16-byte fetch
-    for (int i0 = ((int)blockIdx.x * 256 + (int)threadIdx.x) * V; i0 < P.samples; i0 += (int)gridDim.x * 256 * V) {
-        if (i0 + V <= P.samples && P.vec_ok) {
-            T v[V];
-            *reinterpret_cast<uint4 *>(v) = *reinterpret_cast<const uint4 *>(src + i0);
-            #pragma unroll
-            for (int j = 0; j < V; j += 4) *reinterpret_cast<float4 *>(dst + i0 + j) = float4{(float)v[j], (float)v[j + 1], (float)v[j + 2], (float)v[j + 3]};
-        } else {
-            for (int j = 0; j < V && i0 + j < P.samples; ++j) dst[i0 + j] = (float)src[i0 + j];
-        }
-    }
-}
-hipError_t gfw_launch_to_f32(const GfwToF32Args &A, int nplanes, int sample_bytes, hipStream_t s) {
-    int max_rows = 0, max_samples = 0;
-    for (int i = 0; i < nplanes; ++i) { if (A.pl[i].rows > max_rows) max_rows = A.pl[i].rows; if (A.pl[i].samples > max_samples) max_samples = A.pl[i].samples; }
-    if (max_rows <= 0 || max_samples <= 0) return hipSuccess;
-    const int v = 16 / sample_bytes;
-    int bx = (max_samples + 256 * v - 1) / (256 * v);
-    if (bx < 1) bx = 1;
-    const dim3 grid((unsigned)bx, (unsigned)max_rows, (unsigned)nplanes);
-    if (sample_bytes == 1) hipLaunchKernelGGL(gfw_to_f32_kernel<uint8_t>, grid, dim3(256), 0, s, A);
-    else hipLaunchKernelGGL(gfw_to_f32_kernel<uint16_t>, grid, dim3(256), 0, s, A);
-    return hipGetLastError();
-}
-
 hipError_t gfw_launch_repack(const float *in, float *out, int rows, hipStream_t s) {
     hipLaunchKernelGGL(gfw_repack_matrices_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, in, out, rows);
     return hipGetLastError();

@@ -4,10 +4,6 @@
 #include "gfw_warp.h"
 
 hipError_t gfw_launch_plane(const GfwPlane &A, const GfwCommon &C, hipStream_t s);
-// f32 copies of up to four 8/16-bit planes in one launch (gfw_kernels.hip: gfw_to_f32_kernel)
-struct GfwToF32Plane { const uint8_t *src; uint8_t *dst; int32_t src_stride, dst_stride, rows, samples, vec_ok, pad_; };   // samples = width * channels
-struct GfwToF32Args { GfwToF32Plane pl[4]; };
-hipError_t gfw_launch_to_f32(const GfwToF32Args &A, int nplanes, int sample_bytes, hipStream_t s);
 hipError_t gfw_launch_repack(const float *in, float *out, int rows, hipStream_t s);
 hipError_t gfw_launch_checksum64(const void *buf, size_t bytes, unsigned long long *out, hipStream_t s);
 hipError_t gfw_launch_debug_math(int op, const float *a, const float *b, float *out, size_t n, hipStream_t s);

@@ -20,7 +20,7 @@ def bake_header(frame, rb=4):
     cw, ch = (ow + dw - 1) // dw, (oh + dh - 1) // dh
     d = {"nplanes": n, "width": w, "height": h, "out_w": ow, "out_h": oh, "cw": cw, "ch": ch, "tiles_x": (cw + 63) // 64,
          "tiles_y": (ch + 4 * rb - 1) // (4 * rb), "matrix_count": p0.matrix_count, "hrs": 1 if p0.flags & 16 else 0, "model": frame.model,
-         "k_all_zero": 1 if all(p0.k[i] == 0.0 for i in range(4)) else 0, "background_mode": p0.background_mode, "extras": 0, "ablate": 0}
+         "k_all_zero": 1 if all(p0.k[i] == 0.0 for i in range(4)) else 0, "background_mode": p0.background_mode, "extras": 0, "ablate": 0, "digital": 0}
     out = ["#define GFW_BK_%s (%d)" % kv for kv in d.items()]
     out.append("#define GFW_BK_audit ((unsigned long long *)nullptr)")
     fl = {"f_0": p0.f[0], "f_1": p0.f[1], "c_0": p0.c[0], "c_1": p0.c[1], "t2_0": p0.translation2d[0], "t2_1": p0.translation2d[1],

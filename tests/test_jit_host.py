@@ -43,23 +43,6 @@ def test_embedded_source_compiles_for_the_lut_samplers(tmp_path, taps):
     assert k[".vgpr_count"] <= 73 and k[".private_segment_fixed_size"] == 0, (k[".vgpr_count"], k[".private_segment_fixed_size"])
 
 
-def test_lanczos4_over_f32_copies_of_the_planes_compiles(tmp_path):
-    """GFW_JIT_TS=float: the instantiation gfw_api.hip asks for when it hands the kernel f32 copies of 8/16-bit planes (Lanczos4)"""
-    import re
-    lib = abi.load_library()
-    header = open(os.path.join(ROOT, "tools", "bake_c2.h")).read()
-    for i, st in ((0, 15360), (1, 7680), (2, 7680)):                       # f32 pitches of the 3840- and 1920-wide planes
-        header = re.sub(r"#define GFW_BK_pl%d_src_stride \(\d+\)" % i, "#define GFW_BK_pl%d_src_stride (%d)" % (i, st), header)
-    out = str(tmp_path / "jit.co")
-    log = C.create_string_buffer(1 << 16)
-    n = lib.gfw_debug_jit_compile(b"gfx950", (C2_DEFS % (8, 7) + ";GFW_JIT_TS=float").encode(), header.encode(), out.encode(), log, len(log))
-    if n == -2:
-        pytest.skip("libhiprtc.so not available")
-    assert n > 0, log.value.decode(errors="replace")[-3000:]
-    k = [k for k in KR.report(out) if k[".name"] == "gfw_jit_kernel"][0]
-    assert k[".vgpr_count"] <= 73 and k[".private_segment_fixed_size"] == 0, (k[".vgpr_count"], k[".private_segment_fixed_size"])
-
-
 def test_a_broken_bake_header_is_reported_not_fatal(tmp_path):
     lib = abi.load_library()
     log = C.create_string_buffer(1 << 14)
