@@ -117,6 +117,8 @@ struct gfw_ctx {
     int jit_mode = 1;
     std::string arch;                              // gcnArchName of the device
     std::string jit_header; int jit_seen = 0;      // bake header of the frames being seen, and how many in a row
+    GfwYuvArgs jit_key; int jit_key_misc[8] = {}; bool jit_key_valid = false;      // the clip those frames belong to (argument block, per-frame fields blanked)
+    hipFunction_t jit_fn = nullptr; int jit_grid = 0;                               // its specialised kernel once loaded
     GfwJitInfo jit_info = {GFW_JIT_UNAVAILABLE, 0.0, std::string()};
     static constexpr int kJitAfter = 3;
     bool profile = false;
@@ -290,9 +292,9 @@ int gfw_set_option(gfw_ctx *c, int option, int64_t value) {
     case GFW_OPT_KERNEL_VARIANT: c->kernel_variant = (int)value; return GFW_OK;
     case GFW_OPT_PROFILE: c->profile = value != 0; return GFW_OK;
     case GFW_OPT_TUNE_ROWS: c->tune_rb = (int)value; return GFW_OK;
-    case GFW_OPT_TUNE_GRID: c->tune_grid = (int)value; return GFW_OK;
+    case GFW_OPT_TUNE_GRID: c->tune_grid = (int)value; c->jit_fn = nullptr; c->jit_key_valid = false; return GFW_OK;
     case GFW_OPT_JIT: if (value < 0 || value > 2) { set_error("GFW_OPT_JIT %lld", (long long)value); return GFW_ERR_INVALID_ARGUMENT; }
-                      c->jit_mode = (int)value; return GFW_OK;
+                      c->jit_mode = (int)value; c->jit_fn = nullptr; c->jit_key_valid = false; return GFW_OK;
     default: set_error("unknown option %d", option); return GFW_ERR_INVALID_ARGUMENT;
     }
 }
@@ -845,9 +847,22 @@ static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps,
     // the specialised instantiation serves the fisheye model, alone or under a digital lens (extras == 2); other extras stay ahead of time
     if (c->jit_mode == 0 || c->kernel_variant != 0 || Y.model != GFW_MODEL_OPENCV_FISHEYE || (Y.extras & ~2) || Y.audit || Y.ablate) return nullptr;
     if (!gfw_jit_available()) { c->jit_info.state = GFW_JIT_UNAVAILABLE; c->jit_info.log = "libhiprtc.so not found"; return nullptr; }
-    std::string hdr = bake_header(Y);
-    if (hdr == c->jit_header) { if (c->jit_seen < (1 << 30)) ++c->jit_seen; }
-    else { c->jit_header.swap(hdr); c->jit_seen = 1; }
+    // the same clip as the previous frame?  Compared on the argument block itself with its per-frame fields blanked (the header text and the
+    // cache lookup cost ~15 us of host time, a frame's worth of validation): header, key and function are rebuilt only when it changes
+    GfwYuvArgs K = Y;
+    for (int i = 0; i < 4; ++i) { K.pl[i].src = nullptr; K.pl[i].dst = nullptr; K.pl[i].src_len = 0; K.pl[i].dst_len = 0; }
+    K.matrices = nullptr; K.p1_table = nullptr; K.p1_rho_max = 0.0f; K.p1_rho_scale = 0.0f; K.p1_eps = 0.0f; K.audit = nullptr; K.grid_limit = 0;
+    memset(&K.kp, 0, sizeof(K.kp));
+    { const int dig = K.common.digital; memset(&K.common, 0, sizeof(K.common)); K.common.digital = dig; }
+    const int key_misc[8] = {bps, taps, n0, dw, dh, interleaved ? 1 : 0, fast1 ? 1 : 0, c->tune_grid};
+    const bool same = c->jit_key_valid && memcmp(&K, &c->jit_key, sizeof(K)) == 0 && memcmp(key_misc, c->jit_key_misc, sizeof(key_misc)) == 0;
+    if (same) {
+        if (c->jit_seen < (1 << 30)) ++c->jit_seen;
+        if (c->jit_fn) { *grid = c->jit_grid; return c->jit_fn; }                        // ready and loaded: nothing else to do
+    } else {
+        c->jit_key = K; memcpy(c->jit_key_misc, key_misc, sizeof(key_misc)); c->jit_key_valid = true;
+        c->jit_header = bake_header(Y); c->jit_seen = 1; c->jit_fn = nullptr;
+    }
     if (c->jit_mode == 1 && c->jit_seen < gfw_ctx::kJitAfter) return nullptr;          // one or two frames are not a clip
     const int waves = jit_waves(taps);
     char b[64];
@@ -863,12 +878,17 @@ static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps,
     snprintf(b, sizeof(b), "GFW_JIT_IL=%d", interleaved ? 1 : 0); defs.push_back(b);
     snprintf(b, sizeof(b), "GFW_JIT_RB=%d", gfw_yuv_rows_per_lane(fast1, 0)); defs.push_back(b);
     snprintf(b, sizeof(b), "GFW_JIT_FAST1=%d", fast1 ? 1 : 0); defs.push_back(b);
+    if (const char *extra = getenv("GFW_JIT_DEFS")) {                                    // experiments: further ';'-separated definitions for the build
+        std::string cur;
+        for (const char *p = extra; ; ++p) { if (*p == ';' || *p == 0) { if (!cur.empty()) defs.push_back(cur); cur.clear(); if (!*p) break; } else cur += *p; }
+    }
     hipFunction_t fn = gfw_jit_get(c->device, c->arch, defs, c->jit_header, c->jit_mode == 2, &c->jit_info);
     if (!fn) return nullptr;
     int g = c->tune_grid > 0 ? c->tune_grid : c->num_cus * waves;
     const int per_xcd = (Y.tiles_x * Y.tiles_y + 7) >> 3;
     if (g > per_xcd * 8) g = per_xcd * 8;
     *grid = (g + 7) & ~7;
+    c->jit_fn = fn; c->jit_grid = *grid;
     return fn;
 }
 

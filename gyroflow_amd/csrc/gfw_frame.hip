@@ -75,6 +75,9 @@
 #ifndef GFW_BAKE
 #define GFW_BAKE 0               // 1: GFW_BAKE_APPLY(A) (from the bake header, -include'd) overwrites the clip-invariant arguments with literals
 #endif
+#ifndef GFW_P3_SPLIT
+#define GFW_P3_SPLIT 0             // A/B of the baked kernel (GFW_JIT_DEFS): both projections of a pixel pair before both samples
+#endif
 #ifndef GFW_TIMELINE
 #define GFW_TIMELINE 0           // diagnosis builds only: per-wave start / end / phase clocks and HW_ID into a device array that the 60th launch
                                  // dumps to $GFW_TIMELINE_FILE (tools/analyze_timeline.py)
@@ -91,10 +94,12 @@
 #define AF(x) (GFW_BK_##x)
 #define AFA(x, i) (GFW_BK_##x##_##i)              // element i of an array field
 #define AFM(m, f) (GFW_BK_##m##_##f)              // member f of a map-constant field
+#define GFW_BAKED_DIGITAL ((GFW_BK_extras & 2) != 0)   // a digital lens rides on the specialised fisheye projection (baked builds only)
 #else
 #define AF(x) (A.x)
 #define AFA(x, i) (A.x[i])
 #define AFM(m, f) (A.m.f)
+#define GFW_BAKED_DIGITAL false
 #endif
 
 namespace {
@@ -161,13 +166,14 @@ __device__ __forceinline__ float map_c(float x, float mul, float den, float rcp)
 // multiplier (a subsampled axis): every operation of map_c scales exactly by 1/2 — power-of-two scaling commutes with round-to-nearest
 // while nothing underflows — so the result is l/2; coordinates below 2^-100 (where the residual of the division could go subnormal)
 // send the whole wave through the full evaluation.
+template <bool INF_SAFE>
 __device__ __forceinline__ float chroma_from_luma(float l, float x, float mul_c, float mul_l, float den, float rcp) {
     if (mul_c == mul_l) return l;
     if (2.0f * mul_c == mul_l) {
         const bool tiny = fabsf(l) < 0x1p-100f && l != 0.0f;
         if (__builtin_expect(!__any(tiny), 1)) return 0.5f * l;
     }
-    return map_c<false>(x, mul_c, den, rcp);
+    return map_c<INF_SAFE>(x, mul_c, den, rcp);
 }
 
 // opencv_fisheye.rs:72-95 on (X/W, Y/W); then *f, +c (cpu_undistort.rs:155,167)
@@ -880,6 +886,9 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     constexpr int NPX = DW * DH;
     constexpr int QCAP = 128 * NPX;                  // a wave adds at most 64*NPX entries per row; flushed at half full
     static_assert(RB * NPX <= 64, "slot index must fit the 6 low bits of q_dst");
+    // can a projected coordinate be infinite?  Not out of the specialised fisheye projection alone (a*s is bounded by theta_d); every other
+    // lens model and any digital lens can produce one, and map_c must then keep it infinite (see map_c)
+    constexpr bool INF_COORDS = MODEL != GFW_MODEL_OPENCV_FISHEYE || GFW_BAKED_DIGITAL;
     __shared__ float q_x[FAST1 ? 4 : 1][FAST1 ? QCAP : 1], q_y[FAST1 ? 4 : 1][FAST1 ? QCAP : 1];
     __shared__ unsigned short q_dst[FAST1 ? 4 : 1][FAST1 ? QCAP : 1];           // (owner lane << 6) | slot in s_rows
     __shared__ unsigned q_n[4];
@@ -962,7 +971,10 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         const int ty = t / AF(tiles_x), tx = t - ty * AF(tiles_x);
         const int cx = tx * 64 + lane;
         const int cy0 = (ty * 4 + wave) * RB;            // first chroma-site row of this lane
-        const bool lane_ok = cx < AF(cw);
+        // a frame whose chroma-site grid is whole tiles (4K: 1920 x 2160 sites = 30 x 135 tiles of 64 x 16) needs none of the per-pixel bounds
+        // tests; only a baked build knows at compile time (WHOLE folds, the tests below vanish)
+        const bool WHOLE = GFW_BAKE && (AF(cw) % 64 == 0) && (AF(ch) % (4 * RB) == 0) && (AF(out_w) == AF(cw) * DW) && (AF(out_h) == AF(ch) * DH);
+        const bool lane_ok = WHOLE || cx < AF(cw);
 
 #if GFW_TIMELINE
         const unsigned long long tl_a = __builtin_readcyclecounter();
@@ -981,7 +993,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     const int i = k % DW, j = k / DW;
                     const int lx = cx * DW + i, ly = (cy0 + r) * DH + j;
                     int sy = 0;
-                    if (lane_ok && lx < AF(out_w) && ly < AF(out_h)) {
+                    if (WHOLE || (lane_ok && lx < AF(out_w) && ly < AF(out_h))) {
                         float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
                         if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (AF(extras) & 8)) gfw_lens_correction_blend<(MODEL == GFW_MODEL_GENERIC_EXTRA ? -1 : MODEL)>(ox, oy, A.kp, A.common);   // :429-460
                         if (FAST1) {
@@ -1035,13 +1047,46 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                 set_prio(((tiles_left * RB) - r) / GFW_PRIO_DIV);
 #endif
                 const int cy = cy0 + r;
-                if (cy >= AF(ch)) break;
+                if (!WHOLE && cy >= AF(ch)) break;
                 float u0 = 0.0f, v0 = 0.0f, lu0 = 0.0f, lv0 = 0.0f; bool ok0 = false;
+#if GFW_P3_SPLIT
+                // A/B (GFW_JIT_DEFS=GFW_P3_SPLIT=1): both projections of the lane's pixel pair first, then both samples — the second pixel's
+                // matrix-row fetch and projection overlap the first pixel's tap fetches
+                if (MODEL == GFW_MODEL_OPENCV_FISHEYE && NPX == 2 && DH == 1 && I == 2 && WHOLE) {
+                    GfwPt pp[2]; float lus[2], lvs[2];
+                    #pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int lx = cx * DW + k, ly = cy;
+                        const float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
+                        const int sy = two_pass ? s_rows[r * NPX + k][tid] : default_row<MODEL>(ox, oy, A);
+                        GfwPt p = rd_row<MODEL>(ox, oy, min(sy, AF(matrix_count) - 1), matrices, L, A);
+                        if ((AF(background_mode) == 1 || AF(background_mode) == 2) && p.ok) {
+                            const float width_f = (float)AF(width), height_f = (float)AF(height);
+                            if (AF(background_mode) == 1) {
+                                p.x = fminf(fmaxf(p.x, 3.0f), width_f - 3.0f);
+                                p.y = fminf(fmaxf(p.y, 3.0f), height_f - 3.0f);
+                            } else {
+                                const float rx = roundf(p.x), ry = roundf(p.y);
+                                const float width3 = width_f - 3.0f, height3 = height_f - 3.0f;
+                                if (rx > width3)  p.x = width3  - (rx - width3);
+                                if (rx < 3.0f)    p.x = 3.0f + width_f - (width3  + rx);
+                                if (ry > height3) p.y = height3 - (ry - height3);
+                                if (ry < 3.0f)    p.y = 3.0f + height_f - (height3 + ry);
+                            }
+                        }
+                        pp[k] = p;
+                        lus[k] = map_c<INF_COORDS>(p.x, MP.mul_lx, MP.den_x, MP.rcp_x); lvs[k] = map_c<INF_COORDS>(p.y, MP.mul_ly, MP.den_y, MP.rcp_y);
+                    }
+                    u0 = pp[0].x; v0 = pp[0].y; ok0 = pp[0].ok; lu0 = lus[0]; lv0 = lvs[0];
+                    #pragma unroll
+                    for (int k = 0; k < 2; ++k) sample_store2<T, N0>(lus[k], lvs[k], pp[k].ok, PL0, bg_y, lim_y, cx * DW + k, cy, nullptr);
+                } else
+#endif
                 #pragma unroll (NPX <= 2 ? NPX : 1)
                 for (int k = 0; k < NPX; ++k) {
                     const int i = k % DW, j = k / DW;
                     const int lx = cx * DW + i, ly = cy * DH + j;
-                    if (lx >= AF(out_w) || ly >= AF(out_h)) continue;
+                    if (!WHOLE && (lx >= AF(out_w) || ly >= AF(out_h))) continue;
                     float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
                     if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (AF(extras) & 8)) gfw_lens_correction_blend<(MODEL == GFW_MODEL_GENERIC_EXTRA ? -1 : MODEL)>(ox, oy, A.kp, A.common);       // :429-460
                     const int sy = two_pass ? s_rows[r * NPX + k][tid] : default_row<MODEL>(ox, oy, A);
@@ -1071,7 +1116,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                         feather_store<T, N0, I, true>(p.x, p.y, feather_of(p.x, p.y, A), PL0, bg_y, lim_y, MP.mul_lx, MP.mul_ly, MP, lx, ly, s_lut);
                         continue;
                     }
-                    const float lu = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(p.x, MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(p.y, MP.mul_ly, MP.den_y, MP.rcp_y);   // cpu_undistort.rs:511-514
+                    const float lu = map_c<INF_COORDS>(p.x, MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c<INF_COORDS>(p.y, MP.mul_ly, MP.den_y, MP.rcp_y);   // cpu_undistort.rs:511-514
                     if (AF(ablate) & 2) { if (lane == 99) PL0.dst[0] = (uint8_t)(lu + lv); continue; }  // timing ablation only
                     if (k == 0) { lu0 = lu; lv0 = lv; }
                     if (I == 2) sample_store2<T, N0>(lu, lv, p.ok, PL0, bg_y, lim_y, lx, ly, AUDIT ? AF(audit) : nullptr);
@@ -1087,11 +1132,11 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     float cu, cv;
                     if (GFW_BAKE && MODEL == GFW_MODEL_OPENCV_FISHEYE) {
                         // the chroma site's coordinate from the luma pixel's that shares it (chroma_from_luma): nothing for 4:2:2's rows, one multiply for a halved axis
-                        cu = chroma_from_luma(lu0, u0, MP.mul_cx, MP.mul_lx, MP.den_x, MP.rcp_x);
-                        cv = chroma_from_luma(lv0, v0, MP.mul_cy, MP.mul_ly, MP.den_y, MP.rcp_y);
+                        cu = chroma_from_luma<INF_COORDS>(lu0, u0, MP.mul_cx, MP.mul_lx, MP.den_x, MP.rcp_x);
+                        cv = chroma_from_luma<INF_COORDS>(lv0, v0, MP.mul_cy, MP.mul_ly, MP.den_y, MP.rcp_y);
                     } else {
-                        cu = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(u0, MP.mul_cx, MP.den_x, MP.rcp_x);
-                        cv = map_c<MODEL != GFW_MODEL_OPENCV_FISHEYE>(v0, MP.mul_cy, MP.den_y, MP.rcp_y);
+                        cu = map_c<INF_COORDS>(u0, MP.mul_cx, MP.den_x, MP.rcp_x);
+                        cv = map_c<INF_COORDS>(v0, MP.mul_cy, MP.den_y, MP.rcp_y);
                     }
                     if (I == 2) {
                         if (INTERLEAVED_UV) sample_store2<T, 2>(cu, cv, ok0, PL1, bg_c, lim_u, cx, cy, AUDIT ? AF(audit) : nullptr);

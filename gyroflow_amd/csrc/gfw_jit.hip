@@ -69,6 +69,7 @@ struct Entry {
 
 std::mutex g_mu;
 std::map<std::string, std::shared_ptr<Entry>> g_cache;       // key: device | arch | options | bake header
+constexpr size_t kMaxEntries = 256;
 
 void compile_entry(Entry *e, std::string source, std::vector<std::string> opts) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -109,6 +110,9 @@ hipFunction_t gfw_jit_get(int device, const std::string &arch, const std::vector
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = g_cache.find(key);
         if (it == g_cache.end()) {
+            // a process that walks through hundreds of distinct clips keeps its first kMaxEntries specialisations (modules stay loaded: kernels of
+            // any of them may be in flight); later clips run ahead of time
+            if (g_cache.size() >= kMaxEntries) { if (info) { info->state = GFW_JIT_UNAVAILABLE; info->log = "specialisation cache full"; } return nullptr; }
             e = std::make_shared<Entry>();
             std::vector<std::string> opts = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed",
                                              "-Wno-cuda-compat", "-DGFW_JIT=1", "-DGFW_BAKE=1"};
