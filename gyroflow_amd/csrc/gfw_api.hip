@@ -833,13 +833,14 @@ static std::string bake_header(const GfwYuvArgs &Y) {
     }
     return o;
 }
-// Waves per SIMD the specialised instantiation is budgeted for.  Measured on C2 (us per frame; gpurun_out/r03b, r03e): bilinear 6 -> 65.4,
-// 7 -> 63.2, 8 -> 64.7; Lanczos4 6 -> 202.9, 7 -> 190.1; bicubic 6 -> 104.4, 7 -> 105.3
-static int jit_waves(int taps) {
+// Waves per SIMD the specialised instantiation is budgeted for.  Measured on MI355X (us per frame, priority step of its time; gpurun_out/r03b-m,
+// profiles/r03_ab_waves_priority.txt): C2 bilinear 6 -> 65.4, 7 -> 57.0-59.3, 8 -> 55.0; NV12 64.6 -> 60.5, P010 71.4 -> 67.8, planar f32 97.7 -> 91.5,
+// Lanczos4 180.5 -> 173.6, bicubic 96.3 -> 95.4, fisheye + SuperView 117.3 -> 103.7 at 7 -> 8.  Eight waves lose where a wave's life is short or
+// its registers are many: one matrix per frame (C1 1080p: 9.30 at 7, 10.2 at 8) and packed RGBA planes (C4: 73.0 at 7, 74.7 at 8) stay at seven.
+static int jit_waves(int n0, int matrix_count) {
     static const int forced = getenv("GFW_JIT_WAVES") ? atoi(getenv("GFW_JIT_WAVES")) : 0;      // experiments
     if (forced >= 1 && forced <= 8) return forced;
-    (void)taps;
-    return 7;
+    return (n0 == 1 && matrix_count > 1) ? 8 : 7;
 }
 // The specialised kernel for this frame's arguments, or nullptr (not eligible / not wanted / not ready / failed): the caller then
 // launches the ahead-of-time kernel.
@@ -864,7 +865,7 @@ static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps,
         c->jit_header = bake_header(Y); c->jit_seen = 1; c->jit_fn = nullptr;
     }
     if (c->jit_mode == 1 && c->jit_seen < gfw_ctx::kJitAfter) return nullptr;          // one or two frames are not a clip
-    const int waves = jit_waves(taps);
+    const int waves = jit_waves(n0, Y.matrix_count);
     char b[64];
     std::vector<std::string> defs;
     snprintf(b, sizeof(b), "GFW_FRAME_KIND=%d", bps); defs.push_back(b);

@@ -62,15 +62,17 @@
 #define GFW_GENERIC_WAVES_PER_EU (GFW_FRAME_TAPS == 2 ? 6 : 3)
 #endif
 #ifndef GFW_PRIO_MODE
-#define GFW_PRIO_MODE 1          // wave issue priority by remaining work (s_setprio).  The SIMD arbiter serves the oldest wave first, so the six
+#define GFW_PRIO_MODE 1          // wave issue priority by remaining work (s_setprio).  The SIMD arbiter serves the oldest wave first, so the
                                  // waves of a SIMD progress at 0.115 ... 0.196 lane-rows/us and finish up to 17 us apart
-                                 // (profiles/r02_wave_timeline.txt).  1: priority = min(3, remaining lane-rows / GFW_PRIO_DIV), re-evaluated every
-                                 // row: waves with more work left are served first and the finish times close up — C2: 80.5 -> 76.4 us per frame
-                                 // in round 2 (DIV 3; 78.1 with 2 or 4); on the round-3 lease the same A/B read 79.3 = 79.3 (profiles/r03_ab_northstar.txt):
-                                 // kept, it costs nothing, but no longer claimed.  0: off.
+                                 // (profiles/r02_wave_timeline.txt).  1: the priority steps 3 -> 0 as the wave's remaining lane-rows fall below
+                                 // 3, 2 and 1 x (its total / GFW_PRIO_SPAN), re-evaluated every row: waves with more work left are served first
+                                 // and progress stays level.  0: off.  What it is worth depends on how long a wave lives: nothing on a lone 4K
+                                 // frame at 6 waves (79.3 = 79.3 us), 4 us of 59 once a launch carries 8 frames at 8 waves per SIMD.
 #endif
-#ifndef GFW_PRIO_DIV
-#define GFW_PRIO_DIV 3
+#ifndef GFW_PRIO_SPAN
+#define GFW_PRIO_SPAN 6          // round 3, C2, 8 waves, 63 lane-rows per wave: fixed divisors 3 / 4 / 5 / 6 / 8 / 12 / 16 / 24 / 32 / 64 gave
+                                 // 57.3 / 56.4 / 56.0 / 55.5 / 55.0 / 55.1 / 55.6 / 56.4 / 56.9 / 58.4 us; 1080p (18 rows per wave) wants 3, 8K
+                                 // (253 rows) 16 or more: the step is a sixth of the wave's work (profiles/r03_ab_waves_priority.txt)
 #endif
 #ifndef GFW_BAKE
 #define GFW_BAKE 0               // 1: GFW_BAKE_APPLY(A) (from the bake header, -include'd) overwrites the clip-invariant arguments with literals
@@ -943,12 +945,14 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     unsigned long long tl_p1 = 0, tl_p3 = 0, tl_units = 0;
 #endif
 #if GFW_PRIO_MODE
-    auto set_prio = [](int p) {                       // s_setprio takes an immediate
-        if (p <= 0) __builtin_amdgcn_s_setprio(0); else if (p == 1) __builtin_amdgcn_s_setprio(1);
-        else if (p == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+    int prio_step = 1;                                // lane-rows per priority level (a GFW_PRIO_SPAN-th of this wave's work)
+    auto set_prio = [&](int remaining) {              // s_setprio takes an immediate
+        if (remaining >= 3 * prio_step) __builtin_amdgcn_s_setprio(3); else if (remaining >= 2 * prio_step) __builtin_amdgcn_s_setprio(2);
+        else if (remaining >= prio_step) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     };
     int tiles_left = 0;
     for (int l = (int)blockIdx.x >> 3; l < per_xcd * n_frames; l += wg_per_xcd) if (GFW_XCD_TILE(l % per_xcd) < n_tiles) ++tiles_left;
+    prio_step = max(1, (tiles_left * RB + GFW_PRIO_SPAN - 1) / GFW_PRIO_SPAN);
 #endif
     // l walks (frame, tile of this XCD's band): the frames of a launch are dealt tile by tile like one tall frame
     int cur_frame = 0;
@@ -966,7 +970,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         }
 #endif
 #if GFW_PRIO_MODE == 1
-        set_prio((tiles_left * RB) / GFW_PRIO_DIV);
+        set_prio(tiles_left * RB);
 #endif
         const int ty = t / AF(tiles_x), tx = t - ty * AF(tiles_x);
         const int cx = tx * 64 + lane;
@@ -1044,7 +1048,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
             #pragma unroll 1
             for (int r = 0; r < RB; ++r) {
 #if GFW_PRIO_MODE == 1
-                set_prio(((tiles_left * RB) - r) / GFW_PRIO_DIV);
+                set_prio((tiles_left * RB) - r);
 #endif
                 const int cy = cy0 + r;
                 if (!WHOLE && cy >= AF(ch)) break;
