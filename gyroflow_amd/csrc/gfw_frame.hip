@@ -77,6 +77,9 @@
 #ifndef GFW_BAKE
 #define GFW_BAKE 0               // 1: GFW_BAKE_APPLY(A) (from the bake header, -include'd) overwrites the clip-invariant arguments with literals
 #endif
+#ifndef GFW_DYN_UNITS
+#define GFW_DYN_UNITS 0            // A/B of the baked kernel (GFW_JIT_DEFS): waves draw (tile, row-slot) units from a per-XCD ticket counter instead of a static stride
+#endif
 #ifndef GFW_P3_SPLIT
 #define GFW_P3_SPLIT 0             // A/B of the baked kernel (GFW_JIT_DEFS): both projections of a pixel pair before both samples
 #endif
@@ -956,8 +959,24 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
 #endif
     // l walks (frame, tile of this XCD's band): the frames of a launch are dealt tile by tile like one tall frame
     int cur_frame = 0;
-    for (int l = (int)blockIdx.x >> 3; l < per_xcd * n_frames; l += wg_per_xcd) {
+#if GFW_DYN_UNITS && GFW_BAKE
+    // dynamic distribution: a wave draws the next quarter tile of its XCD's band (all frames of the launch in sequence) from a ticket counter, so
+    // that a wave the arbiter starves simply takes fewer units; tickets of this launch start at clip->dyn_base (the host advances it by the
+    // units plus one failed draw per wave, so the counter never needs a reset)
+    const unsigned units_total = (unsigned)(per_xcd * n_frames) * 4u;
+    auto draw = [&]() {
+        unsigned t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(clip->dyn_counters + xcd * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)t) - clip->dyn_base;
+    };
+    for (unsigned unit = draw(); unit < units_total; unit = draw()) {
+        const int l = (int)(unit >> 2), slot = (int)(unit & 3u);
         const int fi = n_frames > 1 ? l / per_xcd : 0;
+#else
+    for (int l = (int)blockIdx.x >> 3; l < per_xcd * n_frames; l += wg_per_xcd) {
+        const int slot = wave;
+        const int fi = n_frames > 1 ? l / per_xcd : 0;
+#endif
         const int t = GFW_XCD_TILE(l - fi * per_xcd);
         if (t >= n_tiles) continue;                  // the last XCD's band is the short one
 #if GFW_BAKE
@@ -974,7 +993,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
 #endif
         const int ty = t / AF(tiles_x), tx = t - ty * AF(tiles_x);
         const int cx = tx * 64 + lane;
-        const int cy0 = (ty * 4 + wave) * RB;            // first chroma-site row of this lane
+        const int cy0 = (ty * 4 + slot) * RB;            // first chroma-site row of this lane
         // a frame whose chroma-site grid is whole tiles (4K: 1920 x 2160 sites = 30 x 135 tiles of 64 x 16) needs none of the per-pixel bounds
         // tests; only a baked build knows at compile time (WHOLE folds, the tests below vanish)
         const bool WHOLE = GFW_BAKE && (AF(cw) % 64 == 0) && (AF(ch) % (4 * RB) == 0) && (AF(out_w) == AF(cw) * DW) && (AF(out_h) == AF(ch) * DH);
