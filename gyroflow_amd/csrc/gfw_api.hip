@@ -112,7 +112,6 @@ struct gfw_ctx {
     struct StabSlot { DevBuf d; void *h = nullptr; size_t hcap = 0; hipEvent_t done = nullptr; bool used = false; };
     static constexpr int kStabSlots = 4;
     StabSlot sslots[kStabSlots]; int sslot_next = 0;
-    DevBuf d_dyn; uint32_t dyn_base = 0;           // ticket counters of GFW_DYN_UNITS builds (one per XCD, 64 bytes apart) and the next launch's first ticket
     // run-time specialised kernel (gfw_jit.hip): 0 off; 1 build in the background once the context has seen kJitAfter frames of one
     // clip, warp ahead-of-time meanwhile; 2 build at the first frame and wait for it
     int jit_mode = 1;
@@ -269,7 +268,7 @@ void gfw_destroy(gfw_ctx *c) {
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &b : c->stage_src) b.release();
     for (auto &b : c->stage_dst) b.release();
-    c->d_dyn.release(); c->d_mesh.release(); c->d_p1_table.release(); c->d_audit.release(); c->d_tracks.release(); c->d_offsets.release(); for (auto &ss : c->sslots) { ss.d.release(); if (ss.h) (void)hipHostFree(ss.h); if (ss.done) (void)hipEventDestroy(ss.done); } c->d_prefix.release(); c->d_timings.release(); c->d_batch[0].release(); c->d_batch[1].release();
+    c->d_mesh.release(); c->d_p1_table.release(); c->d_audit.release(); c->d_tracks.release(); c->d_offsets.release(); for (auto &ss : c->sslots) { ss.d.release(); if (ss.h) (void)hipHostFree(ss.h); if (ss.done) (void)hipEventDestroy(ss.done); } c->d_prefix.release(); c->d_timings.release(); c->d_batch[0].release(); c->d_batch[1].release();
     if (c->h_timings) (void)hipHostFree(c->h_timings);
     for (auto &e : c->timing_copied) if (e) (void)hipEventDestroy(e);
     for (auto &b : c->bslots) { b.buf.release(); if (b.built) (void)hipEventDestroy(b.built); if (b.consumed) (void)hipEventDestroy(b.consumed); }
@@ -780,25 +779,9 @@ static bool clip_ring_table(gfw_ctx *c, const float *m) {          // a table of
     for (int i = 0; i < gfw_ctx::kBuiltSlots; ++i) if (c->bslots[i].buf.ptr == (const void *)m && c->bslots[i].built) return true;
     return false;
 }
-// Ticket counters for builds that draw their work dynamically (GFW_DYN_UNITS): every launch is handed the first ticket it may draw; the counter
-// of an XCD advances by the launch's units plus one failed draw per wave, so it is never reset.  Builds without the option ignore both fields.
-static hipError_t dyn_stamp(gfw_ctx *c, GfwClipArgs &CA, int grid) {
-    if (!c->d_dyn.ptr) {
-        hipError_t e = c->d_dyn.ensure(8 * 64);
-        if (e != hipSuccess) return e;
-        e = hipMemsetAsync(c->d_dyn.ptr, 0, 8 * 64, c->stream);
-        if (e != hipSuccess) return e;
-    }
-    CA.dyn_counters = (uint32_t *)c->d_dyn.ptr;
-    CA.dyn_base = c->dyn_base;
-    const uint32_t per_xcd = (uint32_t)((CA.Y.tiles_x * CA.Y.tiles_y + 7) >> 3);
-    c->dyn_base += per_xcd * (uint32_t)(CA.n_frames > 1 ? CA.n_frames : 1) * 4u + (uint32_t)(grid >> 3) * 4u;
-    return hipSuccess;
-}
 static int clip_flush(gfw_ctx *c, ClipBatch *b) {
     if (!b || b->n == 0) return GFW_OK;
-    b->CA.n_frames = b->n;
-    { const hipError_t de = dyn_stamp(c, b->CA, b->grid); if (de != hipSuccess) { set_error("ticket counters: %s", hipGetErrorString(de)); b->n = 0; return GFW_ERR_HIP; } }
+    b->CA.n_frames = b->n; b->CA.pad_ = 0;
     prof_begin(c);
     const hipError_t e = gfw_jit_launch(b->fn, b->CA, b->grid, c->stream);
     prof_end(c, b->n);
@@ -988,8 +971,7 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
         prof_begin(c);
         if (jf) {
             GfwClipArgs CA;
-            CA.Y = Y; CA.n_frames = 1;
-            HIP_TRY(dyn_stamp(c, CA, jgrid), GFW_ERR_HIP);
+            CA.Y = Y; CA.n_frames = 1; CA.pad_ = 0;
             HIP_TRY(gfw_jit_launch(jf, CA, jgrid, c->stream), GFW_ERR_HIP);
             c->last_backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit";
         } else {

@@ -61,10 +61,7 @@ struct GfwYuvArgs {
 // Several frames of one clip in one launch (run-time-specialised kernel only): everything but these pointers is shared.
 #define GFW_CLIP_MAX 8          // frames per launch: 8 measured better than 32 (60.4 against 61.4 us per C2 frame) and a batch reaches the GPU sooner
 struct GfwFrameDyn { const uint8_t *src[4]; uint8_t *dst[4]; const float *matrices; };
-struct GfwClipArgs {
-    GfwYuvArgs Y; int32_t n_frames; uint32_t dyn_base; GfwFrameDyn fr[GFW_CLIP_MAX];
-    uint32_t *dyn_counters;     // GFW_DYN_UNITS builds (A/B): one ticket counter per XCD, 64 bytes apart; tickets of this launch start at dyn_base
-};
+struct GfwClipArgs { GfwYuvArgs Y; int32_t n_frames; int32_t pad_; GfwFrameDyn fr[GFW_CLIP_MAX]; };
 
 #if !defined(GFW_JIT) || !GFW_JIT
 int gfw_yuv_rows_per_lane(bool fast1, int tune_rb);

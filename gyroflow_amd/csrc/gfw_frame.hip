@@ -77,12 +77,6 @@
 #ifndef GFW_BAKE
 #define GFW_BAKE 0               // 1: GFW_BAKE_APPLY(A) (from the bake header, -include'd) overwrites the clip-invariant arguments with literals
 #endif
-#ifndef GFW_DYN_UNITS
-#define GFW_DYN_UNITS 0            // A/B of the baked kernel (GFW_JIT_DEFS): waves draw (tile, row-slot) units from a per-XCD ticket counter instead of a static stride
-#endif
-#ifndef GFW_P3_SPLIT
-#define GFW_P3_SPLIT 0             // A/B of the baked kernel (GFW_JIT_DEFS): both projections of a pixel pair before both samples
-#endif
 #ifndef GFW_TIMELINE
 #define GFW_TIMELINE 0           // diagnosis builds only: per-wave start / end / phase clocks and HW_ID into a device array that the 60th launch
                                  // dumps to $GFW_TIMELINE_FILE (tools/analyze_timeline.py)
@@ -959,24 +953,8 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
 #endif
     // l walks (frame, tile of this XCD's band): the frames of a launch are dealt tile by tile like one tall frame
     int cur_frame = 0;
-#if GFW_DYN_UNITS && GFW_BAKE
-    // dynamic distribution: a wave draws the next quarter tile of its XCD's band (all frames of the launch in sequence) from a ticket counter, so
-    // that a wave the arbiter starves simply takes fewer units; tickets of this launch start at clip->dyn_base (the host advances it by the
-    // units plus one failed draw per wave, so the counter never needs a reset)
-    const unsigned units_total = (unsigned)(per_xcd * n_frames) * 4u;
-    auto draw = [&]() {
-        unsigned t = 0;
-        if (lane == 0) t = __hip_atomic_fetch_add(clip->dyn_counters + xcd * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return (unsigned)__builtin_amdgcn_readfirstlane((int)t) - clip->dyn_base;
-    };
-    for (unsigned unit = draw(); unit < units_total; unit = draw()) {
-        const int l = (int)(unit >> 2), slot = (int)(unit & 3u);
-        const int fi = n_frames > 1 ? l / per_xcd : 0;
-#else
     for (int l = (int)blockIdx.x >> 3; l < per_xcd * n_frames; l += wg_per_xcd) {
-        const int slot = wave;
         const int fi = n_frames > 1 ? l / per_xcd : 0;
-#endif
         const int t = GFW_XCD_TILE(l - fi * per_xcd);
         if (t >= n_tiles) continue;                  // the last XCD's band is the short one
 #if GFW_BAKE
@@ -993,7 +971,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
 #endif
         const int ty = t / AF(tiles_x), tx = t - ty * AF(tiles_x);
         const int cx = tx * 64 + lane;
-        const int cy0 = (ty * 4 + slot) * RB;            // first chroma-site row of this lane
+        const int cy0 = (ty * 4 + wave) * RB;            // first chroma-site row of this lane
         // a frame whose chroma-site grid is whole tiles (4K: 1920 x 2160 sites = 30 x 135 tiles of 64 x 16) needs none of the per-pixel bounds
         // tests; only a baked build knows at compile time (WHOLE folds, the tests below vanish)
         const bool WHOLE = GFW_BAKE && (AF(cw) % 64 == 0) && (AF(ch) % (4 * RB) == 0) && (AF(out_w) == AF(cw) * DW) && (AF(out_h) == AF(ch) * DH);
@@ -1072,39 +1050,6 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                 const int cy = cy0 + r;
                 if (!WHOLE && cy >= AF(ch)) break;
                 float u0 = 0.0f, v0 = 0.0f, lu0 = 0.0f, lv0 = 0.0f; bool ok0 = false;
-#if GFW_P3_SPLIT
-                // A/B (GFW_JIT_DEFS=GFW_P3_SPLIT=1): both projections of the lane's pixel pair first, then both samples — the second pixel's
-                // matrix-row fetch and projection overlap the first pixel's tap fetches
-                if (MODEL == GFW_MODEL_OPENCV_FISHEYE && NPX == 2 && DH == 1 && I == 2 && WHOLE) {
-                    GfwPt pp[2]; float lus[2], lvs[2];
-                    #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int lx = cx * DW + k, ly = cy;
-                        const float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
-                        const int sy = two_pass ? s_rows[r * NPX + k][tid] : default_row<MODEL>(ox, oy, A);
-                        GfwPt p = rd_row<MODEL>(ox, oy, min(sy, AF(matrix_count) - 1), matrices, L, A);
-                        if ((AF(background_mode) == 1 || AF(background_mode) == 2) && p.ok) {
-                            const float width_f = (float)AF(width), height_f = (float)AF(height);
-                            if (AF(background_mode) == 1) {
-                                p.x = fminf(fmaxf(p.x, 3.0f), width_f - 3.0f);
-                                p.y = fminf(fmaxf(p.y, 3.0f), height_f - 3.0f);
-                            } else {
-                                const float rx = roundf(p.x), ry = roundf(p.y);
-                                const float width3 = width_f - 3.0f, height3 = height_f - 3.0f;
-                                if (rx > width3)  p.x = width3  - (rx - width3);
-                                if (rx < 3.0f)    p.x = 3.0f + width_f - (width3  + rx);
-                                if (ry > height3) p.y = height3 - (ry - height3);
-                                if (ry < 3.0f)    p.y = 3.0f + height_f - (height3 + ry);
-                            }
-                        }
-                        pp[k] = p;
-                        lus[k] = map_c<INF_COORDS>(p.x, MP.mul_lx, MP.den_x, MP.rcp_x); lvs[k] = map_c<INF_COORDS>(p.y, MP.mul_ly, MP.den_y, MP.rcp_y);
-                    }
-                    u0 = pp[0].x; v0 = pp[0].y; ok0 = pp[0].ok; lu0 = lus[0]; lv0 = lvs[0];
-                    #pragma unroll
-                    for (int k = 0; k < 2; ++k) sample_store2<T, N0>(lus[k], lvs[k], pp[k].ok, PL0, bg_y, lim_y, cx * DW + k, cy, nullptr);
-                } else
-#endif
                 #pragma unroll (NPX <= 2 ? NPX : 1)
                 for (int k = 0; k < NPX; ++k) {
                     const int i = k % DW, j = k / DW;
