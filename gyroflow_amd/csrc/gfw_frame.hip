@@ -16,18 +16,22 @@
 // oracle.
 //
 // Shape of the kernel (all of it driven by measurements in profiles/):
-//   * VALU-issue bound, so instruction count and code size are what matter: every code path exists once (row
-//     loop not unrolled) and slow paths are side branches — a fully unrolled 26 K-instruction body measured slower
-//     (instruction cache).  Pinning the uniform floats in VGPRs was tried and rejected: it cost occupancy (100 VGPRs) and ran
-//     15 % slower than leaving them to the scalar file;
+//   * VALU-issue bound (86 % VALU-active in the shipped configuration), so instruction count and code size are what matter: every code
+//     path exists once (row loop not unrolled) and slow paths are side branches — a fully unrolled 26 K-instruction body measured slower
+//     (instruction cache); uniforms pinned in VGPRs, LDS copies of the matrix rows and of the source window, a certified second pass,
+//     dynamic work distribution: each built, validated bit-exact, measured slower and removed (profiles/r02_*, r03_ab_*.txt);
 //   * persistent workgroups: the grid is sized to the machine and each workgroup walks a band of tiles, so the
-//     ~5 us start-up of a wave (kernel-argument loads) is paid once, not once per tile;
-//   * XCD-banded tile order (workgroup b runs on XCD b % 8): an XCD's L2 sees a contiguous band of source lines.
+//     ~5 us start-up of a wave (kernel-argument loads) is paid once, not once per tile; the issue priority of a wave follows the
+//     work it has left (GFW_PRIO_MODE), which keeps the waves of a SIMD level;
+//   * XCD-banded tile order (workgroup b runs on XCD b % 8): an XCD's L2 sees a contiguous band of source lines;
+//   * two builds of one source: ahead of time, every instantiation the dispatcher can reach (arguments in the kernel-argument
+//     segment); and at run time, per clip, ONE instantiation with the clip's constants as literals and up to 8 frames per launch
+//     (GFW_JIT / GFW_BAKE, gfw_jit.hip) — 75 against 55 us per 4K frame.
 //
 // Eligibility (decided on the host, gfw_api.hip build_yuv_args): bilinear / bicubic / Lanczos4 taps (this file is
-// compiled once per tap count and sample type), background_mode 0-2, no input rotation, lens_correction_amount >= 1,
-// no mesh / colour-range fix / fill flag, translation3d == 0 (refraction, digital lens and IBIS/OIS terms are served by
-// the generic-model instantiation with the exact first pass), stretches in
+// compiled once per tap count and sample type), background_mode 0-3, no input rotation,
+// no colour-range fix / fill flag, translation3d == 0 (other lens models, refraction, digital lens, IBIS/OIS terms, the lens-correction
+// blend, background mode 3 and the Sony mesh are served by the generic-model instantiations with the exact first pass), stretches in
 // {<=0.001, 1}, full-plane rects; Luma8/Luma16 (+UV8/UV16) planes with chroma planes of identical geometry, one
 // packed RGB(A)8/16 / BGRA8 / AYUV16 / RGBAf plane, or planar R32f planes.
 #ifndef GFW_JIT
@@ -44,13 +48,11 @@
 #include <cstdlib>
 #endif
 
-#ifndef GFW_TAP_ROW_UNROLL8
-#define GFW_TAP_ROW_UNROLL8 1     // tap rows in flight in the Lanczos4 path (measured: 1 beats 2)
-#endif
 #ifndef GFW_WAVES_PER_EU
-#define GFW_WAVES_PER_EU 6       // register budget of the frame kernels, in waves per SIMD (512 / N VGPRs).  6: 71 VGPRs, 106 SGPRs = six workgroups
-                                 // per CU.  7 (94 SGPRs, more scalar reloads) measures 2-4 % slower even with seven workgroups per CU resident, 8
-                                 // (78 SGPRs: 700 v_readlane) 6 % slower: profiles/r02_scheduling_experiments.md
+#define GFW_WAVES_PER_EU 6       // register budget of the AHEAD-OF-TIME frame kernels, in waves per SIMD (512 / N VGPRs).  6: 64-71 VGPRs, 106 SGPRs = six
+                                 // workgroups per CU.  With the arguments in SGPRs 7 (94 SGPRs, more scalar reloads) measured 2-4 % slower and 8 (78 SGPRs:
+                                 // 700 v_readlane) 6 % slower: profiles/r02_scheduling_experiments.md.  The baked builds need far fewer SGPRs and run at
+                                 // 8 or 7 (GFW_JIT_WAVES, gfw_api.hip jit_waves)
 #endif
 #ifndef GFW_HOT_ONLY
 #define GFW_HOT_ONLY 0           // A/B builds (tools/build_variants.sh): only the C2 instantiation (u16, 4:2:2 planar, bilinear), seconds to compile
@@ -75,14 +77,11 @@
                                  // (253 rows) 16 or more: the step is a sixth of the wave's work (profiles/r03_ab_waves_priority.txt)
 #endif
 #ifndef GFW_BAKE
-#define GFW_BAKE 0               // 1: GFW_BAKE_APPLY(A) (from the bake header, -include'd) overwrites the clip-invariant arguments with literals
+#define GFW_BAKE 0               // 1: the clip-invariant arguments are the literals GFW_BK_<field> of the bake header in front of this file (read through AF())
 #endif
 #ifndef GFW_TIMELINE
 #define GFW_TIMELINE 0           // diagnosis builds only: per-wave start / end / phase clocks and HW_ID into a device array that the 60th launch
                                  // dumps to $GFW_TIMELINE_FILE (tools/analyze_timeline.py)
-#endif
-#ifndef GFW_TAP_ROW_UNROLL
-#define GFW_TAP_ROW_UNROLL 2      // tap rows fetched together by the bicubic / Lanczos4 paths (registers vs loads in flight)
 #endif
 
 // Template value of MODEL for the generic-model instantiation that also carries background mode 3 (margin with feather) and the
@@ -387,7 +386,7 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
             const uint8_t *rp0 = src + (uint32_t)off0;
             const unsigned mis = (unsigned)(uintptr_t)rp0 & 3u, sh = mis * 8u;
             const uint8_t *ap = rp0 - mis;
-            #pragma unroll (I >= 8 ? GFW_TAP_ROW_UNROLL8 : GFW_TAP_ROW_UNROLL)
+            #pragma unroll (I >= 8 ? 1 : 2)      // tap rows in flight: one for Lanczos4 (measured: 1 beats 2), two for bicubic (registers against loads in flight)
             for (int yp = 0; yp < I; ++yp) row(reinterpret_cast<const uint32_t *>(ap + (uint32_t)(yp * stride)), mis, sh, b.ty[yp]);
         } else {
             #pragma unroll 1
