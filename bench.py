@@ -53,6 +53,15 @@ N_CHECK = 3                      # frames of the timed region compared with the 
 TRAFFIC_FILE = os.path.join("profiles", "r03_c2_traffic.json")
 
 
+# coefficient sets of the other physical lens models (the ones tests/test_gpu_lens_models.py runs), for --lens-model
+LENS_MODEL_K = {
+    "opencv_standard": [0.12, -0.05, 0.001, 0.002, 0.01, 0.02, -0.01, 0.001, 0.0005, -0.0002, 0.0003, 0.0001],
+    "poly3": [0.06], "poly5": [0.08, -0.02], "ptlens": [0.01, -0.03, 0.02], "insta360": [0.05, -0.01, 0.002, 0.001, -0.001, 0.6],
+    "sony": [1.0, 0.01, -0.05, 0.02, 0.003, -0.001], "generic_polynomial": [1.0, 0.01, -0.05, 0.02, 0.003, -0.001, 0.0005, 0.0, 0.0, 0.0, 0.0, 0.0],
+    "gopro": [0.0, 1.0, 0.01, -0.12, 0.02, 0.01, -0.004],
+}
+
+
 def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +101,9 @@ def parse_args(argv):
                     help="bracket every N-th launch of the timed region with hipEvents for the roofline's kernel duration "
                          "(0 = none); the event pairs themselves cost GPU time between back-to-back kernels")
     ap.add_argument("--digital", default="", help="digital lens on top of the physical one (gopro_superview, gopro_hyperview, ...)")
+    ap.add_argument("--lens-model", default="", help="physical lens model instead of opencv_fisheye (opencv_standard, poly3, poly5, ptlens, insta360, "
+                                                     "sony, generic_polynomial, gopro): the fused kernel's generic-model body")
+    ap.add_argument("--lca", type=float, default=1.0, help="lens_correction_amount (< 1: the blend of cpu_undistort.rs:429-460)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2, 4),
@@ -227,6 +239,13 @@ def worker(args):
     lens = S.gopro_style_lens(W, H)
     if args.digital:
         lens["digital"] = args.digital
+    if args.lens_model:
+        k = LENS_MODEL_K[args.lens_model]
+        lens["model"], lens["k"] = args.lens_model, k + [0.0] * (12 - len(k))
+        if args.lens_model == "gopro":
+            lens["r_limit"] = 2.5
+    if args.lca != 1.0:
+        ov = dict(ov or {}, lens_correction_amount=args.lca)
     NR = 4 if args.host_buffers else max(1, args.resident)
     device_built = args.build_matrices or args.c5
     # frame j of this rank: seed and timestamp of its own (seed = 0x9F10 + frame index); the C5 clip's
@@ -514,14 +533,16 @@ def worker(args):
     alg_bytes = frames[0].algorithmic_bytes()
     frames_done = total if args.c5 else n_steps * world
     value = luma_px * frames_done / elapsed / 1e6
-    cfg_name = ("C5" if args.c5 else "C1" if args.c1 else "C2" if (W, H, args.fmt, args.crop) == (3840, 2160, FMT, False) else
+    cfg_name = ("custom" if (args.lens_model or args.lca != 1.0 or args.digital) else "C5" if args.c5 else "C1" if args.c1 else "C2" if (W, H, args.fmt, args.crop) == (3840, 2160, FMT, False) else
                 "C3" if (W, H, args.fmt) == (7680, 4320, FMT) else "C4" if args.crop else "custom")
     how = (" — HOST buffers: H2D + warp + D2H + sync per frame (PCIe-inclusive)" if args.host_buffers else
            " (matrices re-uploaded per frame)" if args.upload_matrices else
            " (per-row matrices built on the device every frame from quaternion tracks, %d frames per build launch)" % BATCH if device_built else "")
-    workload = "%s: %dx%d %s, opencv_fisheye GoPro-style lens, rolling shutter matrix_count=%d, %s, %d distinct source frames%s resident in HBM%s" % (
+    workload = "%s: %dx%d %s, LENS GoPro-style lens, rolling shutter matrix_count=%d, %s, %d distinct source frames%s resident in HBM%s" % (
         cfg_name, W, H, args.fmt, rows_n, {2: "bilinear", 4: "bicubic", 8: "Lanczos4"}.get(args.interp, str(args.interp)), NR,
         "" if device_built else " + per-row matrix tables", how)
+    workload = workload.replace("LENS", (args.lens_model or "opencv_fisheye") + (" + " + args.digital if args.digital else "") +
+                                ("" if args.lca == 1.0 else " (lens correction %g)" % args.lca))
     if args.c5:
         workload += "; %d-frame clip dealt round-robin to %d rank(s), one 64-bit checksum per frame" % (total, world)
     if clip_n > 1:
@@ -547,7 +568,7 @@ def worker(args):
         # HBM bytes per launch: rocprofv3 PMC passes cannot run inside bench.py; the stored figure of this exact workload is quoted
         traffic, tsrc = None, None
         tpath = os.path.join(ROOT, TRAFFIC_FILE)
-        if (W, H, args.fmt, args.interp, args.crop, args.variant, args.host_buffers, bool(args.digital)) == (WIDTH, HEIGHT, FMT, 2, False, 0, False, False) and os.path.exists(tpath):
+        if (W, H, args.fmt, args.interp, args.crop, args.variant, args.host_buffers, bool(args.digital or args.lens_model or args.lca != 1.0)) == (WIDTH, HEIGHT, FMT, 2, False, 0, False, False) and os.path.exists(tpath):
             tj = json.load(open(tpath))                  # per frame; a launch carries fpl of them
             traffic = int((tj["fetch_size_kib_per_frame"] * tj["fetch_correction"] + tj["write_size_kib_per_frame"]) * 1024 * fpl)
             tsrc = "%s (stored rocprofv3 PMC passes of this workload and library, not measured in this run)" % TRAFFIC_FILE

@@ -837,16 +837,21 @@ static std::string bake_header(const GfwYuvArgs &Y) {
 // profiles/r03_ab_waves_priority.txt): C2 bilinear 6 -> 65.4, 7 -> 57.0-59.3, 8 -> 55.0; NV12 64.6 -> 60.5, P010 71.4 -> 67.8, planar f32 97.7 -> 91.5,
 // Lanczos4 180.5 -> 173.6, bicubic 96.3 -> 95.4, fisheye + SuperView 117.3 -> 103.7 at 7 -> 8.  Eight waves lose where a wave's life is short or
 // its registers are many: one matrix per frame (C1 1080p: 9.30 at 7, 10.2 at 8) and packed RGBA planes (C4: 73.0 at 7, 74.7 at 8) stay at seven.
-static int jit_waves(int n0, int matrix_count) {
+// The generic-model body with the lens-correction blend, background mode 3 or the Sony mesh (extras 8 / 16 / 32) wants up to 80 registers: six waves.
+static int jit_waves(int n0, int matrix_count, int jit_model, int extras) {
     static const int forced = getenv("GFW_JIT_WAVES") ? atoi(getenv("GFW_JIT_WAVES")) : 0;      // experiments
     if (forced >= 1 && forced <= 8) return forced;
+    if (jit_model < 0 && (extras & (8 | 16 | 32))) return 6;
     return (n0 == 1 && matrix_count > 1) ? 8 : 7;
 }
 // The specialised kernel for this frame's arguments, or nullptr (not eligible / not wanted / not ready / failed): the caller then
 // launches the ahead-of-time kernel.
 static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps, int n0, int dw, int dh, bool interleaved, bool fast1, int *grid) {
-    // the specialised instantiation serves the fisheye model, alone or under a digital lens (extras == 2); other extras stay ahead of time
-    if (c->jit_mode == 0 || c->kernel_variant != 0 || Y.model != GFW_MODEL_OPENCV_FISHEYE || (Y.extras & ~2) || Y.audit || Y.ablate) return nullptr;
+    // every frame the fused kernel serves can be specialised: the fisheye model alone or under a digital lens (extras 0 / 2) takes the lean
+    // projection (MODEL = 1); everything else the generic-model body with the lens model, the digital lens and the feature bits as literals
+    // (MODEL = -1, or -2 with background mode 3 / the Sony mesh) — the run-time switch over 14 lens models folds to the one in use
+    if (c->jit_mode == 0 || c->kernel_variant != 0 || Y.audit || Y.ablate) return nullptr;
+    const int jit_model = (Y.model == GFW_MODEL_OPENCV_FISHEYE && (Y.extras & ~2) == 0) ? GFW_MODEL_OPENCV_FISHEYE : ((Y.extras & (16 | 32)) ? -2 : -1);
     if (!gfw_jit_available()) { c->jit_info.state = GFW_JIT_UNAVAILABLE; c->jit_info.log = "libhiprtc.so not found"; return nullptr; }
     // the same clip as the previous frame?  Compared on the argument block itself with its per-frame fields blanked (the header text and the
     // cache lookup cost ~15 us of host time, a frame's worth of validation): header, key and function are rebuilt only when it changes
@@ -865,13 +870,13 @@ static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps,
         c->jit_header = bake_header(Y); c->jit_seen = 1; c->jit_fn = nullptr;
     }
     if (c->jit_mode == 1 && c->jit_seen < gfw_ctx::kJitAfter) return nullptr;          // one or two frames are not a clip
-    const int waves = jit_waves(n0, Y.matrix_count);
+    const int waves = jit_waves(n0, Y.matrix_count, jit_model, Y.extras);
     char b[64];
     std::vector<std::string> defs;
     snprintf(b, sizeof(b), "GFW_FRAME_KIND=%d", bps); defs.push_back(b);
     snprintf(b, sizeof(b), "GFW_FRAME_TAPS=%d", taps); defs.push_back(b);
     snprintf(b, sizeof(b), "GFW_JIT_WAVES=%d", waves); defs.push_back(b);
-    defs.push_back("GFW_JIT_MODEL=1");
+    snprintf(b, sizeof(b), "GFW_JIT_MODEL=%d", jit_model); defs.push_back(b);
     defs.push_back(bps == 1 ? "GFW_JIT_T=uint8_t" : bps == 2 ? "GFW_JIT_T=uint16_t" : "GFW_JIT_T=float");
     snprintf(b, sizeof(b), "GFW_JIT_N0=%d", n0); defs.push_back(b);
     snprintf(b, sizeof(b), "GFW_JIT_DW=%d", dw); defs.push_back(b);

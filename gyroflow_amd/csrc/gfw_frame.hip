@@ -93,11 +93,15 @@
 #define AFA(x, i) (GFW_BK_##x##_##i)              // element i of an array field
 #define AFM(m, f) (GFW_BK_##m##_##f)              // member f of a map-constant field
 #define GFW_BAKED_DIGITAL ((GFW_BK_extras & 2) != 0)   // a digital lens rides on the specialised fisheye projection (baked builds only)
+#define GFW_BAKED_DIGITAL_MODEL (((GFW_BK_extras & 2) != 0) ? GFW_BK_digital : -1)     // the generic branch's digital lens as a literal
+#define GFW_CLIP_DIGITAL (GFW_BK_digital)
 #else
 #define AF(x) (A.x)
 #define AFA(x, i) (A.x[i])
 #define AFM(m, f) (A.m.f)
 #define GFW_BAKED_DIGITAL false
+#define GFW_BAKED_DIGITAL_MODEL (-1)
+#define GFW_CLIP_DIGITAL (A.common.digital)
 #endif
 
 namespace {
@@ -254,7 +258,7 @@ __device__ __forceinline__ GfwPt rd(float px, float py, const float4 ma, const f
         if (MODEL == GFW_MODEL_GENERIC_EXTRA && (AF(extras) & 32)) gfw_mesh_apply(u, v, A.kp, A.common);   // Sony mesh + focal-plane distortion (:169-214)
         if (AF(extras) & 2) {
             float d0, d1;
-            gfw_lens::distort<-1>(A.common.digital, u, v, 1.0f, A.kp, A.common, d0, d1);
+            gfw_lens::distort<GFW_BAKED_DIGITAL_MODEL>(GFW_CLIP_DIGITAL, u, v, 1.0f, A.kp, A.common, d0, d1);
             u = d0; v = d1;
         }
         o.x = u; o.y = v;
@@ -995,7 +999,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     int sy = 0;
                     if (WHOLE || (lane_ok && lx < AF(out_w) && ly < AF(out_h))) {
                         float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
-                        if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (AF(extras) & 8)) gfw_lens_correction_blend<(MODEL == GFW_MODEL_GENERIC_EXTRA ? -1 : MODEL)>(ox, oy, A.kp, A.common);   // :429-460
+                        if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (AF(extras) & 8)) gfw_lens_correction_blend<(MODEL == GFW_MODEL_GENERIC_EXTRA ? -1 : MODEL)>(ox, oy, A.kp, A.common, AF(model), GFW_CLIP_DIGITAL);   // :429-460
                         if (FAST1) {
                             float v_fast;
                             const float ax = __builtin_fmaf(ox, M.m0, M.m2), ay = __builtin_fmaf(ox, M.m3, M.m5), aw = __builtin_fmaf(ox, M.m6, M.m8);
@@ -1055,7 +1059,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     const int lx = cx * DW + i, ly = cy * DH + j;
                     if (!WHOLE && (lx >= AF(out_w) || ly >= AF(out_h))) continue;
                     float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
-                    if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (AF(extras) & 8)) gfw_lens_correction_blend<(MODEL == GFW_MODEL_GENERIC_EXTRA ? -1 : MODEL)>(ox, oy, A.kp, A.common);       // :429-460
+                    if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (AF(extras) & 8)) gfw_lens_correction_blend<(MODEL == GFW_MODEL_GENERIC_EXTRA ? -1 : MODEL)>(ox, oy, A.kp, A.common, AF(model), GFW_CLIP_DIGITAL);       // :429-460
                     const int sy = two_pass ? s_rows[r * NPX + k][tid] : default_row<MODEL>(ox, oy, A);
                     GfwPt p;
                     if (AF(ablate) & 8) { p.x = ox * 0.5f; p.y = oy * 0.5f; p.ok = true; }              // timing ablation only

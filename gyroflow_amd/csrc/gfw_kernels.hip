@@ -246,7 +246,13 @@ __global__ __launch_bounds__(256) void gfw_checksum64_kernel(const uint64_t *p, 
     const size_t stride = (size_t)gridDim.x * 256u * 2u;
     const ulonglong2 *p2 = reinterpret_cast<const ulonglong2 *>(p);
     const size_t n2 = n >> 1;
-    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n2; i += stride >> 1) { const ulonglong2 v = p2[i]; acc += v.x + v.y; }
+    const size_t step = stride >> 1;
+    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    for (; i + 3 * step < n2; i += 4 * step) {        // four independent 16-byte loads in flight per lane
+        const ulonglong2 a = p2[i], b = p2[i + step], c = p2[i + 2 * step], d = p2[i + 3 * step];
+        acc += (a.x + a.y) + (b.x + b.y) + (c.x + c.y) + (d.x + d.y);
+    }
+    for (; i < n2; i += step) { const ulonglong2 v = p2[i]; acc += v.x + v.y; }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc += p[n - 1];
     #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);

@@ -629,19 +629,20 @@ __device__ __forceinline__ GfwPt gfw_rotate_and_distort(float px, float py, int 
 // (x, y) are OUTPUT-BUFFER pixel indices as floats.  The result is in full-resolution source pixels.
 // The lens-correction blend of undistort_coord (cpu_undistort.rs:429-460): the output position moves towards its
 // undistorted counterpart by (1 - lens_correction_amount) before any projection.
+// (lens, digital: the clip's lens model and digital lens — C.model / C.digital, or literals in a run-time specialised kernel)
 template <int MODEL>
-__device__ __forceinline__ void gfw_lens_correction_blend(float &opx, float &opy, const gfw_kernel_params &P, const GfwCommon &C) {
+__device__ __forceinline__ void gfw_lens_correction_blend(float &opx, float &opy, const gfw_kernel_params &P, const GfwCommon &C, const int lens, const int digital) {
         const float factor = gfw_max(1.0f - P.lens_correction_amount, 0.001f);          // :526
         const float ocx = (float)P.output_width / 2.0f, ocy = (float)P.output_height / 2.0f;
         const float ofx = P.f[0] / P.fov / factor, ofy = P.f[1] / P.fov / factor;
         float nx = opx, ny = opy;
-        if ((P.flags & 2) == 2 && C.digital != GFW_MODEL_NONE) {
+        if ((P.flags & 2) == 2 && digital != GFW_MODEL_NONE) {
             const float uzx = (nx - ocx) * P.fov + ocx, uzy = (ny - ocy) * P.fov + ocy;
-            const GfwPt pt = gfw_lens::undistort<-1>(C.digital, uzx, uzy, P, C);
+            const GfwPt pt = gfw_lens::undistort<-1>(digital, uzx, uzy, P, C);
             if (pt.ok) { nx = (pt.x - ocx) / P.fov + ocx; ny = (pt.y - ocy) / P.fov + ocy; }
         }
         nx = (nx - ocx) / ofx; ny = (ny - ocy) / ofy;
-        const GfwPt pt = gfw_lens::undistort<MODEL>(C.model, nx, ny, P, C);
+        const GfwPt pt = gfw_lens::undistort<MODEL>(lens, nx, ny, P, C);
         if (pt.ok) { nx = pt.x; ny = pt.y; }
         if (P.light_refraction_coefficient != 1.0f && P.light_refraction_coefficient > 0.0f) {
             const float r = sqrtf(nx * nx + ny * ny);
@@ -655,6 +656,10 @@ __device__ __forceinline__ void gfw_lens_correction_blend(float &opx, float &opy
         nx = (nx * ofx) + ocx; ny = (ny * ofy) + ocy;
         opx = nx * (1.0f - P.lens_correction_amount) + (opx * P.lens_correction_amount);
         opy = ny * (1.0f - P.lens_correction_amount) + (opy * P.lens_correction_amount);
+}
+template <int MODEL>
+__device__ __forceinline__ void gfw_lens_correction_blend(float &opx, float &opy, const gfw_kernel_params &P, const GfwCommon &C) {
+    gfw_lens_correction_blend<MODEL>(opx, opy, P, C, C.model, C.digital);
 }
 template <int MODEL>
 __device__ __forceinline__ GfwPt gfw_undistort_coord_fullres(float x, float y, const gfw_kernel_params &P, const GfwCommon &C) {

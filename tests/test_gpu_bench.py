@@ -86,3 +86,31 @@ def test_c5_clip_checksums_do_not_depend_on_the_rank_count():
         assert o["config"]["parity_vs_oracle"] == "bit-exact", o["config"]
     assert one["steps"] == 70 and two["steps"] == 35
     assert one["config"]["checksum"] == two["config"]["checksum"]
+
+
+@pytest.mark.parametrize("words", [1, 2, 3, 511, 2048 * 256 * 2 * 4 + 6, 2048 * 256 * 2 * 5 - 1, 3840 * 2160 * 4 // 8])
+def test_checksum64_is_the_sum_of_the_words(words):
+    """gfw_checksum64 (the per-frame checksum of the C5 clip): the little-endian u64 words summed modulo 2^64, accumulated into *out — through the
+    unrolled main loop, its remainder loop and the odd tail word."""
+    import numpy as np
+    import torch
+    from gyroflow_amd import abi
+    lib = abi.load_library()
+    assert lib.gfw_set_device(0) == 0
+    rng = np.random.default_rng(words)
+    host = rng.integers(0, 2 ** 64, size=words, dtype=np.uint64)
+    dev = torch.device("cuda", 0)
+    buf = torch.from_numpy(host.view(np.int64)).to(dev)
+    out = torch.full((1,), 5, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+    fr = __import__("gyroflow_amd.synthetic", fromlist=["SyntheticFrame"]).SyntheticFrame("NV12", 64, 32, seed=1)
+    from gyroflow_amd import warp
+    pl = fr.planes[0]
+    be = warp.Backend(pl["params"], pl["pixel_type"], fr.model, fr.digital, warp.host_buffers(pl["src"], pl["size"], pl["dst"].copy(), pl["out_size"]))
+    try:
+        assert lib.gfw_checksum64(be.ctx, buf.data_ptr(), words * 8, out.data_ptr()) == 0
+        be.synchronize()
+    finally:
+        be.close()
+    want = (int(host.sum(dtype=np.uint64)) + 5) % (1 << 64)
+    assert int(out.cpu().numpy().view(np.uint64)[0]) == want

@@ -57,6 +57,74 @@ def test_digital_lens_on_top_of_the_fisheye(digital):
     assert warp.last_backend() == "yuv_fused"                 # the ahead-of-time run that check_jit ends with
 
 
+@pytest.mark.parametrize("model", ["opencv_standard", "poly3", "poly5", "ptlens", "insta360", "sony", "generic_polynomial", "gopro", "opencv_fisheye"])
+@pytest.mark.parametrize("lca", [1.0, 0.45])
+def test_every_lens_model_specialised(model, lca):
+    """Every physical lens model — and the fisheye under the lens-correction blend — through the generic-model body with the model as a literal
+    (GFW_JIT_MODEL = -1: the switch over the lens models folds to the one in use)."""
+    from test_gpu_lens_models import PHYSICAL
+    if model == "opencv_fisheye" and lca == 1.0:
+        pytest.skip("the lean fisheye instantiation: every other test of this file")
+    w, h = 256, 160
+    lens = S.gopro_style_lens(w, h)
+    lens["model"] = model
+    lens["k"] = PHYSICAL[model] + [0.0] * (12 - len(PHYSICAL[model]))
+    if model == "gopro":
+        lens["r_limit"] = 2.5
+    check_jit(S.SyntheticFrame("YUV422P16LE", w, h, seed=31, lens=lens, fov=1.2, base_overrides={"lens_correction_amount": lca}), "%s lca %g" % (model, lca))
+
+
+@pytest.mark.parametrize("interp", [2, 8])
+def test_generic_features_specialised(interp):
+    """Refraction, blend under a digital lens, IBIS/OIS terms, background mode 3 (MODEL = -2): feature bits as literals."""
+    from test_gpu_lens_models import DIGITAL, PHYSICAL
+    w, h = 256, 160
+    check_jit(S.SyntheticFrame("YUV422P16LE", w, h, seed=61, fov=1.3, interpolation=interp, base_overrides={"light_refraction_coefficient": 1.33}), "refraction")
+    lens = S.gopro_style_lens(w, h)
+    lens["digital"] = "gopro_superview"
+    check_jit(S.SyntheticFrame("NV12", w, h, seed=62, lens=lens, fov=1.1, interpolation=interp,
+                               base_overrides={"lens_correction_amount": 0.6, "digital_lens_params": DIGITAL["gopro_superview"]}), "digital lens + blend")
+    lens = S.gopro_style_lens(w, h)
+    lens["model"] = "poly5"
+    lens["k"] = PHYSICAL["poly5"] + [0.0] * (12 - len(PHYSICAL["poly5"]))
+    lens["digital"] = "digital_stretch"
+    check_jit(S.SyntheticFrame("YUV420P", w, h, seed=63, lens=lens, fov=1.1, interpolation=interp,
+                               base_overrides={"digital_lens_params": DIGITAL["digital_stretch"]}), "poly5 under a digital lens")
+    fr = S.SyntheticFrame("YUV422P16LE", w, h, seed=53, fov=1.2, interpolation=interp)
+    y = np.arange(fr.matrices.shape[0], dtype=np.float32)
+    fr.matrices[:, 9] = 1.5 * np.sin(y * 0.05)
+    fr.matrices[:, 10] = -0.8 * np.cos(y * 0.03)
+    fr.matrices[:, 11] = 0.004 * np.sin(y * 0.02)
+    fr.matrices[:, 12] = 0.6
+    fr.matrices[:, 13] = -0.4
+    check_jit(fr, "IBIS / OIS terms")
+    fr = S.SyntheticFrame("YUV422P16LE", 322, 190, seed=64, fov=2.2, interpolation=interp,
+                          base_overrides={"background_mode": 3, "background_margin": 0.08, "background_margin_feather": 0.12})
+    check_jit(fr, "background mode 3")
+
+
+@pytest.mark.parametrize("with_mesh,with_fpd", [(True, True), (False, True)])
+def test_sony_mesh_specialised(with_mesh, with_fpd):
+    from test_gpu_lens_models import synthetic_mesh
+    w, h = 192, 128
+    fr = S.SyntheticFrame("NV12", w, h, seed=47, fov=1.1)
+    mesh = synthetic_mesh(w, h, with_fpd, with_mesh)
+    for pl in fr.planes:
+        ref = pl["dst"].copy()
+        assert O.undistort_image(pl["src"], pl["size"], ref, pl["out_size"], pl["params"], pl["pixel_type"], fr.model, fr.digital, fr.matrices, mesh=mesh) == 1
+        for jit in (2, 0):
+            dst = pl["dst"].copy()
+            b = warp.host_buffers(pl["src"], pl["size"], dst, pl["out_size"])
+            be = warp.Backend(pl["params"], pl["pixel_type"], fr.model, fr.digital, b)
+            try:
+                be.set_option(abi.OPT_JIT, jit)
+                be.undistort_image(b, pl["params"], fr.matrices, mesh)
+                assert warp.last_backend().endswith("_jit") == (jit == 2), warp.last_backend()
+            finally:
+                be.close()
+            assert_plane_equal(ref, dst, pl["pixel_type"], "mesh, jit %d" % jit)
+
+
 def test_geometry_variants():
     check_jit(S.SyntheticFrame("YUV422P16LE", 256, 160, seed=23, readout_ms=0.0), "one matrix")
     check_jit(S.SyntheticFrame("YUV422P16LE", 256, 160, seed=23, horizontal_rs=True), "horizontal rolling shutter")

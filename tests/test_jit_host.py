@@ -50,3 +50,24 @@ def test_a_broken_bake_header_is_reported_not_fatal(tmp_path):
     if n == -2:
         pytest.skip("libhiprtc.so not available")
     assert n == -1 and b"GFW_BK_" in log.value
+
+
+@pytest.mark.parametrize("model,extras,waves,jit_model", [(2, 0, 8, -1), (9, 8, 6, -1), (7, 4 | 1, 8, -1), (8, 8 | 2, 6, -1), (3, 2, 8, -1)])
+def test_generic_model_body_specialises_without_scratch(tmp_path, model, extras, waves, jit_model):
+    """Other lens models and feature bits: the generic-model body with the model and the bits as literals (gfw_api.hip jit_for) — the ahead-of-time
+    instantiation of the same body spills (tests/test_kernel_resources.py), the specialised one must not (a few spilled dwords at most under the blend of two lens solvers)."""
+    lib = abi.load_library()
+    header = open(os.path.join(ROOT, "tools", "bake_c2.h")).read()
+    header = header.replace("#define GFW_BK_model (1)", "#define GFW_BK_model (%d)" % model).replace("#define GFW_BK_extras (0)", "#define GFW_BK_extras (%d)" % extras)
+    assert "GFW_BK_model (%d)" % model in header and "GFW_BK_extras (%d)" % extras in header
+    if extras & 2:
+        header = header.replace("#define GFW_BK_digital (0)", "#define GFW_BK_digital (10)")
+    defs = (C2_DEFS % (2, waves)).replace("GFW_JIT_MODEL=1", "GFW_JIT_MODEL=%d" % jit_model).replace("GFW_JIT_RB=4;GFW_JIT_FAST1=1", "GFW_JIT_RB=1;GFW_JIT_FAST1=0")
+    out = str(tmp_path / "jit.co")
+    log = C.create_string_buffer(1 << 16)
+    n = lib.gfw_debug_jit_compile(b"gfx950", defs.encode(), header.encode(), out.encode(), log, len(log))
+    if n == -2:
+        pytest.skip("libhiprtc.so not available")
+    assert n > 0, log.value.decode(errors="replace")[-3000:]
+    k = [k for k in KR.report(out) if k[".name"] == "gfw_jit_kernel"][0]
+    assert k[".private_segment_fixed_size"] <= (0 if waves == 8 else 64) and k[".vgpr_count"] <= (64 if waves == 8 else 80), (k[".vgpr_count"], k[".private_segment_fixed_size"])
