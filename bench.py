@@ -48,6 +48,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FMT, WIDTH, HEIGHT = "YUV422P16LE", 3840, 2160
 N_RESIDENT = 64                  # distinct source frames + per-row matrix tables resident in HBM, cycled by the steps
                                  # (SURVEY.md 8d "64 distinct resident source frames cycled": 2.1 GB, far beyond L2 + MALL)
+CLIP_FRAMES = 8                  # frames of one gfw_undistort_clip launch (GFW_CLIP_MAX)
 N_DST = 8                        # destination frame sets written round-robin (the frames of one clip launch are in flight together: one set each)
 N_CHECK = 3                      # frames of the timed region compared with the oracle afterwards
 TRAFFIC_FILE = os.path.join("profiles", "r03_c2_traffic.json")
@@ -231,6 +232,9 @@ def worker(args):
     # ---- synthetic clip, produced directly in HBM ---------------------------------------------------------
     if args.c1:
         args.width, args.height, args.fmt = 1920, 1080, "NV12"
+    global N_DST
+    if args.streams > 1 and args.clip > 1:            # clip launches dealt to S streams: each stream's launches write a destination-set group of their own
+        N_DST = CLIP_FRAMES * args.streams
     W, H = args.width, args.height
     readout = 0.0 if args.c1 else 16.0
     cquat = S.quat_from_euler_deg(5.0, 2.0, 3.0) if args.c1 else None
@@ -363,8 +367,8 @@ def worker(args):
 
     # ---- clip mode: the steps reach the library as gfw_undistort_clip calls of `clip_n` frames (the frames of one call use distinct
     # destination sets: the specialised kernel takes up to 8 of them in one launch)
-    clip_n = max(1, min(args.clip, N_DST) if device_built else min(args.clip, N_DST, NR))
-    if args.upload_matrices or args.host_buffers or n_streams > 1 or (device_built and not args.c5) or (NR % clip_n and not device_built):
+    clip_n = max(1, min(args.clip, CLIP_FRAMES) if device_built else min(args.clip, CLIP_FRAMES, NR))
+    if args.upload_matrices or args.host_buffers or (device_built and not args.c5) or (NR % clip_n and not device_built):
         clip_n = 1
     if args.c5 and BATCH % clip_n:
         clip_n = 1
@@ -385,15 +389,19 @@ def worker(args):
     clip_cache = {}
 
     def clip_for(k0, ln):
-        """pre-marshalled gfw_undistort_clip call for steps k0 .. k0+ln-1"""
+        """pre-marshalled gfw_undistort_clip call for steps k0 .. k0+ln-1 (with --streams S, launch c goes to context c mod S)"""
         js = tuple(plan(k0 + i)[1] for i in range(ln))
-        call = clip_cache.get(js)
+        sidx = (k0 // clip_n) % n_streams
+        call = clip_cache.get((sidx, js))
+        if call is None and sidx:
+            call = warp.ClipCall(all_bes[sidx], [bufsets[j * N_DST + (j % N_DST)] for j in js], tmpl, types, [d_mat[j].data_ptr() for j in js], rows_n)
+            clip_cache[(sidx, js)] = call
         if call is None:
             if device_built:                            # C5: frame i of the call writes destination set i; its table pointer is set per call
                 call = warp.ClipCall(be, [bufsets[j * N_DST + i] for i, j in enumerate(js)], tmpl, types, [table0] * ln, rows_n)
             else:
                 call = warp.ClipCall(be, [bufsets[j * N_DST + (j % N_DST)] for j in js], tmpl, types, [d_mat[j].data_ptr() for j in js], rows_n)
-            clip_cache[js] = call
+            clip_cache[(sidx, js)] = call
         return call
 
     def clip_step(k0, ln):
@@ -454,10 +462,10 @@ def worker(args):
                 ln = min(clip_n, n - k0)
                 if enq_mark[0] is None and k0 >= ENQ_WINDOW:
                     enq_mark[0], enq_mark[1] = time.perf_counter(), k0
-                if bracket_every and c % 2 == 0:        # a launch carries clip_n frames: every other one is bracketed
-                    set_opt(ctxps[0], abi.OPT_PROFILE, 1)
+                if bracket_every and (c // n_streams) % 2 == 0:        # a launch carries clip_n frames: every other one (per stream) is bracketed
+                    set_opt(ctxps[c % n_streams], abi.OPT_PROFILE, 1)
                     clip_step(k0, ln)
-                    set_opt(ctxps[0], abi.OPT_PROFILE, 0)
+                    set_opt(ctxps[c % n_streams], abi.OPT_PROFILE, 0)
                 else:
                     clip_step(k0, ln)
         elif bracket_every > 1:

@@ -108,21 +108,26 @@ def test_sony_mesh_specialised(with_mesh, with_fpd):
     from test_gpu_lens_models import synthetic_mesh
     w, h = 192, 128
     fr = S.SyntheticFrame("NV12", w, h, seed=47, fov=1.1)
-    mesh = synthetic_mesh(w, h, with_fpd, with_mesh)
+    mesh = np.asarray(synthetic_mesh(w, h, with_fpd, with_mesh), dtype=np.float32)
+    ref = []
     for pl in fr.planes:
-        ref = pl["dst"].copy()
-        assert O.undistort_image(pl["src"], pl["size"], ref, pl["out_size"], pl["params"], pl["pixel_type"], fr.model, fr.digital, fr.matrices, mesh=mesh) == 1
-        for jit in (2, 0):
-            dst = pl["dst"].copy()
-            b = warp.host_buffers(pl["src"], pl["size"], dst, pl["out_size"])
-            be = warp.Backend(pl["params"], pl["pixel_type"], fr.model, fr.digital, b)
-            try:
-                be.set_option(abi.OPT_JIT, jit)
-                be.undistort_image(b, pl["params"], fr.matrices, mesh)
-                assert warp.last_backend().endswith("_jit") == (jit == 2), warp.last_backend()
-            finally:
-                be.close()
-            assert_plane_equal(ref, dst, pl["pixel_type"], "mesh, jit %d" % jit)
+        dst = pl["dst"].copy()
+        assert O.undistort_image(pl["src"], pl["size"], dst, pl["out_size"], pl["params"], pl["pixel_type"], fr.model, fr.digital, fr.matrices, mesh=mesh) == 1
+        ref.append(dst)
+    params = [pl["params"] for pl in fr.planes]
+    types = [pl["pixel_type"] for pl in fr.planes]
+    for jit in (2, 0):
+        outs = [pl["dst"].copy() for pl in fr.planes]
+        bufs = [warp.host_buffers(pl["src"], pl["size"], o, pl["out_size"]) for pl, o in zip(fr.planes, outs)]
+        be = warp.Backend(params[0], types[0], fr.model, fr.digital, bufs[0])
+        try:
+            be.set_option(abi.OPT_JIT, jit)
+            be.undistort_frame(bufs, params, types, fr.matrices, mesh=mesh)
+            assert warp.last_backend() == ("yuv_fused_jit" if jit else "yuv_fused"), warp.last_backend()
+        finally:
+            be.close()
+        for i, (a, b) in enumerate(zip(ref, outs)):
+            assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "mesh, jit %d, plane %d" % (jit, i))
 
 
 def test_geometry_variants():
