@@ -71,6 +71,9 @@
                                  // and progress stays level.  0: off.  What it is worth depends on how long a wave lives: nothing on a lone 4K
                                  // frame at 6 waves (79.3 = 79.3 us), 4 us of 59 once a launch carries 8 frames at 8 waves per SIMD.
 #endif
+#ifndef GFW_BAND_ROT
+#define GFW_BAND_ROT 3            // experiment knob (0: every frame of a launch gives XCD x band x)
+#endif
 #ifndef GFW_PRIO_SPAN
 #define GFW_PRIO_SPAN 6          // round 3, C2, 8 waves, 63 lane-rows per wave: fixed divisors 3 / 4 / 5 / 6 / 8 / 12 / 16 / 24 / 32 / 64 gave
                                  // 57.3 / 56.4 / 56.0 / 55.5 / 55.0 / 55.1 / 55.6 / 56.4 / 56.9 / 58.4 us; 1080p (18 rows per wave) wants 3, 8K
@@ -937,7 +940,10 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     // persistent walk over this workgroup's share of the XCD band of tiles
     const int n_tiles = AF(tiles_x) * AF(tiles_y);
     const int per_xcd = (n_tiles + 7) >> 3;
-#define GFW_XCD_TILE(l) (xcd * per_xcd + (l))
+    // frame fi of a clip launch gives XCD x the band (x + GFW_BAND_ROT * fi) mod 8: an XCD works inside one contiguous band per frame (its L2 sees
+    // neighbouring source lines) but sees a different band of every frame, so that cheap bands (the top and bottom of a frame hold most of
+    // the out-of-frame pixels) and dear ones are spread over the eight XCDs instead of always landing on the same ones
+#define GFW_XCD_TILE(fi, l) ((((xcd + GFW_BAND_ROT * (fi)) & 7) * per_xcd) + (l))
     const int wg_per_xcd = (int)gridDim.x >> 3;
     const int xcd = (int)blockIdx.x & 7;
 #if GFW_TIMELINE
@@ -951,14 +957,14 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         else if (remaining >= prio_step) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     };
     int tiles_left = 0;
-    for (int l = (int)blockIdx.x >> 3; l < per_xcd * n_frames; l += wg_per_xcd) if (GFW_XCD_TILE(l % per_xcd) < n_tiles) ++tiles_left;
+    for (int l = (int)blockIdx.x >> 3; l < per_xcd * n_frames; l += wg_per_xcd) { const int fi = l / per_xcd; if (GFW_XCD_TILE(fi, l - fi * per_xcd) < n_tiles) ++tiles_left; }
     prio_step = max(1, (tiles_left * RB + GFW_PRIO_SPAN - 1) / GFW_PRIO_SPAN);
 #endif
     // l walks (frame, tile of this XCD's band): the frames of a launch are dealt tile by tile like one tall frame
     int cur_frame = 0;
     for (int l = (int)blockIdx.x >> 3; l < per_xcd * n_frames; l += wg_per_xcd) {
         const int fi = n_frames > 1 ? l / per_xcd : 0;
-        const int t = GFW_XCD_TILE(l - fi * per_xcd);
+        const int t = GFW_XCD_TILE(fi, l - fi * per_xcd);
         if (t >= n_tiles) continue;                  // the last XCD's band is the short one
 #if GFW_BAKE
         if (fi != cur_frame) {                       // next frame of the launch: its planes and its matrices
