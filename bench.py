@@ -48,7 +48,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FMT, WIDTH, HEIGHT = "YUV422P16LE", 3840, 2160
 N_RESIDENT = 64                  # distinct source frames + per-row matrix tables resident in HBM, cycled by the steps
                                  # (SURVEY.md 8d "64 distinct resident source frames cycled": 2.1 GB, far beyond L2 + MALL)
-CLIP_FRAMES = 8                  # frames of one gfw_undistort_clip launch (GFW_CLIP_MAX)
+CLIP_FRAMES = 16                 # most frames gfw_undistort_clip puts into one launch (GFW_CLIP_FRAMES_MAX)
 N_DST = 8                        # destination frame sets written round-robin (the frames of one clip launch are in flight together: one set each)
 N_CHECK = 3                      # frames of the timed region compared with the oracle afterwards
 TRAFFIC_FILE = os.path.join("profiles", "r03_c2_traffic.json")
@@ -233,8 +233,8 @@ def worker(args):
     if args.c1:
         args.width, args.height, args.fmt = 1920, 1080, "NV12"
     global N_DST
-    if args.streams > 1 and args.clip > 1:            # clip launches dealt to S streams: each stream's launches write a destination-set group of their own
-        N_DST = CLIP_FRAMES * args.streams
+    # the frames of a clip launch write one destination set each; clip launches dealt to S streams: a group of sets per stream
+    N_DST = max(8, min(args.clip, CLIP_FRAMES)) * (args.streams if args.clip > 1 else 1)
     W, H = args.width, args.height
     readout = 0.0 if args.c1 else 16.0
     cquat = S.quat_from_euler_deg(5.0, 2.0, 3.0) if args.c1 else None

@@ -757,6 +757,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
 }
 
 // Frames of one gfw_undistort_clip call waiting to go out in one launch of the specialised kernel.
+static_assert(GFW_CLIP_MAX == GFW_CLIP_FRAMES_MAX, "gfw_frame.h and gfwarp.h disagree on the frames of a clip launch");
 struct ClipBatch {
     GfwClipArgs CA;
     hipFunction_t fn = nullptr;
@@ -777,6 +778,23 @@ static bool clip_same_shape(const gfw_buffers *a, const gfw_buffers *b, int npla
 }
 static bool clip_ring_table(gfw_ctx *c, const float *m) {          // a table of gfw_build_matrices' cross-stream ring (ordered by events)
     for (int i = 0; i < gfw_ctx::kBuiltSlots; ++i) if (c->bslots[i].buf.ptr == (const void *)m && c->bslots[i].built) return true;
+    return false;
+}
+// The frames of one launch are in flight together, the calls they stand for are ordered: a frame whose planes overlap a pending frame's
+// destination (it would read or overwrite that frame's output) or whose destination overlaps a pending frame's source must go out behind them.
+static bool clip_overlaps(const ClipBatch *b, const gfw_buffers *planes, int nplanes) {
+    auto hit = [](const uint8_t *p, size_t pl, const uint8_t *q, size_t ql) { return p && q && p < q + ql && q < p + pl; };
+    for (int k = 0; k < b->n; ++k) {
+        const GfwFrameDyn &F = b->CA.fr[k];
+        for (int i = 0; i < nplanes; ++i) {
+            const uint8_t *ns = (const uint8_t *)planes[i].input.data, *nd = (const uint8_t *)planes[i].output.data;
+            const size_t nsl = planes[i].input.len, ndl = planes[i].output.len;
+            for (int j = 0; j < nplanes && j < 4; ++j) {
+                const size_t sl = b->first[j].input.len, dl = b->first[j].output.len;
+                if (hit(nd, ndl, F.dst[j], dl) || hit(nd, ndl, F.src[j], sl) || hit(ns, nsl, F.dst[j], dl)) return true;
+            }
+        }
+    }
     return false;
 }
 static int clip_flush(gfw_ctx *c, ClipBatch *b) {
@@ -837,11 +855,13 @@ static std::string bake_header(const GfwYuvArgs &Y) {
 // profiles/r03_ab_waves_priority.txt): C2 bilinear 6 -> 65.4, 7 -> 57.0-59.3, 8 -> 55.0; NV12 64.6 -> 60.5, P010 71.4 -> 67.8, planar f32 97.7 -> 91.5,
 // Lanczos4 180.5 -> 173.6, bicubic 96.3 -> 95.4, fisheye + SuperView 117.3 -> 103.7 at 7 -> 8.  Eight waves lose where a wave's life is short or
 // its registers are many: one matrix per frame (C1 1080p: 9.30 at 7, 10.2 at 8) and packed RGBA planes (C4: 73.0 at 7, 74.7 at 8) stay at seven.
-// The generic-model body with the lens-correction blend, background mode 3 or the Sony mesh (extras 8 / 16 / 32) wants up to 80 registers: six waves.
+// The generic-model body keeps the rule — the lens-correction blend too, although it spills a few dwords at eight waves (GoPro lens, blend 0.5:
+// 141.5 us at 6 waves, 139.2 at 7, 134.4 at 8; fisheye + blend 140.5 / 137.4 / 135.9) — except with background mode 3 or the Sony mesh (two
+// samples per pixel, f64 splines: up to 80 registers), which get six.
 static int jit_waves(int n0, int matrix_count, int jit_model, int extras) {
     static const int forced = getenv("GFW_JIT_WAVES") ? atoi(getenv("GFW_JIT_WAVES")) : 0;      // experiments
     if (forced >= 1 && forced <= 8) return forced;
-    if (jit_model < 0 && (extras & (8 | 16 | 32))) return 6;
+    if (jit_model < 0 && (extras & (16 | 32))) return 6;
     return (n0 == 1 && matrix_count > 1) ? 8 : 7;
 }
 // The specialised kernel for this frame's arguments, or nullptr (not eligible / not wanted / not ready / failed): the caller then
@@ -961,7 +981,7 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
         if (jf && batch && all_device && c->bslot_cur < 0 && c->mslot_cur < 0) {      // (a table of the cross-stream ring is ordered by events: frame by frame)
             // the frame joins the clip launch being assembled; a frame that does not share the pending ones' kernel or first-pass table goes out behind them
             if (batch->n > 0 && (batch->fn != jf || batch->CA.Y.p1_table != Y.p1_table || batch->CA.Y.p1_rho_max != Y.p1_rho_max ||
-                                 batch->CA.Y.p1_rho_scale != Y.p1_rho_scale || batch->CA.Y.p1_eps != Y.p1_eps)) {
+                                 batch->CA.Y.p1_rho_scale != Y.p1_rho_scale || batch->CA.Y.p1_eps != Y.p1_eps || clip_overlaps(batch, planes, nplanes))) {
                 const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc;
             }
             if (batch->n == 0) { batch->CA.Y = Y; batch->fn = jf; batch->grid = jgrid; batch->first = planes; batch->backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit"; }
@@ -1035,13 +1055,13 @@ int gfw_undistort_clip(gfw_ctx *c, int n_frames, int nplanes, const gfw_buffers 
     for (int i = 0; i < nplanes; ++i)
         if (pixel_types[i] < 0 || pixel_types[i] >= GFW_PIX_COUNT) { set_error("plane %d: unknown pixel type %d", i, pixel_types[i]); return GFW_ERR_INVALID_ARGUMENT; }
     // the frame loop of a render (rendering/mod.rs:487-547 calls process_pixels once per frame), here on the library side: frames that
-    // share the specialised kernel leave in launches of up to GFW_CLIP_MAX (8) frames, everything else exactly as gfw_undistort_frame
+    // share the specialised kernel leave in launches of up to GFW_CLIP_MAX frames, everything else exactly as gfw_undistort_frame
     ClipBatch batch;
     for (int f = 0; f < n_frames; ++f) {
         // A frame shaped exactly like the one that opened the pending launch (same descriptions but for the pointers; the parameters are
         // shared by construction) needs none of the per-frame validation again: its pointers join the launch.  ~10 us -> < 1 us of host time.
         if (batch.n > 0 && batch.n < GFW_CLIP_MAX && c->matrices_on_device == 2 && matrices[f] && clip_same_shape(batch.first, planes + (size_t)f * nplanes, nplanes) &&
-            !clip_ring_table(c, matrices[f])) {
+            !clip_ring_table(c, matrices[f]) && !clip_overlaps(&batch, planes + (size_t)f * nplanes, nplanes)) {
             GfwFrameDyn &F = batch.CA.fr[batch.n++];
             for (int i = 0; i < 4; ++i) {
                 F.src[i] = i < nplanes ? (const uint8_t *)planes[(size_t)f * nplanes + i].input.data : nullptr;

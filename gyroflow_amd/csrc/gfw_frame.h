@@ -59,7 +59,7 @@ struct GfwYuvArgs {
 };
 
 // Several frames of one clip in one launch (run-time-specialised kernel only): everything but these pointers is shared.
-#define GFW_CLIP_MAX 8          // frames per launch: 8 measured better than 32 (60.4 against 61.4 us per C2 frame) and a batch reaches the GPU sooner
+#define GFW_CLIP_MAX 16         // frames per launch (= GFW_CLIP_FRAMES_MAX of gfwarp.h)
 struct GfwFrameDyn { const uint8_t *src[4]; uint8_t *dst[4]; const float *matrices; };
 struct GfwClipArgs { GfwYuvArgs Y; int32_t n_frames; int32_t pad_; GfwFrameDyn fr[GFW_CLIP_MAX]; };
 

@@ -71,8 +71,8 @@
                                  // and progress stays level.  0: off.  What it is worth depends on how long a wave lives: nothing on a lone 4K
                                  // frame at 6 waves (79.3 = 79.3 us), 4 us of 59 once a launch carries 8 frames at 8 waves per SIMD.
 #endif
-#ifndef GFW_BAND_ROT
-#define GFW_BAND_ROT 3            // experiment knob (0: every frame of a launch gives XCD x band x)
+#ifndef GFW_SUB_BANDS
+#define GFW_SUB_BANDS 4           // experiment knob: contiguous sub-bands of a frame per XCD
 #endif
 #ifndef GFW_PRIO_SPAN
 #define GFW_PRIO_SPAN 6          // round 3, C2, 8 waves, 63 lane-rows per wave: fixed divisors 3 / 4 / 5 / 6 / 8 / 12 / 16 / 24 / 32 / 64 gave
@@ -939,13 +939,19 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
 
     // persistent walk over this workgroup's share of the XCD band of tiles
     const int n_tiles = AF(tiles_x) * AF(tiles_y);
-    const int per_xcd = (n_tiles + 7) >> 3;
-    // frame fi of a clip launch gives XCD x the band (x + GFW_BAND_ROT * fi) mod 8: an XCD works inside one contiguous band per frame (its L2 sees
-    // neighbouring source lines) but sees a different band of every frame, so that cheap bands (the top and bottom of a frame hold most of
-    // the out-of-frame pixels) and dear ones are spread over the eight XCDs instead of always landing on the same ones
-#define GFW_XCD_TILE(fi, l) ((((xcd + GFW_BAND_ROT * (fi)) & 7) * per_xcd) + (l))
-    const int wg_per_xcd = (int)gridDim.x >> 3;
+    // A frame's tiles form 8 * GFW_SUB_BANDS contiguous sub-bands; XCD x owns sub-bands x, x + 8, x + 16, ... of a frame, rotated by three
+    // for every further frame of a clip launch.  An XCD still works inside contiguous runs of tile rows (its L2 sees neighbouring source
+    // lines), but cheap regions (the top and bottom of a frame hold most of the out-of-frame pixels) and dear ones no longer land on the
+    // same XCDs every frame: one band per XCD measured 54.6 us per C2 frame, rotating it across the clip's frames 51.1.
     const int xcd = (int)blockIdx.x & 7;
+    constexpr int SUB = GFW_SUB_BANDS;
+    const int per_sub = (n_tiles + 8 * SUB - 1) / (8 * SUB);
+    const int per_xcd = SUB * per_sub;                    // tile slots of one XCD in one frame (the last sub-bands may run past n_tiles)
+    auto xcd_tile = [&](int fi, int r) {                  // slot r of this XCD in frame fi -> tile index (>= n_tiles: none)
+        const int h = r / per_sub;
+        return ((((xcd + 3 * fi) & 7) + 8 * h) * per_sub) + (r - h * per_sub);
+    };
+    const int wg_per_xcd = (int)gridDim.x >> 3;
 #if GFW_TIMELINE
     const unsigned long long tl_start = wall_clock64();
     unsigned long long tl_p1 = 0, tl_p3 = 0, tl_units = 0;
@@ -957,15 +963,15 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         else if (remaining >= prio_step) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     };
     int tiles_left = 0;
-    for (int l = (int)blockIdx.x >> 3; l < per_xcd * n_frames; l += wg_per_xcd) { const int fi = l / per_xcd; if (GFW_XCD_TILE(fi, l - fi * per_xcd) < n_tiles) ++tiles_left; }
+    for (int l = (int)blockIdx.x >> 3; l < per_xcd * n_frames; l += wg_per_xcd) { const int fi = l / per_xcd; if (xcd_tile(fi, l - fi * per_xcd) < n_tiles) ++tiles_left; }
     prio_step = max(1, (tiles_left * RB + GFW_PRIO_SPAN - 1) / GFW_PRIO_SPAN);
 #endif
     // l walks (frame, tile of this XCD's band): the frames of a launch are dealt tile by tile like one tall frame
     int cur_frame = 0;
     for (int l = (int)blockIdx.x >> 3; l < per_xcd * n_frames; l += wg_per_xcd) {
         const int fi = n_frames > 1 ? l / per_xcd : 0;
-        const int t = GFW_XCD_TILE(fi, l - fi * per_xcd);
-        if (t >= n_tiles) continue;                  // the last XCD's band is the short one
+        const int t = xcd_tile(fi, l - fi * per_xcd);
+        if (t >= n_tiles) continue;                  // the last sub-bands are the short ones
 #if GFW_BAKE
         if (fi != cur_frame) {                       // next frame of the launch: its planes and its matrices
             cur_frame = fi;
@@ -1143,7 +1149,6 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         o[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); o[6] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); o[7] = blockIdx.x;
     }
 #endif
-#undef GFW_XCD_TILE
 }
 
 #if GFW_JIT

@@ -251,8 +251,11 @@ int gfw_undistort_frame(gfw_ctx *ctx, int nplanes,
  * `params` (nplanes entries) and `pixel_types` are shared by all frames; matrices[f] is frame f's table, with the meaning
  * GFW_OPT_MATRICES_ON_DEVICE gives it.  Frames are warped in order on the context's stream with the results of
  * gfw_undistort_frame; frames with HIP_DEVICE buffers and device-resident tables that share the context's run-time specialised
- * kernel (GFW_OPT_JIT) leave in launches of up to 8 frames, so that the occupancy tail of one frame is filled by the next
- * (the frames of one launch are in flight together: their destination buffers must be distinct). */
+ * kernel (GFW_OPT_JIT) leave in launches of up to GFW_CLIP_FRAMES_MAX frames, so that the occupancy tail of one frame is
+ * filled by the next and the cost differences between image regions average out over the GPU's partitions.  The frames of
+ * one launch are in flight together; a frame whose buffers overlap a pending frame's (it writes or reads a destination
+ * already in the launch, or writes one of its sources) starts a new launch, so the results are those of the ordered calls. */
+#define GFW_CLIP_FRAMES_MAX 16
 int gfw_undistort_clip(gfw_ctx *ctx, int n_frames, int nplanes,
                        const gfw_buffers *planes,
                        const gfw_kernel_params *params,

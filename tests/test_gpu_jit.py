@@ -143,7 +143,7 @@ def test_geometry_variants():
     check_jit(S.SyntheticFrame("RGBAF32", 320, 192, seed=33, fov=0.82, base_overrides={"translation2d": (13.25, -7.5)}), "adaptive-zoom crop")
 
 
-def device_clip(frames, jit_mode, use_clip, reps=1):
+def device_clip(frames, jit_mode, use_clip, reps=1, shared_dst=False, chain=False):
     """Frames through HIP_DEVICE buffers and device-resident tables on one context: frame by frame, or gfw_undistort_clip.
     Returns (backend of the last call, jit status, outputs per frame)."""
     import torch
@@ -154,6 +154,10 @@ def device_clip(frames, jit_mode, use_clip, reps=1):
     torch.cuda.synchronize(dev)
     types = [pl["pixel_type"] for pl in frames[0].planes]
     params = [pl["params"] for pl in frames[0].planes]
+    if shared_dst:                                    # every frame writes frame 0's destination
+        d_dst = [d_dst[0]] * len(frames)
+    if chain:                                         # frame j reads what frame j - 1 wrote (same plane sizes on both sides)
+        d_src = [d_src[0]] + d_dst[:-1]
     bufs = [[warp.device_buffers(d_src[j][p].data_ptr(), d_src[j][p].numel(), pl["size"], d_dst[j][p].data_ptr(), d_dst[j][p].numel(), pl["out_size"])
              for p, pl in enumerate(fr.planes)] for j, fr in enumerate(frames)]
     rows = frames[0].matrices.shape[0]
@@ -184,13 +188,31 @@ def test_clip_entry_point_matches_frame_by_frame_and_the_oracle(fmt, n):
     frames = [S.SyntheticFrame(fmt, 320, 192, seed=0x9F10 + j, timestamp_ms=1000.0 + 33.3 * j, pixels=False) for j in range(n)]
     backend, status, (ms, launches, covered), outs, srcs = device_clip(frames, 2, True)
     assert backend.endswith("_jit") and status[0] == 2, (backend, status)
-    assert covered == n and launches == (n + 7) // 8, (launches, covered)          # launches of up to 8 frames
+    assert covered == n and launches == (n + abi.CLIP_MAX - 1) // abi.CLIP_MAX, (launches, covered)          # launches of up to GFW_CLIP_FRAMES_MAX frames
     _, _, _, outs_fb, _ = device_clip(frames, 0, False)
     for j, fr in enumerate(frames):
         ref = O.run_frame(_View(fr, srcs[j]))
         for p, (a, b, c) in enumerate(zip(ref, outs[j], outs_fb[j])):
             assert_plane_equal(a, b, fr.planes[p]["pixel_type"], "clip launch, frame %d plane %d" % (j, p))
             assert_plane_equal(a, c, fr.planes[p]["pixel_type"], "frame by frame, frame %d plane %d" % (j, p))
+
+
+def test_clip_frames_that_touch_a_pending_frames_buffers_leave_in_order():
+    """The calls a clip stands for are ordered.  Frames that all write one destination go out one by one (the last one wins); a frame that
+    reads the previous frame's output waits for it — same bytes as the frame-by-frame loop either way."""
+    frames = [S.SyntheticFrame("YUV422P16LE", 320, 192, seed=0x9F10 + j, timestamp_ms=1000.0 + 33.3 * j, pixels=False) for j in range(5)]
+    backend, status, (ms, launches, covered), outs, srcs = device_clip(frames, 2, True, shared_dst=True)
+    assert backend.endswith("_jit") and covered == 5 and launches == 5, (backend, launches, covered)
+    ref = O.run_frame(_View(frames[4], srcs[4]))
+    for p, (a, b) in enumerate(zip(ref, outs[0])):
+        assert_plane_equal(a, b, frames[4].planes[p]["pixel_type"], "shared destination, plane %d" % p)
+    frames = [S.SyntheticFrame("YUV444P16LE", 320, 192, seed=0x9F10 + j, timestamp_ms=1000.0 + 33.3 * j, pixels=False) for j in range(4)]
+    backend, status, (ms, launches, covered), outs, srcs = device_clip(frames, 2, True, chain=True)
+    assert backend.endswith("_jit") and covered == 4 and launches == 4, (backend, launches, covered)
+    _, _, _, outs_fb, _ = device_clip(frames, 0, False, chain=True)
+    for j in range(4):
+        for p, (a, b) in enumerate(zip(outs_fb[j], outs[j])):
+            assert np.array_equal(a, b), "chained frames, frame %d plane %d" % (j, p)
 
 
 def test_clip_entry_point_without_the_specialised_kernel_runs_frame_by_frame():
