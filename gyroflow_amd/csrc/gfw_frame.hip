@@ -71,6 +71,9 @@
                                  // and progress stays level.  0: off.  What it is worth depends on how long a wave lives: nothing on a lone 4K
                                  // frame at 6 waves (79.3 = 79.3 us), 4 us of 59 once a launch carries 8 frames at 8 waves per SIMD.
 #endif
+#ifndef GFW_DYN_TAIL
+#define GFW_DYN_TAIL 3            // experiment knob: sixteenths of a launch's tiles handed out dynamically, wave by wave, at the end (0: none)
+#endif
 #ifndef GFW_SUB_BANDS
 #define GFW_SUB_BANDS 4           // experiment knob: contiguous sub-bands of a frame per XCD
 #endif
@@ -858,7 +861,9 @@ __device__ __forceinline__ bool pass1_fast(float ax, float ay, float aw, float o
 }
 
 #if GFW_TIMELINE
-__device__ unsigned long long gfw_tl[8192 * 8];
+}  // namespace
+extern "C" { __device__ unsigned long long gfw_tl[8192 * 8]; }      // external name: the host reads it by symbol (hipModuleGetGlobal in a run-time build)
+namespace {
 #endif
 // The kernel body.  `clip` (baked builds only): the per-frame pointers of the frames of one launch — the frames of a clip share every
 // other argument, so a launch can carry several of them and the occupancy tail of one frame is filled by the next (the effect two
@@ -952,6 +957,14 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         return ((((xcd + 3 * fi) & 7) + 8 * h) * per_sub) + (r - h * per_sub);
     };
     const int wg_per_xcd = (int)gridDim.x >> 3;
+    const int n_slots = per_xcd * n_frames;
+#if GFW_BAKE
+    unsigned *const sched = clip ? clip->sched : nullptr;      // [0..7] the XCDs' tail counters, [8..15] waves that have left: zero between launches
+    // GFW_DYN_TAIL sixteenths of an XCD's slots are not dealt in advance (a whole number of rounds is)
+    const int n_static = (GFW_DYN_TAIL > 0 && sched != nullptr) ? ((n_slots * (16 - GFW_DYN_TAIL)) >> 4) / wg_per_xcd * wg_per_xcd : n_slots;
+#else
+    const int n_static = n_slots;
+#endif
 #if GFW_TIMELINE
     const unsigned long long tl_start = wall_clock64();
     unsigned long long tl_p1 = 0, tl_p3 = 0, tl_units = 0;
@@ -963,14 +976,40 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         else if (remaining >= prio_step) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     };
     int tiles_left = 0;
-    for (int l = (int)blockIdx.x >> 3; l < per_xcd * n_frames; l += wg_per_xcd) { const int fi = l / per_xcd; if (xcd_tile(fi, l - fi * per_xcd) < n_tiles) ++tiles_left; }
+    for (int l = (int)blockIdx.x >> 3; l < n_static; l += wg_per_xcd) { const int fi = l / per_xcd; if (xcd_tile(fi, l - fi * per_xcd) < n_tiles) ++tiles_left; }
     prio_step = max(1, (tiles_left * RB + GFW_PRIO_SPAN - 1) / GFW_PRIO_SPAN);
 #endif
-    // l walks (frame, tile of this XCD's band): the frames of a launch are dealt tile by tile like one tall frame
+    // l walks (frame, tile of this XCD's band): the frames of a launch are dealt tile by tile like one tall frame.  The first n_static slots
+    // are dealt statically (workgroup w takes slots w, w + W, ...: its four waves the four 4-row strips of the tile); the rest — the tail —
+    // wave by wave from the XCD's counter, so that the waves of the launch end together (see GFW_DYN_TAIL above)
     int cur_frame = 0;
-    for (int l = (int)blockIdx.x >> 3; l < per_xcd * n_frames; l += wg_per_xcd) {
-        const int fi = n_frames > 1 ? l / per_xcd : 0;
-        const int t = xcd_tile(fi, l - fi * per_xcd);
+    int l = (int)blockIdx.x >> 3;
+    bool dynamic = false;
+    for (;;) {
+        int slot, strip = wave;
+        if (!dynamic) {
+            if (l < n_static) { slot = l; l += wg_per_xcd; }
+            else {
+                if (n_static >= n_slots) break;
+                dynamic = true;
+#if GFW_PRIO_MODE
+                __builtin_amdgcn_s_setprio(0);
+#endif
+                continue;
+            }
+        } else {
+#if GFW_BAKE
+            unsigned u = 0;
+            if (lane == 0) u = atomicAdd(&sched[xcd], 1u);
+            u = (unsigned)__builtin_amdgcn_readfirstlane((int)u);
+            if (u >= (unsigned)(n_slots - n_static) * 4u) break;
+            slot = n_static + (int)(u >> 2); strip = (int)(u & 3u);
+#else
+            break;
+#endif
+        }
+        const int fi = n_frames > 1 ? slot / per_xcd : 0;
+        const int t = xcd_tile(fi, slot - fi * per_xcd);
         if (t >= n_tiles) continue;                  // the last sub-bands are the short ones
 #if GFW_BAKE
         if (fi != cur_frame) {                       // next frame of the launch: its planes and its matrices
@@ -982,11 +1021,11 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         }
 #endif
 #if GFW_PRIO_MODE == 1
-        set_prio(tiles_left * RB);
+        if (!dynamic) set_prio(tiles_left * RB);
 #endif
         const int ty = t / AF(tiles_x), tx = t - ty * AF(tiles_x);
         const int cx = tx * 64 + lane;
-        const int cy0 = (ty * 4 + wave) * RB;            // first chroma-site row of this lane
+        const int cy0 = (ty * 4 + strip) * RB;           // first chroma-site row of this lane
         // a frame whose chroma-site grid is whole tiles (4K: 1920 x 2160 sites = 30 x 135 tiles of 64 x 16) needs none of the per-pixel bounds
         // tests; only a baked build knows at compile time (WHOLE folds, the tests below vanish)
         const bool WHOLE = GFW_BAKE && (AF(cw) % 64 == 0) && (AF(ch) % (4 * RB) == 0) && (AF(out_w) == AF(cw) * DW) && (AF(out_h) == AF(ch) * DH);
@@ -1142,6 +1181,12 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         { const unsigned long long tl_c = __builtin_readcyclecounter(); tl_p1 += tl_b - tl_a; tl_p3 += tl_c - tl_b; tl_units += (unsigned long long)RB; }
 #endif
     }
+#if GFW_BAKE
+    // the last wave of this XCD to leave (every wave ends with one fetch past the tail) clears the counters for the next launch
+    if (n_static < n_slots && lane == 0) {
+        if (atomicAdd(&sched[8 + xcd], 1u) == (unsigned)(wg_per_xcd * 4 - 1)) { atomicExch(&sched[xcd], 0u); atomicExch(&sched[8 + xcd], 0u); }
+    }
+#endif
 #if GFW_TIMELINE
     if (lane == 0) {       // per wave: start, end (100 MHz device clock), phase clocks, lane-rows, HW_ID, XCC_ID, workgroup
         unsigned long long *o = gfw_tl + ((size_t)blockIdx.x * 4 + wave) * 8;

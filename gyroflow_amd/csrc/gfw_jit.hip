@@ -162,6 +162,19 @@ long gfw_jit_compile_only(const std::string &arch, const std::vector<std::string
     return n;
 }
 
+// Diagnosis builds (GFW_JIT_DEFS=GFW_TIMELINE=1): copy a __device__ array of the module that holds `fn` to the host.
+bool gfw_jit_read_symbol(hipFunction_t fn, const char *name, void *dst, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &kv : g_cache) {
+        Entry *e = kv.second.get();
+        if (e->fn != fn || !e->mod) continue;
+        hipDeviceptr_t p = nullptr; size_t n = 0;
+        if (hipModuleGetGlobal(&p, &n, e->mod, name) != hipSuccess || n < bytes) return false;
+        return hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    return false;
+}
+
 hipError_t gfw_jit_launch(hipFunction_t fn, const GfwClipArgs &C, int grid, hipStream_t s) {
     size_t size = sizeof(GfwClipArgs);
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<GfwClipArgs *>(&C), HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};

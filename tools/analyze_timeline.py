@@ -31,3 +31,17 @@ print("per-CU last end us: min %.1f p50 %.1f max %.1f;   rows per CU: min %d max
 ts = np.linspace(0, e_us.max(), 21)
 occ = [(np.sum((s_us <= t) & (e_us > t))) / 1024.0 for t in ts]
 print("resident waves per SIMD over time:", " ".join("%.1f" % o for o in occ))
+# how level the launch is: wave-slot time that does no work before the last wave ends, where the waves end, and the same per XCD
+span = e_us.max() - s_us.min()
+print("busy fraction of the launch: %.4f   (idle before start %.4f, idle after end %.4f)" % (
+    life.sum() / (n * span), (s_us - s_us.min()).sum() / (n * span), (e_us.max() - e_us).sum() / (n * span)))
+print("wave end us percentiles 1/5/25/50/75/95/99/100: " + " ".join("%.1f" % v for v in np.percentile(e_us, [1, 5, 25, 50, 75, 95, 99, 100])))
+for x in sorted(set(xcc.tolist())):
+    m = xcc == x
+    print("  xcc %d: end p5 %.1f p50 %.1f max %.1f   idle-after-end share %.4f" % (x, *np.percentile(e_us[m], [5, 50]), e_us[m].max(), (e_us.max() - e_us[m]).sum() / (m.sum() * span)))
+simd_key = key * 4 + simd
+sk = np.unique(simd_key)
+send = np.array([e_us[simd_key == k].max() for k in sk])
+print("per-SIMD last end us: p5 %.1f p50 %.1f p95 %.1f max %.1f" % (*np.percentile(send, [5, 50, 95]), send.max()))
+per_row = life / np.maximum(units, 1)
+print("us per lane-row by wave: p5 %.3f p50 %.3f p95 %.3f" % tuple(np.percentile(per_row, [5, 50, 95])))
