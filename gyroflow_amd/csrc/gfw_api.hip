@@ -78,7 +78,6 @@ struct gfw_ctx {
     size_t src_len = 0, dst_len = 0;              // sizes declared at create (opencl.rs:287-293)
     std::vector<DevBuf> stage_src, stage_dst;      // per-plane staging for HOST buffers
     DevBuf d_mesh;
-    DevBuf d_sched;                                // 16 words, zero between launches: the tail scheduler of the specialised kernel (gfw_frame.hip)
     // per-row matrices: ring of (pinned host, device) slots so that an asynchronous caller can enqueue several frames;
     // uploads run on their own stream and overlap the previous frame's kernel.
     struct MatSlot { float *h = nullptr; float *d = nullptr; hipEvent_t copied = nullptr, done = nullptr; bool used = false; };
@@ -248,7 +247,6 @@ gfw_ctx *gfw_create(const gfw_kernel_params *params, int pixel_type, int distort
         ok = ok && hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, prio_hi) == hipSuccess;
     }
     ok = ok && c->d_mesh.ensure(GFW_MESH_MAX * sizeof(float)) == hipSuccess;
-    ok = ok && c->d_sched.ensure(64) == hipSuccess && hipMemset(c->d_sched.ptr, 0, 64) == hipSuccess;
     const size_t mat_bytes = (size_t)c->max_matrix_rows * GFW_MAT_STRIDE * sizeof(float);
     for (int i = 0; i < gfw_ctx::kMatSlots && ok; ++i) {
         gfw_ctx::MatSlot &s = c->mslots[i];
@@ -270,7 +268,7 @@ void gfw_destroy(gfw_ctx *c) {
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &b : c->stage_src) b.release();
     for (auto &b : c->stage_dst) b.release();
-    c->d_mesh.release(); c->d_sched.release(); c->d_p1_table.release(); c->d_audit.release(); c->d_tracks.release(); c->d_offsets.release(); for (auto &ss : c->sslots) { ss.d.release(); if (ss.h) (void)hipHostFree(ss.h); if (ss.done) (void)hipEventDestroy(ss.done); } c->d_prefix.release(); c->d_timings.release(); c->d_batch[0].release(); c->d_batch[1].release();
+    c->d_mesh.release(); c->d_p1_table.release(); c->d_audit.release(); c->d_tracks.release(); c->d_offsets.release(); for (auto &ss : c->sslots) { ss.d.release(); if (ss.h) (void)hipHostFree(ss.h); if (ss.done) (void)hipEventDestroy(ss.done); } c->d_prefix.release(); c->d_timings.release(); c->d_batch[0].release(); c->d_batch[1].release();
     if (c->h_timings) (void)hipHostFree(c->h_timings);
     for (auto &e : c->timing_copied) if (e) (void)hipEventDestroy(e);
     for (auto &b : c->bslots) { b.buf.release(); if (b.built) (void)hipEventDestroy(b.built); if (b.consumed) (void)hipEventDestroy(b.consumed); }
@@ -799,17 +797,11 @@ static bool clip_overlaps(const ClipBatch *b, const gfw_buffers *planes, int npl
     }
     return false;
 }
-// The tail scheduler's counters, or nullptr (GFW_DYN_TAIL=0 in the environment: every tile dealt in advance — experiments)
-static unsigned *sched_words(gfw_ctx *c) {
-    static const bool off = getenv("GFW_DYN_TAIL") && atoi(getenv("GFW_DYN_TAIL")) == 0;
-    return off ? nullptr : (unsigned *)c->d_sched.ptr;
-}
 static int clip_flush(gfw_ctx *c, ClipBatch *b) {
     if (!b || b->n == 0) return GFW_OK;
-    b->CA.n_frames = b->n; b->CA.pad_ = 0; b->CA.sched = sched_words(c);
+    b->CA.n_frames = b->n; b->CA.pad_ = 0;
     prof_begin(c);
     const hipError_t e = gfw_jit_launch(b->fn, b->CA, b->grid, c->stream);
-    if (e != hipSuccess) (void)hipMemsetAsync(c->d_sched.ptr, 0, 64, c->stream);     // whatever a failed launch left in the counters
     prof_end(c, b->n);
     {   // diagnosis (GFW_JIT_DEFS=GFW_TIMELINE=1 builds): the 40th clip launch's per-wave clocks go to $GFW_TIMELINE_FILE (tools/analyze_timeline.py)
         static const char *tl_file = getenv("GFW_TIMELINE_FILE");
@@ -1014,7 +1006,7 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
         prof_begin(c);
         if (jf) {
             GfwClipArgs CA;
-            CA.Y = Y; CA.n_frames = 1; CA.pad_ = 0; CA.sched = sched_words(c);
+            CA.Y = Y; CA.n_frames = 1; CA.pad_ = 0;
             HIP_TRY(gfw_jit_launch(jf, CA, jgrid, c->stream), GFW_ERR_HIP);
             c->last_backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit";
         } else {

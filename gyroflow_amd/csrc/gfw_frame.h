@@ -61,7 +61,7 @@ struct GfwYuvArgs {
 // Several frames of one clip in one launch (run-time-specialised kernel only): everything but these pointers is shared.
 #define GFW_CLIP_MAX 16         // frames per launch (= GFW_CLIP_FRAMES_MAX of gfwarp.h)
 struct GfwFrameDyn { const uint8_t *src[4]; uint8_t *dst[4]; const float *matrices; };
-struct GfwClipArgs { GfwYuvArgs Y; int32_t n_frames; int32_t pad_; unsigned *sched; GfwFrameDyn fr[GFW_CLIP_MAX]; };   // sched: 16 zeroed words (tail scheduler), or nullptr
+struct GfwClipArgs { GfwYuvArgs Y; int32_t n_frames; int32_t pad_; GfwFrameDyn fr[GFW_CLIP_MAX]; };
 
 #if !defined(GFW_JIT) || !GFW_JIT
 int gfw_yuv_rows_per_lane(bool fast1, int tune_rb);

@@ -23,10 +23,11 @@
 //   * persistent workgroups: the grid is sized to the machine and each workgroup walks a band of tiles, so the
 //     ~5 us start-up of a wave (kernel-argument loads) is paid once, not once per tile; the issue priority of a wave follows the
 //     work it has left (GFW_PRIO_MODE), which keeps the waves of a SIMD level;
-//   * XCD-banded tile order (workgroup b runs on XCD b % 8): an XCD's L2 sees a contiguous band of source lines;
+//   * XCD-banded tile order (workgroups b, b + 8, ... share an XCD): an XCD's L2 sees contiguous runs of source lines — four sub-bands of a
+//     frame per XCD, rotated from frame to frame of a clip launch, so that no XCD always gets the cheap (top, bottom) or the dear regions;
 //   * two builds of one source: ahead of time, every instantiation the dispatcher can reach (arguments in the kernel-argument
-//     segment); and at run time, per clip, ONE instantiation with the clip's constants as literals and up to 8 frames per launch
-//     (GFW_JIT / GFW_BAKE, gfw_jit.hip) — 75 against 55 us per 4K frame.
+//     segment); and at run time, per clip, ONE instantiation with the clip's constants as literals and up to 16 frames per launch
+//     (GFW_JIT / GFW_BAKE, gfw_jit.hip) — 74 against 51 us per 4K frame.
 //
 // Eligibility (decided on the host, gfw_api.hip build_yuv_args): bilinear / bicubic / Lanczos4 taps (this file is
 // compiled once per tap count and sample type), background_mode 0-3, no input rotation,
@@ -70,12 +71,6 @@
                                  // 3, 2 and 1 x (its total / GFW_PRIO_SPAN), re-evaluated every row: waves with more work left are served first
                                  // and progress stays level.  0: off.  What it is worth depends on how long a wave lives: nothing on a lone 4K
                                  // frame at 6 waves (79.3 = 79.3 us), 4 us of 59 once a launch carries 8 frames at 8 waves per SIMD.
-#endif
-#ifndef GFW_DYN_TAIL
-#define GFW_DYN_TAIL 3            // experiment knob: sixteenths of a launch's tiles handed out dynamically, wave by wave, at the end (0: none)
-#endif
-#ifndef GFW_SUB_BANDS
-#define GFW_SUB_BANDS 4           // experiment knob: contiguous sub-bands of a frame per XCD
 #endif
 #ifndef GFW_PRIO_SPAN
 #define GFW_PRIO_SPAN 6          // round 3, C2, 8 waves, 63 lane-rows per wave: fixed divisors 3 / 4 / 5 / 6 / 8 / 12 / 16 / 24 / 32 / 64 gave
@@ -944,12 +939,12 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
 
     // persistent walk over this workgroup's share of the XCD band of tiles
     const int n_tiles = AF(tiles_x) * AF(tiles_y);
-    // A frame's tiles form 8 * GFW_SUB_BANDS contiguous sub-bands; XCD x owns sub-bands x, x + 8, x + 16, ... of a frame, rotated by three
+    // A frame's tiles form 8 * SUB contiguous sub-bands; XCD x owns sub-bands x, x + 8, x + 16, ... of a frame, rotated by three
     // for every further frame of a clip launch.  An XCD still works inside contiguous runs of tile rows (its L2 sees neighbouring source
     // lines), but cheap regions (the top and bottom of a frame hold most of the out-of-frame pixels) and dear ones no longer land on the
     // same XCDs every frame: one band per XCD measured 54.6 us per C2 frame, rotating it across the clip's frames 51.1.
     const int xcd = (int)blockIdx.x & 7;
-    constexpr int SUB = GFW_SUB_BANDS;
+    constexpr int SUB = 4;                                // (1: 51.13 us per C2 frame in clip launches / 60.8 frame by frame, 4: 51.02 / 57.9, 8: 50.85)
     const int per_sub = (n_tiles + 8 * SUB - 1) / (8 * SUB);
     const int per_xcd = SUB * per_sub;                    // tile slots of one XCD in one frame (the last sub-bands may run past n_tiles)
     auto xcd_tile = [&](int fi, int r) {                  // slot r of this XCD in frame fi -> tile index (>= n_tiles: none)
@@ -958,13 +953,6 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     };
     const int wg_per_xcd = (int)gridDim.x >> 3;
     const int n_slots = per_xcd * n_frames;
-#if GFW_BAKE
-    unsigned *const sched = clip ? clip->sched : nullptr;      // [0..7] the XCDs' tail counters, [8..15] waves that have left: zero between launches
-    // GFW_DYN_TAIL sixteenths of an XCD's slots are not dealt in advance (a whole number of rounds is)
-    const int n_static = (GFW_DYN_TAIL > 0 && sched != nullptr) ? ((n_slots * (16 - GFW_DYN_TAIL)) >> 4) / wg_per_xcd * wg_per_xcd : n_slots;
-#else
-    const int n_static = n_slots;
-#endif
 #if GFW_TIMELINE
     const unsigned long long tl_start = wall_clock64();
     unsigned long long tl_p1 = 0, tl_p3 = 0, tl_units = 0;
@@ -976,38 +964,14 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         else if (remaining >= prio_step) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     };
     int tiles_left = 0;
-    for (int l = (int)blockIdx.x >> 3; l < n_static; l += wg_per_xcd) { const int fi = l / per_xcd; if (xcd_tile(fi, l - fi * per_xcd) < n_tiles) ++tiles_left; }
+    for (int l = (int)blockIdx.x >> 3; l < n_slots; l += wg_per_xcd) { const int fi = l / per_xcd; if (xcd_tile(fi, l - fi * per_xcd) < n_tiles) ++tiles_left; }
     prio_step = max(1, (tiles_left * RB + GFW_PRIO_SPAN - 1) / GFW_PRIO_SPAN);
 #endif
-    // l walks (frame, tile of this XCD's band): the frames of a launch are dealt tile by tile like one tall frame.  The first n_static slots
-    // are dealt statically (workgroup w takes slots w, w + W, ...: its four waves the four 4-row strips of the tile); the rest — the tail —
-    // wave by wave from the XCD's counter, so that the waves of the launch end together (see GFW_DYN_TAIL above)
+    // l walks (frame, tile slot of this XCD): the frames of a launch are dealt tile by tile like one tall frame.  (Handing the last eighth of
+    // a launch's tiles out dynamically, wave by wave from per-XCD counters, levelled the waves' end times — idle wave-slot time 6.3 % -> 3.2 % —
+    // and gained nothing: the SIMDs were busy either way, profiles/r03_ab_scheduling.txt.)
     int cur_frame = 0;
-    int l = (int)blockIdx.x >> 3;
-    bool dynamic = false;
-    for (;;) {
-        int slot, strip = wave;
-        if (!dynamic) {
-            if (l < n_static) { slot = l; l += wg_per_xcd; }
-            else {
-                if (n_static >= n_slots) break;
-                dynamic = true;
-#if GFW_PRIO_MODE
-                __builtin_amdgcn_s_setprio(0);
-#endif
-                continue;
-            }
-        } else {
-#if GFW_BAKE
-            unsigned u = 0;
-            if (lane == 0) u = atomicAdd(&sched[xcd], 1u);
-            u = (unsigned)__builtin_amdgcn_readfirstlane((int)u);
-            if (u >= (unsigned)(n_slots - n_static) * 4u) break;
-            slot = n_static + (int)(u >> 2); strip = (int)(u & 3u);
-#else
-            break;
-#endif
-        }
+    for (int slot = (int)blockIdx.x >> 3; slot < n_slots; slot += wg_per_xcd) {
         const int fi = n_frames > 1 ? slot / per_xcd : 0;
         const int t = xcd_tile(fi, slot - fi * per_xcd);
         if (t >= n_tiles) continue;                  // the last sub-bands are the short ones
@@ -1021,11 +985,11 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         }
 #endif
 #if GFW_PRIO_MODE == 1
-        if (!dynamic) set_prio(tiles_left * RB);
+        set_prio(tiles_left * RB);
 #endif
         const int ty = t / AF(tiles_x), tx = t - ty * AF(tiles_x);
         const int cx = tx * 64 + lane;
-        const int cy0 = (ty * 4 + strip) * RB;           // first chroma-site row of this lane
+        const int cy0 = (ty * 4 + wave) * RB;            // first chroma-site row of this lane
         // a frame whose chroma-site grid is whole tiles (4K: 1920 x 2160 sites = 30 x 135 tiles of 64 x 16) needs none of the per-pixel bounds
         // tests; only a baked build knows at compile time (WHOLE folds, the tests below vanish)
         const bool WHOLE = GFW_BAKE && (AF(cw) % 64 == 0) && (AF(ch) % (4 * RB) == 0) && (AF(out_w) == AF(cw) * DW) && (AF(out_h) == AF(ch) * DH);
@@ -1181,12 +1145,6 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         { const unsigned long long tl_c = __builtin_readcyclecounter(); tl_p1 += tl_b - tl_a; tl_p3 += tl_c - tl_b; tl_units += (unsigned long long)RB; }
 #endif
     }
-#if GFW_BAKE
-    // the last wave of this XCD to leave (every wave ends with one fetch past the tail) clears the counters for the next launch
-    if (n_static < n_slots && lane == 0) {
-        if (atomicAdd(&sched[8 + xcd], 1u) == (unsigned)(wg_per_xcd * 4 - 1)) { atomicExch(&sched[xcd], 0u); atomicExch(&sched[8 + xcd], 0u); }
-    }
-#endif
 #if GFW_TIMELINE
     if (lane == 0) {       // per wave: start, end (100 MHz device clock), phase clocks, lane-rows, HW_ID, XCC_ID, workgroup
         unsigned long long *o = gfw_tl + ((size_t)blockIdx.x * 4 + wave) * 8;
