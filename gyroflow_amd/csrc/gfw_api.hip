@@ -701,6 +701,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     // luma output pixel -> output space identity: x*ow/ow = x
     if (!int_products_exact(p0.output_width, p0.output_width) || !int_products_exact(p0.output_height, p0.output_height)) return false;
     if (p0.output_width >= (1 << 23) || p0.output_height >= (1 << 23)) return false;
+    if (p0.width > 65535 || p0.height > 65535) return false;                // the first pass keeps its row / column indices in 16 bits (s_rows)
     // IBIS/OIS terms (matrices[9..13]): host matrices are scanned, device matrices rely on the flag (get_kernel_flags sets
     // it whenever the clip has IBIS/OIS data, mod.rs:226-251); packed device rows carry cos/sin of the roll from
     // gfw_pack_matrices, raw device rows[14] get them from gfw_repack_matrices_kernel (the same libm routines, restated)

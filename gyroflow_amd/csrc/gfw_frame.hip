@@ -889,7 +889,8 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     const float *matrices = A_in.matrices;             // the current frame's table
     // tile = 64 x 4 lanes; each lane owns RB vertically stacked DW x DH luma blocks (+ their chroma sites).
     constexpr int NPX = DW * DH;
-    constexpr int QCAP = 128 * NPX;                  // a wave adds at most 64*NPX entries per row; flushed at half full
+    constexpr int QSTEP = NPX > 2 ? 2 : NPX;         // pixels of a lane between two looks at the queue
+    constexpr int QCAP = 128 * QSTEP;                // a wave adds at most 64*QSTEP entries between two looks; flushed at half full
     static_assert(RB * NPX <= 64, "slot index must fit the 6 low bits of q_dst");
     // can a projected coordinate be infinite?  Not out of the specialised fisheye projection alone (a*s is bounded by theta_d); every other
     // lens model and any digital lens can produce one, and map_c must then keep it infinite (see map_c)
@@ -897,7 +898,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     __shared__ float q_x[FAST1 ? 4 : 1][FAST1 ? QCAP : 1], q_y[FAST1 ? 4 : 1][FAST1 ? QCAP : 1];
     __shared__ unsigned short q_dst[FAST1 ? 4 : 1][FAST1 ? QCAP : 1];           // (owner lane << 6) | slot in s_rows
     __shared__ unsigned q_n[4];
-    __shared__ int s_rows[RB * NPX][256];                                        // phase-1 rows, one column per lane
+    __shared__ unsigned short s_rows[RB * NPX][256];                             // phase-1 rows (< 65536: the host keeps larger frames off this path), one column per lane
     __shared__ float s_lut[I == 2 ? 1 : 448];                                    // bicubic / Lanczos4 tap table
     const int wave = threadIdx.y, lane = threadIdx.x, tid = wave * 64 + lane;
     if (MODEL == GFW_MODEL_OPENCV_FISHEYE) gfw_atan_lds_init(tid);
@@ -998,6 +999,22 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
 #if GFW_TIMELINE
         const unsigned long long tl_a = __builtin_readcyclecounter();
 #endif
+        // ---- phase 2 (inside phase 1): the wave resolves its queued pixels exactly, densely packed.  Flushed after the last row, or
+        // earlier when the pixels up to the next look (<= 64*QSTEP new entries) could overflow the queue.
+        auto flush_queue = [&](bool last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const unsigned qn = q_n[wave];
+            if (last || qn + 64u * QSTEP > (unsigned)QCAP) {
+                for (unsigned e = lane; e < qn; e += 64) {
+                    const int sy = pass1_exact<MODEL>(q_x[wave][e], q_y[wave][e], M, matrices, L, A);
+                    const unsigned d = q_dst[wave][e];
+                    s_rows[d & 63u][wave * 64 + (d >> 6)] = (unsigned short)sy;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (lane == 0) q_n[wave] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        };
         // ---- phase 1: rolling-shutter row of every luma pixel of this lane ----------------------------
         if (two_pass) {
             if (FAST1) {
@@ -1033,25 +1050,11 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                             sy = pass1_exact<MODEL>(ox, oy, M, matrices, L, A);
                         }
                     }
-                    s_rows[r * NPX + k][tid] = sy;
+                    s_rows[r * NPX + k][tid] = (unsigned short)sy;
+                    if (FAST1 && NPX > QSTEP && (k % QSTEP) == QSTEP - 1 && k != NPX - 1) flush_queue(false);      // 4:2:0: a look at the queue per pixel pair
                 }
               }
-                if (FAST1) {
-                    // ---- phase 2: the wave resolves its queued pixels exactly, densely packed.  Flushed after
-                    // the last row, or earlier when the next row (<= 64*NPX new entries) could overflow the queue.
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    const unsigned qn = q_n[wave];
-                    if (r == RB - 1 || qn + 64u * NPX > (unsigned)QCAP) {
-                        for (unsigned e = lane; e < qn; e += 64) {
-                            const int sy = pass1_exact<MODEL>(q_x[wave][e], q_y[wave][e], M, matrices, L, A);
-                            const unsigned d = q_dst[wave][e];
-                            s_rows[d & 63u][wave * 64 + (d >> 6)] = sy;
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        if (lane == 0) q_n[wave] = 0;
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    }
-                }
+                if (FAST1) flush_queue(r == RB - 1);
             }
         }
 
