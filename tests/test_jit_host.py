@@ -71,3 +71,39 @@ def test_generic_model_body_specialises_without_scratch(tmp_path, model, extras,
     assert n > 0, log.value.decode(errors="replace")[-3000:]
     k = [k for k in KR.report(out) if k[".name"] == "gfw_jit_kernel"][0]
     assert k[".private_segment_fixed_size"] <= (128 if extras & 8 else 0) and k[".vgpr_count"] <= (64 if waves == 8 else 80), (k[".vgpr_count"], k[".private_segment_fixed_size"])
+
+
+def test_420_specialisation_keeps_eight_workgroups_per_cu(tmp_path):
+    """4:2:0 (a lane owns 4 x 4 luma pixels of a tile): the first pass's LDS staging must leave room for eight workgroups per CU — it took
+    37 KB per workgroup (four workgroups, 60 us per 4K NV12 frame) before the row indices went to 16 bits and the queue to a fixed size (45 us)."""
+    import re
+    import struct
+    lib = abi.load_library()
+    header = open(os.path.join(ROOT, "tools", "bake_c2.h")).read()
+
+    def seti(name, v):
+        nonlocal header
+        header, n = re.subn(r"#define GFW_BK_%s \([^\n]*\)" % name, "#define GFW_BK_%s (%d)" % (name, v), header)
+        assert n == 1, name
+
+    def setf(name, v):
+        nonlocal header
+        bits = struct.unpack("<I", struct.pack("<f", v))[0]
+        header, n = re.subn(r"#define GFW_BK_%s __builtin_bit_cast\(float, 0x[0-9a-f]+u\)" % name, "#define GFW_BK_%s __builtin_bit_cast(float, 0x%08xu)" % (name, bits), header)
+        assert n == 1, name
+
+    for k, v in (("nplanes", 2), ("ch", 1080), ("tiles_y", 68), ("pl0_src_stride", 3840), ("pl0_dst_stride", 3840), ("pl1_src_stride", 3840),
+                 ("pl1_dst_stride", 3840), ("pl1_h", 1080), ("pl2_src_stride", 0), ("pl2_dst_stride", 0), ("pl2_w", 0), ("pl2_h", 0)):
+        seti(k, v)
+    for k, v in (("map_cy_mul", 1080.0), ("pl0_limit", 255.0), ("pl1_limit", 255.0), ("pl1_bg_0", 127.5), ("pl1_bg_1", 127.5)):
+        setf(k, v)
+    defs = "GFW_FRAME_KIND=1;GFW_FRAME_TAPS=2;GFW_JIT_WAVES=8;GFW_JIT_MODEL=1;GFW_JIT_T=uint8_t;GFW_JIT_N0=1;GFW_JIT_DW=2;GFW_JIT_DH=2;GFW_JIT_IL=1;GFW_JIT_RB=4;GFW_JIT_FAST1=1"
+    out = str(tmp_path / "nv12.co")
+    log = C.create_string_buffer(1 << 16)
+    n = lib.gfw_debug_jit_compile(b"gfx950", defs.encode(), header.encode(), out.encode(), log, len(log))
+    if n == -2:
+        pytest.skip("libhiprtc.so not available")
+    assert n > 0, log.value.decode(errors="replace")[-3000:]
+    k = [k for k in KR.report(out) if k[".name"] == "gfw_jit_kernel"][0]
+    assert k[".group_segment_fixed_size"] <= 20 * 1024 and k[".vgpr_count"] <= 64 and k[".private_segment_fixed_size"] == 0, k
+    assert KR.workgroups_per_cu(k) >= 8, KR.workgroups_per_cu(k)
