@@ -13,17 +13,25 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  * The product (libgfwarp) never links, loads or calls anything in oracle/.
  *
- * PARITY STATUS: *unpinned by the reference* — gyroflow ships no test, golden
- * vector or fixture for this path, and its Rust cannot be
- * built here (no cargo/rustc).  What pins this file instead:
- *   - analytic known-answer tests (identity warp, integer translation,
- *     background fill, out-of-frame) in tests/test_oracle_kat.py,
- *   - self-generated golden checksums in tests/golden/ (script committed),
- *   - 40-digit mpmath statements of the 14 lens models, both directions, written from
- *     the Rust independently of this file (tests/test_oracle_mpmath.py),
- *   - the reference's own OpenCL kernel compiled offline for gfx950 (oracle/build_ref_cl.py)
- *     and run beside this file on the GPU box as a tolerance-level second opinion
- *     (tests/test_gpu_ref_opencl.py: >= 99.8 % identical pixels).
+ * PARITY STATUS: *pinned on the reference's own code* since round 3 — gyroflow ships no test, golden vector or
+ * fixture for this path and its Rust cannot be built here (no cargo/rustc), but its OpenCL
+ * twin of the path can be: oracle/build_ref_cl.py assembles src/core/gpu/opencl_undistort.cl + the lens model's
+ * .cl the way OclWrapper::new does (opencl.rs:181-214) from /root/reference and compiles that text for the host
+ * cores; oracle/ref_cl_host.c supplies the OpenCL builtins (transcendentals from glibc — what the CPU path calls).
+ *   - tests/golden/ref_golden.json holds what THAT code wrote for 42 configurations in which none of the twin's
+ *     documented deviations from the CPU path can fire (BASELINE's C2 frame at 3840x2160, C1 1080p, C4's crop, every
+ *     pixel type its OpenCL backend serves x bilinear / bicubic / Lanczos4, both shutter directions, edge-repeat and
+ *     mirror backgrounds, stretches, rescaled output, four more lens models, the five digital lenses, IBIS terms, quarter-turn input rotation): this file reproduces every plane BIT
+ *     FOR BIT (tests/test_ref_golden.py, CPU tier), and so does libgfwarp (GPU tier);
+ *   - where the deviations do fire (negative coordinates under the twin's rtz rounding, the r-limit formula, NaN
+ *     coordinates, background mode 3's feather zone) every differing pixel is attributed to one of them, zero
+ *     unexplained, at a 2e-5 px tolerance (tests/test_ref_opencl_host.py); EWA agrees to one code value;
+ *   - the same twin compiled for gfx950 runs beside this file on the GPU box (tests/test_gpu_ref_opencl.py; there its
+ *     atan / tan are OpenCL's, hence a 2e-4 px tolerance);
+ *   - what no twin can pin — the CPU-only colour-range fix (cpu_undistort.rs:255-260 differs from .cl:157-160 by
+ *     design), the Sony mesh beyond 99.9 % (f64 spline here, f32 in the twin), three-channel and half-float pixels — rests on: analytic known-answer tests (tests/test_oracle_kat.py), 40-digit mpmath statements of the 14
+ *     lens models in both directions written from the Rust independently of this file (tests/test_oracle_mpmath.py),
+ *     and self-generated golden checksums (tests/golden/golden.json).
  *
  * Rust semantics honoured here:
  *   f32::round      = half away from zero            -> roundf

@@ -8,6 +8,12 @@ which it differs from the oracle by WHY the reference's GPU twin may differ from
         matrix moves the sample by a few 1/32 px
   neg   a coordinate is negative: for x < 0 the twin's rtz rounding lands one bin above Rust's round-half-away
   invalid  the oracle rejects the ray (w <= 0 or the r-limit test, whose formula differs between the twins: cpu_undistort.rs:139, .cl:402)
+  rlimit   the other way round: an r-limit is set and the twin rejects (writes background for) a ray the CPU path's formula keeps
+  rlimit_row  the two formulas decide the pixel's rolling-shutter first pass differently (rlimit_first_pass_mask): another matrix row
+  nan      the oracle's coordinate is NaN (refraction beyond total reflection): the CPU path samples at `NaN as i32` = 0, the twin writes background
+  sentinel a coordinate (either pass) beyond +-99998: the twin marks invalid rays by the coordinate -99999 (.cl:403,535,616) and casts with C's `(int)`,
+           so a diverged digital-lens iteration is "invalid" there and saturates in Rust
+  feather  background mode 3, inside the feather zone: the twin scales the margin sample about (w-1, h-1), the CPU path about (w, h)
 Anything else is unexplained."""
 import ctypes as C
 import os
@@ -51,6 +57,26 @@ def run_reference_cl(name, pl, matrices, block=(64, 4)):
     return out
 
 
+def run_reference_cl_host(name, pl, matrices, mesh=None):
+    """The same kernel compiled for the host cores (oracle/_ref/gfw_ref_cl_<name>.host.so: oracle/build_ref_cl.py build_host +
+    oracle/ref_cl_host.c): one call of the reference's undistort_image() per work-item of the output plane's NDRange.  No GPU."""
+    path = os.path.join(ROOT, "oracle", "_ref", "gfw_ref_cl_%s.host.so" % name)
+    if not os.path.exists(path):
+        pytest.skip("host build of the reference OpenCL kernel not present (needs /root/reference at build time)")
+    lib = C.CDLL(path)
+    lib.gfw_ref_cl_run.argtypes = [C.c_void_p] * 6 + [C.c_int] * 3
+    lib.gfw_ref_cl_run.restype = None
+    src = np.ascontiguousarray(pl["src"])
+    dst = pl["dst"].copy()
+    prm = np.frombuffer(bytes(pl["params"]), dtype=np.uint8).copy()
+    mat = np.ascontiguousarray(matrices, dtype=np.float32)
+    drawing = np.zeros(16, dtype=np.uint8)
+    mesh = np.zeros(16, dtype=np.float32) if mesh is None else np.ascontiguousarray(mesh, dtype=np.float32)
+    ow, oh = pl["out_size"][0], pl["out_size"][1]
+    lib.gfw_ref_cl_run(src.ctypes.data, dst.ctypes.data, prm.ctypes.data, mat.ctypes.data, drawing.ctypes.data, mesh.ctypes.data, ow, 0, oh)
+    return dst
+
+
 def oracle_plane(fr, idx=0):
     pl = fr.planes[idx]
     dst = pl["dst"].copy()
@@ -86,7 +112,34 @@ def coords_of(fr, pts):
     return res
 
 
-def classify(fr, ref, got, interp, taus=(5e-5, 1e-4, 2e-4, 4e-4, 1e-3), tau_row=2e-3):
+def in_feather_zone(p, u, v):
+    """cpu_undistort.rs:582: the pixel blends a second, margin-scaled sample"""
+    widthf, heightf = float(p.width) - 1.0, float(p.height) - 1.0
+    feather = max(p.background_margin_feather * heightf, 0.0001)
+    return (u > widthf - feather) or (u < feather) or (v > heightf - feather) or (v < feather)
+
+
+def rlimit_first_pass_mask(fr, run_twin):
+    """Pixels whose rolling-shutter FIRST pass (the projection with the middle row's matrix that picks the pixel's own row,
+    cpu_undistort.rs:465-482) is decided differently by the two r-limit formulas: there the twins use different matrix rows for the
+    second pass and the sample moves by a fraction of a pixel.  Found by running both on the same frame with the middle matrix alone
+    (matrix_count = 1: the first pass is then the only pass) and comparing which pixels each leaves as background."""
+    pl = dict(fr.planes[0])
+    p = abi.KernelParams.from_buffer_copy(bytes(pl["params"]))
+    mid = np.ascontiguousarray(fr.matrices[p.matrix_count // 2: p.matrix_count // 2 + 1], dtype=np.float32)
+    p.matrix_count = 1
+    pl["params"] = p
+    dt = np.dtype(abi.PIXEL_TYPES[pl["pixel_type"]][1])
+    w, h = pl["out_size"][0], pl["out_size"][1]
+    dst = pl["dst"].copy()
+    assert O.undistort_image(pl["src"], pl["size"], dst, pl["out_size"], p, pl["pixel_type"], fr.model, fr.digital, mid) == 1
+    a = dst.view(dt).reshape(h, -1)[:, :w]
+    b = run_twin(pl, mid).view(dt).reshape(h, -1)[:, :w]
+    bg = dt.type(np.float32(p.background[0]) * np.float32(p.max_pixel_value))
+    return (a == bg) != (b == bg)
+
+
+def classify(fr, ref, got, interp, taus=(5e-5, 1e-4, 2e-4, 4e-4, 1e-3), tau_row=2e-3, rlimit_row_mask=None):
     """-> dict: differing pixels by class ("bin@tau" cumulative for every tau in taus; a pixel counts as explained by a bin edge at the
     largest tau), "row", "neg", and the unexplained ones with their coordinates"""
     pl = fr.planes[0]
@@ -107,7 +160,7 @@ def classify(fr, ref, got, interp, taus=(5e-5, 1e-4, 2e-4, 4e-4, 1e-3), tau_row=
         return out
     cs = coords_of(fr, list(zip(xs.tolist(), ys.tolist())))
     off = {2: 0.0, 4: 1.0, 8: 3.0}[interp]
-    cls = {"row": 0, "neg": 0, "invalid": 0}
+    cls = {"row": 0, "neg": 0, "invalid": 0, "nan": 0, "rlimit": 0, "rlimit_row": 0, "feather": 0, "sentinel": 0}
     for t in taus:
         cls["bin@%g" % t] = 0
     unexplained = []
@@ -121,8 +174,19 @@ def classify(fr, ref, got, interp, taus=(5e-5, 1e-4, 2e-4, 4e-4, 1e-3), tau_row=
             fr_ = float(t) - np.floor(float(t))
             extra = max(4.0 * float(np.spacing(np.float32(abs(c)))), 1e-6 * abs(float(c) - centre))
             return abs(fr_ - 0.5) / 32.0 - max(0.0, extra - min(taus))
-        d = min(edge_dist(u, float(pl["params"].c[0])), edge_dist(v, float(pl["params"].c[1])))
         p = pl["params"]
+        bgpx = [float(np.float32(p.background[c]) * np.float32(p.max_pixel_value)) for c in range(n)]
+        twin_wrote_bg = all(abs(float(bv) - g) < 1.0 for bv, g in zip(b[y, x].tolist(), bgpx))      # the twin's value is its background (truncated to the pixel type)
+        if not ok:
+            cls["invalid"] += 1                  # the oracle rejects the ray: w <= 0 agrees between the twins, the r-limit formula does not
+            continue
+        if u != u or v != v or (ok1 and p.matrix_count > 1 and (u1 != u1 or v1 != v1)):      # ... or the first pass's coordinate is NaN (its row pick then differs too)
+            cls["nan"] += 1                      # NaN coordinate: the CPU path samples at the cast of NaN (0), the twin's `uv.x > -99998` test writes background (.cl:616)
+            continue
+        if max(abs(u), abs(v)) > 99998.0 or (ok1 and p.matrix_count > 1 and max(abs(u1), abs(v1)) > 99998.0):
+            cls["sentinel"] += 1                 # a coordinate beyond the twin's "invalid" sentinel (-99999: .cl:535,616) or beyond i32 (its C cast is not Rust's saturating one)
+            continue
+        d = min(edge_dist(u, float(p.c[0])), edge_dist(v, float(p.c[1])))
         hrs = bool(p.flags & 16)
         pv = u1 if hrs else v1
         drow = abs((pv - np.floor(pv)) - 0.5) if ok1 else 0.0
@@ -134,8 +198,14 @@ def classify(fr, ref, got, interp, taus=(5e-5, 1e-4, 2e-4, 4e-4, 1e-3), tau_row=
         if not hit:
             if drow <= tau_row and p.matrix_count > 1:
                 cls["row"] += 1
-            elif ok and ((u - off) < 0.0 or (v - off) < 0.0):
+            elif (u - off) < 0.0 or (v - off) < 0.0:
                 cls["neg"] += 1
+            elif p.r_limit > 0.0 and twin_wrote_bg:
+                cls["rlimit"] += 1               # the twin's length((x, y) / w) > r_limit rejects a ray that x^2 + y^2 > r_limit^2 * w (sic) keeps
+            elif rlimit_row_mask is not None and rlimit_row_mask[y, x]:
+                cls["rlimit_row"] += 1           # the two r-limit formulas disagree on the pixel's first pass: a different matrix row
+            elif p.background_mode == 3 and in_feather_zone(p, u, v):
+                cls["feather"] += 1              # margin-with-feather: the twin scales the second sample about (w-1, h-1), the CPU path about (w, h) (.cl:622, cpu_undistort.rs:586)
             else:
                 unexplained.append({"x": x, "y": y, "u": u, "v": v, "bin_dist": float(d), "row_dist": float(drow), "ref": a[y, x].tolist(), "got": b[y, x].tolist()})
     out["classes"] = cls
