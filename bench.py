@@ -624,6 +624,22 @@ def worker(args):
             out["config"]["parity_vs_oracle"] = "bit-exact" if not bad else "MISMATCH at steps %s" % bad
             out["config"]["parity_checked"] = "outputs of timed steps %s (frames %s) vs oracle/gfw_oracle.c, all planes" % (
                 [c[0] for c in checks], [c[1] for c in checks])
+        # ... and against the reference itself: source frame 0 of the default workload is the frame whose output the reference's OWN kernel (its
+        # OpenCL source compiled for the host cores, tests/golden/make_ref_golden.py) froze as tests/golden/ref_golden.json — one more launch
+        # through the timed region's own call path, compared with numbers no restatement stands behind
+        fixture = os.path.join(ROOT, "tests", "golden", "ref_golden.json")
+        c2_default = (W, H, args.fmt, args.interp, args.crop, args.variant, args.host_buffers, bool(args.digital or args.lens_model or args.lca != 1.0),
+                      args.fov, seed_base, device_built, n_streams) == (WIDTH, HEIGHT, FMT, 2, False, 0, False, False, 1.0, 0, False, 1)
+        if not args.no_parity and c2_default and os.path.exists(fixture):
+            want = json.load(open(fixture))["c2_yuv422p16_3840x2160_rs"]["planes"]
+            if clip_n > 1:
+                clip_step(0, min(clip_n, NR))
+            else:
+                step(0)
+            torch.cuda.synchronize()
+            crcs = [zlib.crc32(dst_host(0, p).tobytes()) for p in range(nplanes)]
+            out["config"]["parity_vs_reference_kernel"] = ("bit-exact: CRC32 of all %d planes of frame 0 = tests/golden/ref_golden.json[c2_yuv422p16_3840x2160_rs], written by "
+                                                           "the reference's opencl_undistort.cl compiled for the host" % nplanes) if crcs == want else "MISMATCH %s != %s" % (crcs, want)
         if world == 1 and not args.no_cpu_baseline:
             cores = O.lib().gfw_oracle_num_threads()
             views = [c[3] for c in checks]

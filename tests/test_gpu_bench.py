@@ -34,6 +34,8 @@ def test_driver_command_line():
     assert out["unit"] == "Mpix/s" and out["value"] > 0 and out["higher_is_better"] is True and out["scaling"] == "weak"
     assert out["config"]["workload"].startswith("C2:")
     assert out["config"]["parity_vs_oracle"] == "bit-exact", out["config"]
+    # frame 0 through the timed region's call path = what the reference's own kernel wrote for it (tests/golden/ref_golden.json)
+    assert out["config"]["parity_vs_reference_kernel"].startswith("bit-exact"), out["config"]["parity_vs_reference_kernel"]
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["launches"] >= 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
@@ -55,6 +57,7 @@ def test_ahead_of_time_kernels_frame_by_frame():
     out, _ = run_bench(["--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--jit", "0", "--clip", "1"])
     assert out["config"]["backend"] == "yuv_fused_p1" and out["config"]["jit"]["state"] == "none"
     assert out["config"]["parity_vs_oracle"] == "bit-exact"
+    assert out["config"]["parity_vs_reference_kernel"].startswith("bit-exact"), out["config"]["parity_vs_reference_kernel"]
     assert out["roofline"]["algorithmic_bytes_per_launch"] == 66355200 and out["roofline"]["frames_per_launch"] == 1.0
 
 
