@@ -35,14 +35,14 @@ for _m in ("opencv_standard", "poly3", "poly5", "ptlens", "insta360", "sony", "g
 
 
 # Host builds (x86-64, build_host below): name -> (ocl_names, bytes per pixel, interpolation, lens model).  The fisheye model with every
-# pixel type the reference's OpenCL backend serves (pixel_formats.rs ocl_names; its three-channel types carry a FIXME there and RGBAf16
-# needs the fp16 extension: both left out) x every sampler (2 bilinear, 4 bicubic, 8 Lanczos4, 10-13 EWA on 16-bit luma); the other
+# pixel type the reference's OpenCL backend serves (pixel_formats.rs ocl_names; its three-channel types carry a FIXME there: left out) x every sampler (2 bilinear, 4 bicubic, 8 Lanczos4, 10-13 EWA on 16-bit luma); the other
 # eight physical lens models on 16-bit luma, bilinear.  Flags stay run-time tests in these builds (assemble(fold_flags=False)).
 OCL_NAMES = {
     "luma8": (("uchar", "convert_uchar_sat", "float", "convert_float"), 1), "luma16": (("ushort", "convert_ushort_sat", "float", "convert_float"), 2),
     "rgba8": (("uchar4", "convert_uchar4_sat", "float4", "convert_float4"), 4), "rgba16": (("ushort4", "convert_ushort4_sat", "float4", "convert_float4"), 8),
     "rgbaf": (("float4", "convert_float4", "float4", "convert_float4"), 16), "r32f": (("float", "convert_float", "float", "convert_float"), 4),
     "uv8": (("uchar2", "convert_uchar2_sat", "float2", "convert_float2"), 2), "uv16": (("ushort2", "convert_ushort2_sat", "float2", "convert_float2"), 4),
+    "rgbaf16": (("half4", "convert_half4", "float4", "convert_half4_to_float4"), 8),
 }
 SAMPLERS = {2: "bilinear", 4: "bicubic", 8: "lanczos4", 10: "ewa10", 11: "ewa11", 12: "ewa12", 13: "ewa13"}
 HOST_CONFIGS = {}
@@ -79,7 +79,12 @@ def assemble(names, bpp, interp, flags, model, fold_flags=True):
     else:
         lens += ("float2 digital_undistort_point(float2 uv, __global KernelParams *p) { return uv; }\n"
                  "float2 digital_distort_point(float2 uv, __global KernelParams *p) { return uv; }")
-    kernel = (kernel.replace("LENS_MODEL_FUNCTIONS;", lens).replace("EXTENSIONS;", "")
+    extensions = ""
+    if names[1] == "convert_half4":          # opencl.rs:190-197: the fp16 helpers pushed for RGBAf16, a raw string literal of that file
+        rs = open(os.path.join(REF, "gpu", "opencl.rs")).read()
+        a = rs.index('r#"', rs.index("extensions.push_str(")) + 3
+        extensions = rs[a:rs.index('"#', a)]
+    kernel = (kernel.replace("LENS_MODEL_FUNCTIONS;", lens).replace("EXTENSIONS;", extensions)
               .replace("DATA_CONVERTF", names[3]).replace("DATA_TYPEF", names[2])
               .replace("DATA_CONVERT", names[1]).replace("DATA_TYPE", names[0])
               .replace("PIXEL_BYTES", str(bpp)).replace("INTERPOLATION", str(interp)))

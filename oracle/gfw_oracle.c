@@ -18,7 +18,7 @@
  * twin of the path can be: oracle/build_ref_cl.py assembles src/core/gpu/opencl_undistort.cl + the lens model's
  * .cl the way OclWrapper::new does (opencl.rs:181-214) from /root/reference and compiles that text for the host
  * cores; oracle/ref_cl_host.c supplies the OpenCL builtins (transcendentals from glibc — what the CPU path calls).
- *   - tests/golden/ref_golden.json holds what THAT code wrote for 42 configurations in which none of the twin's
+ *   - tests/golden/ref_golden.json holds what THAT code wrote for 44 configurations in which none of the twin's
  *     documented deviations from the CPU path can fire (BASELINE's C2 frame at 3840x2160, C1 1080p, C4's crop, every
  *     pixel type its OpenCL backend serves x bilinear / bicubic / Lanczos4, both shutter directions, edge-repeat and
  *     mirror backgrounds, stretches, rescaled output, four more lens models, the five digital lenses, IBIS terms, quarter-turn input rotation): this file reproduces every plane BIT
@@ -29,7 +29,7 @@
  *   - the same twin compiled for gfx950 runs beside this file on the GPU box (tests/test_gpu_ref_opencl.py; there its
  *     atan / tan are OpenCL's, hence a 2e-4 px tolerance);
  *   - what no twin can pin — the CPU-only colour-range fix (cpu_undistort.rs:255-260 differs from .cl:157-160 by
- *     design), the Sony mesh beyond 99.9 % (f64 spline here, f32 in the twin), three-channel and half-float pixels — rests on: analytic known-answer tests (tests/test_oracle_kat.py), 40-digit mpmath statements of the 14
+ *     design), the Sony mesh beyond 99.9 % (f64 spline here, f32 in the twin), three-channel pixels — rests on: analytic known-answer tests (tests/test_oracle_kat.py), 40-digit mpmath statements of the 14
  *     lens models in both directions written from the Rust independently of this file (tests/test_oracle_mpmath.py),
  *     and self-generated golden checksums (tests/golden/golden.json).
  *

@@ -67,6 +67,16 @@ OCL(float2, convert_float2_us, "_Z14convert_float2Dv2_t", ushort2 v) { return (f
 OCL(float4, convert_float4_uc, "_Z14convert_float4Dv4_h", uchar4 v) { return (float4){(float)v.x, (float)v.y, (float)v.z, (float)v.w}; }
 OCL(float4, convert_float4_us, "_Z14convert_float4Dv4_t", ushort4 v) { return (float4){(float)v.x, (float)v.y, (float)v.z, (float)v.w}; }
 
+/* cl_khr_fp16 loads / stores (6.12.7 vload_half / vstore_half_rte): IEEE binary16 storage, round to nearest even on the way in */
+OCL(float4, vload_half4, "_Z11vload_half4mPU9CLgenericKDh", size_t offset, const _Float16 *p) {
+    p += 4 * offset;
+    return (float4){(float)p[0], (float)p[1], (float)p[2], (float)p[3]};
+}
+OCL(void, vstore_half4_rte, "_Z16vstore_half4_rteDv4_fmPU9CLgenericDh", float4 v, size_t offset, _Float16 *p) {
+    p += 4 * offset;
+    p[0] = (_Float16)v.x; p[1] = (_Float16)v.y; p[2] = (_Float16)v.z; p[3] = (_Float16)v.w;
+}
+
 /* common functions, 6.12.4 */
 static inline float min_f(float x, float y) { return y < x ? y : x; }
 static inline float max_f(float x, float y) { return x < y ? y : x; }

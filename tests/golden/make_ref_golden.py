@@ -33,7 +33,7 @@ from gyroflow_amd import abi, synthetic as S  # noqa: E402
 
 # pixel type -> host build family (oracle/build_ref_cl.py OCL_NAMES; BGRA8 / AYUV16 share the four-channel kernels, as in pixel_formats.rs)
 PIX = {"Luma8": "luma8", "Luma16": "luma16", "RGBA8": "rgba8", "BGRA8": "rgba8", "RGBA16": "rgba16", "AYUV16": "rgba16",
-       "RGBAf": "rgbaf", "R32f": "r32f", "UV8": "uv8", "UV16": "uv16"}
+       "RGBAf": "rgbaf", "RGBAf16": "rgbaf16", "R32f": "r32f", "UV8": "uv8", "UV16": "uv16"}
 SAMPLERS = {2: "bilinear", 4: "bicubic", 8: "lanczos4"}
 MODEL_TAG = {"opencv_fisheye": "fisheye"}
 
@@ -71,6 +71,8 @@ CASES = {
     "bgra_bilinear_640x360": dict(fmt="BGRA", w=640, h=360, seed=0x1234),
     "rgba64_bicubic_640x360": dict(fmt="RGBA64BE", w=640, h=360, seed=0x1234, interp=4),
     "rgbaf32_lanczos4_640x360": dict(fmt="RGBAF32", w=640, h=360, seed=0x1234, interp=8),
+    "rgbaf16_bilinear_640x360": dict(fmt="RGBAF16", w=640, h=360, seed=0x1234),
+    "rgbaf16_lanczos4_640x360": dict(fmt="RGBAF16", w=640, h=360, seed=0x1234, interp=8),
     "gbrapf32_bicubic_640x360": dict(fmt="GBRAPF32LE", w=640, h=360, seed=0x1234, interp=4),
     # geometry
     "yuv422p16_fov05_hrs": dict(fmt="YUV422P16LE", w=640, h=360, seed=77, fov=0.5, hrs=True, readout_ms=25.0),
