@@ -128,7 +128,9 @@ def test_margin_with_feather_differs_only_inside_the_feather_zone():
 
 @pytest.mark.parametrize("interp", [10, 11, 12, 13])
 def test_ewa_samplers_agree_to_one_code_value(interp):
-    """EWA (cpu_undistort.rs:331-369 / .cl:254-303): the twin accumulates the footprint in another order — at most one 16-bit code value apart."""
+    """EWA (cpu_undistort.rs:331-369 / .cl:254-303, :320-352): the cubic weight is associated differently — `p2 * x2 + p3 * x2 * x` with
+    x2 = x * x in the CPU path (cpu_undistort.rs:318-320), `p.z * x * x + p.w * x * x * x` in the twin (.cl:296-298) — so weights differ in
+    the last bit and the normalised sum lands at most one 16-bit code value apart."""
     fr = S.SyntheticFrame("YUV422P16LE", W, H, seed=0x1235, interpolation=interp)
     ref = oracle_plane(fr).view(np.uint16).astype(np.int64)
     got = run_reference_cl_host("luma16_ewa%d_fisheye" % interp, fr.planes[0], fr.matrices).view(np.uint16).astype(np.int64)
