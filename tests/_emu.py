@@ -1,0 +1,221 @@
+"""TEST INFRASTRUCTURE: the fused kernel's SOURCE, interpreted on the host — so that the CPU tier holds the product's device code itself
+(not only the oracle) to the reference's numbers without a GPU.
+
+What is built: the text libgfwarp.so embeds for hiprtc (tools/gen_jit_source.py: gfw_frame.hip + its headers), unedited except that its seven
+inline-asm statements (AMD mnemonics) become calls of same-named C functions; in front of it tests/emu/emu_prelude.h (what hiprtc's implicit
+HIP environment provides: vector types, threadIdx, __shared__, the handful of amdgcn builtins the source uses) and the clip's bake header
+(tests/_bake.py, the test-side restatement of gfw_api.hip's); behind it tests/emu/emu_driver.inc (the launch, lane by lane: 256 cooperative
+fibers per workgroup, rendezvous at __syncthreads and at wavefront fences).  Compiled as C++17 for x86-64 with -ffp-contract=off, like the
+device build.  The host side here restates what gfw_api.hip prepares for a launch (template arguments as jit_for picks them, the first
+pass's s(rho) table and certificate half-width as p1_setup computes them).
+
+It is not a product path and cannot become one: nothing under gyroflow_amd/ imports it, the library does not know it, a 640x360 frame takes a
+second.  What it buys: tests/test_emu_kernel.py runs the kernel's own arithmetic, tile walk, first-pass certificate, LDS queue and address
+computations against the oracle and against the reference kernel's fixture on every CPU-only run, and kernel changes can be checked for
+parity before any GPU time is spent on measuring them."""
+import ctypes as C
+import hashlib
+import math
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_jit_source as G  # noqa: E402
+
+from gyroflow_amd import abi, warp  # noqa: E402
+import _bake  # noqa: E402
+
+EMU = os.path.join(ROOT, "tests", "emu")
+OUT = os.path.join(ROOT, "build", "emu")
+CXX = "/opt/rocm/lib/llvm/bin/clang++" if os.path.exists("/opt/rocm/lib/llvm/bin/clang++") else "g++"
+P1_TABLE_N = 8192                 # GFW_P1_TABLE_N
+
+
+def kernel_source():
+    """gfw_frame.hip + headers as one text (gen_jit_source.expand, without its typedef prelude: the host has <stdint.h>), asm -> emu_*()."""
+    out = []
+    G.expand(os.path.join(G.CSRC, "gfw_frame.hip"), set(), out)
+    src = "".join(out)
+
+    def fix(m):
+        mm = re.match(r'asm\("(\w*)[^"]*"\s*:\s*"[=+]v"\((\w+)\)(?:\s*:\s*(.*))?\);', m.group(0))
+        assert mm, m.group(0)
+        op, dst, ins = mm.group(1), mm.group(2), mm.group(3)
+        if not op:
+            return "/* asm(\"\"): an optimisation barrier */;"
+        return "%s = emu_%s(%s);" % (dst, op, ", ".join(re.findall(r'"\w"\(([^)]+)\)', ins)))
+    src, n = re.subn(r'asm\(.*\);', fix, src)
+    assert n == 7, "inline-asm statements in the kernel source: %d (the emulator knows 7)" % n
+    return src
+
+
+def build(defs, header):
+    """-> path of the host library for these template arguments + bake header (cached under build/emu/ by content)."""
+    os.makedirs(OUT, exist_ok=True)
+    text = ('#include "emu_prelude.h"\n' + header + "\n" + kernel_source() + '\n#include "emu_driver.inc"\n')
+    flags = ["-std=c++17", "-O1", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-Wno-everything", "-I" + EMU, "-DGFW_JIT=1", "-DGFW_BAKE=1"] + \
+            ["-D%s=%s" % kv for kv in sorted(defs.items())]
+    key = hashlib.sha256((text + " ".join(flags) + open(os.path.join(EMU, "emu_prelude.h")).read() + open(os.path.join(EMU, "emu_driver.inc")).read()).encode()).hexdigest()[:20]
+    so = os.path.join(OUT, "emu_%s.so" % key)
+    if not os.path.exists(so):
+        cpp = os.path.join(OUT, "emu_%s.cpp" % key)
+        open(cpp, "w").write(text)
+        r = subprocess.run([CXX] + flags + [cpp, "-o", so + ".tmp", "-lm"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("emulator build failed:\n" + r.stderr[-4000:])
+        os.replace(so + ".tmp", so)
+    return so
+
+
+def p1_table(p0, matrices, matrix_count):
+    """gfw_api.hip p1_setup / p1_prepare_table restated: the s(rho) table of the certified first pass (f64 -> float2 entries), its range and
+    the certificate half-width E.  -> (table [N+1][2] f32, rho_max, rho_scale, eps) or None when the certified pass is not used."""
+    k = [float(p0.k[i]) for i in range(4)]
+    hrs = bool(p0.flags & abi.FLAG_HORIZONTAL_RS)
+    m = np.asarray(matrices, dtype=np.float64)[matrix_count >> 1]
+    rho_max = 0.0
+    for y in (0.0, p0.output_height * 0.5, float(p0.output_height)):
+        for x in (0.0, p0.output_width * 0.5, float(p0.output_width)):
+            ox, oy = x + p0.translation2d[0], y + p0.translation2d[1]
+            X, Y, Wd = ox * m[0] + oy * m[1] + m[2], ox * m[3] + oy * m[4] + m[5], ox * m[6] + oy * m[7] + m[8]
+            rho_max = 1e9 if not Wd > 0.05 else max(rho_max, (X * X + Y * Y) / (Wd * Wd))
+    rho_max = min(min(rho_max * 1.25 + 0.01, 64.0) * 1.15, 64.0)
+    rho_max = float(np.float32(rho_max))
+
+    def s_of(rho):
+        if all(v == 0.0 for v in k):
+            return 1.0
+        r = math.sqrt(rho)
+        if r == 0.0:
+            return 1.0
+        t = math.atan(r)
+        t2 = t * t
+        return t * (1.0 + t2 * (k[0] + t2 * (k[1] + t2 * (k[2] + t2 * k[3])))) / r
+    n = P1_TABLE_N
+    h = rho_max / n
+    s = [s_of(i * h) for i in range(n + 1)]
+    tab = np.zeros((n + 1, 2), dtype=np.float32)
+    etab = smax = 0.0
+    for i in range(n):
+        tab[i] = (s[i], s[i + 1] - s[i])
+        for q in range(1, 8):
+            etab = max(etab, abs(float(tab[i, 0]) + q / 8.0 * float(tab[i, 1]) - s_of((i + q / 8.0) * h)))
+        smax = max(smax, abs(s[i]), abs(s[i + 1]))
+    tab[n] = (s[n], 0.0)
+    f = abs(float(p0.f[0] if hrs else p0.f[1]))
+    c = abs(float(p0.c[0] if hrs else p0.c[1]))
+    rmax = math.sqrt(rho_max)
+    eps = 1.5 * 1.2e-6 * (f * rmax * smax + c) + 2.0 * f * rmax * etab + 1.0 / 4096.0
+    if matrix_count <= 1 or not eps < 0.2:
+        return None
+    return tab, rho_max, float(np.float32(n / rho_max)), float(np.float32(eps))
+
+
+def launch_shape(fr):
+    """Template arguments of the frame's instantiation, as gfw_api.hip's build_yuv_args + jit_for choose them (fisheye, no extras)."""
+    pls = fr.planes
+    p0 = pls[0]["params"]
+    t0 = pls[0]["pixel_type"]
+    bps, n0 = {"Luma8": (1, 1), "Luma16": (2, 1), "RGBA8": (1, 4), "BGRA8": (1, 4), "RGBA16": (2, 4), "AYUV16": (2, 4), "RGBAf": (4, 4), "R32f": (4, 1)}[t0]
+    il = len(pls) == 2 and pls[1]["pixel_type"] in ("UV8", "UV16")
+    dw = dh = 1
+    if len(pls) >= 2:
+        dw, dh = p0.output_width // pls[1]["out_size"][0], p0.output_height // pls[1]["out_size"][1]
+    return bps, n0, dw, dh, il
+
+
+class Common(C.Structure):
+    """GfwCommon (gfw_warp.h): lens ids + the host-libm-evaluated uniforms of the generic-model bodies"""
+    _fields_ = [("matrices", C.c_void_p), ("mesh", C.c_void_p), ("mesh_len", C.c_int32), ("model", C.c_int32), ("digital", C.c_int32), ("pad_", C.c_int32),
+                ("rot_cos", C.c_float), ("rot_sin", C.c_float), ("frame_w", C.c_float), ("frame_h", C.c_float), ("gopro_tt", C.c_float), ("pad2_", C.c_float)]
+
+
+def feature_bits(fr, mesh=None):
+    """`extras` as gfw_api.hip's build_yuv_args derives it: 1 IBIS/OIS terms in the matrix rows, 2 digital lens, 4 refraction, 8 lens-correction
+    blend, 16 background mode 3, 32 Sony mesh / focal-plane distortion"""
+    p0 = fr.planes[0]["params"]
+    e = 0
+    if mesh is not None and len(mesh):
+        e |= 32
+    if fr.digital and (p0.flags & abi.FLAG_HAS_DIGITAL_LENS):
+        e |= 2
+    if p0.background_mode == 3:
+        e |= 16
+    if p0.lens_correction_amount < 1.0:
+        e |= 8
+    if p0.light_refraction_coefficient != 1.0 and p0.light_refraction_coefficient > 0.0:
+        e |= 4
+    if np.any(np.asarray(fr.matrices)[:, 9:14] != 0.0):
+        e |= 1
+    return e
+
+
+def fused_eligible(fr):
+    """the conditions under which the library serves a frame with the fused kernel at all (build_yuv_args) — anything else is the per-plane kernel's"""
+    for pl in fr.planes:
+        p = pl["params"]
+        if p.input_rotation != 0.0 or (p.flags & (abi.FLAG_FIX_COLOR_RANGE | abi.FLAG_FILL_WITH_BACKGROUND)) or p.interpolation not in (2, 4, 8):
+            return False
+        for st in (p.input_horizontal_stretch, p.input_vertical_stretch):
+            if st > 0.001 and st != 1.0:
+                return False
+    return fr.planes[0]["pixel_type"] in ("Luma8", "Luma16", "RGBA8", "BGRA8", "RGBA16", "AYUV16", "RGBAf", "R32f")
+
+
+def run_frames(frames, mesh=None):
+    """One clip launch of the host-interpreted kernel over `frames` (same shape and constants, <= 16) -> [[plane outputs] per frame]."""
+    fr0 = frames[0]
+    p0 = fr0.planes[0]["params"]
+    assert fused_eligible(fr0), "not a frame the fused kernel serves"
+    bps, n0, dw, dh, il = launch_shape(fr0)
+    extras = feature_bits(fr0, mesh)
+    fisheye = fr0.model == abi.MODELS["opencv_fisheye"]
+    jit_model = 1 if (fisheye and (extras & ~2) == 0) else (-2 if extras & (16 | 32) else -1)
+    p1 = p1_table(p0, fr0.matrices, p0.matrix_count) if (fisheye and extras == 0) else None
+    fast1 = p1 is not None
+    rb = 4 if fast1 else 1
+    defs = {"GFW_FRAME_KIND": bps, "GFW_FRAME_TAPS": p0.interpolation, "GFW_JIT_WAVES": 8, "GFW_JIT_MODEL": jit_model,
+            "GFW_JIT_T": {1: "uint8_t", 2: "uint16_t", 4: "float"}[bps], "GFW_JIT_N0": n0, "GFW_JIT_DW": dw, "GFW_JIT_DH": dh,
+            "GFW_JIT_IL": 1 if il else 0, "GFW_JIT_RB": rb, "GFW_JIT_FAST1": 1 if fast1 else 0}
+    header = _bake.bake_header(fr0, rb=rb)
+    header, n1 = re.subn(r"#define GFW_BK_extras \(0\)", "#define GFW_BK_extras (%d)" % extras, header)
+    header, n2 = re.subn(r"#define GFW_BK_digital \(0\)", "#define GFW_BK_digital (%d)" % (fr0.digital if extras & 2 else 0), header)
+    assert n1 == 1 and n2 == 1
+    lib = C.CDLL(build(defs, header))
+    lib.gfw_emu_launch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
+                                   C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int]
+    n = len(frames)
+    srcs, dsts, mats, keep, outs = (C.c_void_p * (4 * n))(), (C.c_void_p * (4 * n))(), (C.c_void_p * n)(), [], []
+    for f, fr in enumerate(frames):
+        packed = warp.pack_matrices(fr.matrices)
+        keep.append(packed)
+        mats[f] = packed.ctypes.data
+        planes = []
+        for p, pl in enumerate(fr.planes):
+            src = np.concatenate([np.ascontiguousarray(pl["src"]), np.zeros(64, np.uint8)])        # the aligned tap-row fetches may read a few bytes past the plane
+            dst = pl["dst"].copy()
+            keep.append(src)
+            planes.append(dst)
+            srcs[4 * f + p], dsts[4 * f + p] = src.ctypes.data, dst.ctypes.data
+        outs.append(planes)
+    tab = p1[0] if fast1 else np.zeros((2, 2), np.float32)
+    libm = C.CDLL("libm.so.6")
+    libm.tanf.restype, libm.tanf.argtypes = C.c_float, [C.c_float]
+    com = Common(model=fr0.model, digital=fr0.digital, rot_cos=1.0, rot_sin=0.0, frame_w=float(p0.width), frame_h=float(p0.height), gopro_tt=libm.tanf(1.5533))
+    if mesh is not None and len(mesh):
+        mesh = np.ascontiguousarray(mesh, dtype=np.float32)
+        com.mesh, com.mesh_len = mesh.ctypes.data, mesh.size
+    kp = fr0.planes[0]["params"]
+    rc = lib.gfw_emu_launch(n, srcs, dsts, mats, tab.ctypes.data, p1[1] if fast1 else 0.0, p1[2] if fast1 else 0.0, p1[3] if fast1 else 0.0,
+                            C.cast(C.byref(kp), C.c_void_p), C.cast(C.byref(com), C.c_void_p), 8)
+    assert rc == 0, "gfw_emu_launch -> %d" % rc
+    return outs
+
+
+def run_frame(fr, mesh=None):
+    return run_frames([fr], mesh)[0]

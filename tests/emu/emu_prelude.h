@@ -1,0 +1,86 @@
+// emu_prelude.h — TEST INFRASTRUCTURE: what hiprtc's implicit HIP environment gives the fused kernel's source, restated for a HOST build.
+//
+// tests/emu/ compiles the very text libgfwarp.so embeds for hiprtc (tools/gen_jit_source.py: gfw_frame.hip + its headers, amalgamated) as
+// plain C++ for the host cores and interprets the launch lane by lane (emu_driver.cpp), so that the CPU tier of the test suite runs the
+// product's kernel SOURCE against the oracle without a GPU.  It is not a fallback: nothing under gyroflow_amd/ knows it exists, the
+// library never loads it, and it is as slow as it sounds.  The source text is not edited for this — the only transformation is the
+// seven inline-asm statements (AMD mnemonics) turned into calls of the emu_v_* functions below (tests/emu/build_emu.py).
+#pragma once
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#define __device__
+#define __host__
+#define __global__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __constant__
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct int2 { int x, y; };
+struct dim3 { unsigned x, y, z; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+
+// ---- the lane being interpreted (emu_driver.cpp switches it) --------------------------------------------------------------
+struct EmuLane { dim3 tid, bid, bdim, gdim; };
+extern EmuLane *emu_cur;
+#define threadIdx (emu_cur->tid)
+#define blockIdx (emu_cur->bid)
+#define blockDim (emu_cur->bdim)
+#define gridDim (emu_cur->gdim)
+
+// ---- synchronisation: the driver runs the 256 lanes of a workgroup as cooperative fibers ----------------------------------
+void emu_workgroup_barrier();                 // __syncthreads: every lane of the workgroup
+void emu_wave_sync(int site);                 // a wavefront-scope fence: in hardware the wave's lanes are in lockstep around it
+#define __syncthreads() emu_workgroup_barrier()
+#define __builtin_amdgcn_fence(order, scope) emu_wave_sync(__LINE__)
+// wave votes: both outcomes of every vote in this source compute the same bits for a lane (they select a cheaper route when the whole
+// wave qualifies), so the lane's own predicate is a valid answer
+#define __all(p) ((p) ? 1 : 0)
+#define __any(p) ((p) ? 1 : 0)
+
+// A lane reaching an atomic waits until every other live lane of its wave has run as far as it can (to its own atomic, or to a fence): in
+// hardware the wave executes the instructions BEFORE the atomic in lockstep, so no lane may see its effect earlier (the first pass reads the
+// queue length right after a fence, then lanes push new entries).
+void emu_wave_atomic_point();
+template <typename T> static inline T atomicAdd(T *p, T v) { emu_wave_atomic_point(); const T old = *p; *p = (T)(old + v); return old; }
+
+// ---- hardware instructions and builtins --------------------------------------------------------------------------------
+static inline float emu_sat_i32(float v) { return v; }
+static inline int emu_v_cvt_i32_f32(float v) { if (v != v) return 0; if (v >= 2147483648.0f) return INT32_MAX; if (v <= -2147483648.0f) return INT32_MIN; return (int)v; }
+static inline uint32_t emu_v_cvt_u32_f32(float v) { if (v != v || v <= 0.0f) return 0u; if (v >= 4294967296.0f) return 0xFFFFFFFFu; return (uint32_t)v; }
+static inline float emu_v_min_f32(float a, float b) { return fminf(a, b); }                  // IEEE mode: the non-NaN operand wins
+static inline int emu_v_mul_i32_i24(int a, int b) { return (int)((int64_t)((a << 8) >> 8) * (int64_t)((b << 8) >> 8)); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }                       // v_rcp_f32 is within 1 ulp of this; the callers refine it
+static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
+static inline float __builtin_amdgcn_fractf(float x) { const float f = x - floorf(x); return f < 1.0f ? f : 0x1.fffffep-1f; }
+static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31u)); }
+static inline uint32_t __builtin_amdgcn_udot4(uint32_t a, uint32_t b, uint32_t c, bool) {
+    uint32_t s = c;
+    for (int i = 0; i < 4; ++i) s += ((a >> (8 * i)) & 255u) * ((b >> (8 * i)) & 255u);
+    return s;
+}
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_getreg(x) (0u)
+#define __builtin_readcyclecounter() (0ull)
+
+// HIP's integer / float min and max overloads
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
+static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
+static inline long long min(long long a, long long b) { return a < b ? a : b; }
+static inline long long max(long long a, long long b) { return a > b ? a : b; }
+static inline float min(float a, float b) { return fminf(a, b); }
+static inline float max(float a, float b) { return fmaxf(a, b); }
+template <typename T> static inline T atomicMax(T *p, T v) { emu_wave_atomic_point(); const T old = *p; if (v > old) *p = v; return old; }
+#define amdgpu_waves_per_eu(...)

@@ -1,0 +1,102 @@
+"""The fused kernel's SOURCE on the host cores (tests/_emu.py: the text embedded for hiprtc, compiled as C++ for x86-64 and interpreted lane by
+lane) against the fixture the reference's own kernel wrote and against the oracle — the CPU tier's check of the product's device code itself:
+its arithmetic (lean divide / sqrt / table atanf, the exact projection, the taps), the persistent tile walk and clip launch, the certified
+first pass with its LDS queue, chroma sites from luma coordinates, the generic-model bodies with every lens model and feature bit as a literal.
+
+What the interpreter cannot stand for is the hardware itself (v_rcp_f32 / v_sqrt_f32 are exact here and refined from there, wave votes answer
+per lane, occupancy and timing do not exist): the GPU tier runs the same checks on the MI355X.  Nothing here is a product path."""
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_ref_golden as G  # noqa: E402
+
+from gyroflow_amd import abi, synthetic as S  # noqa: E402
+import _emu  # noqa: E402
+import _oracle as O  # noqa: E402
+
+GOLD = json.load(open(os.path.join(HERE, "golden", "ref_golden.json")))
+FUSED = sorted(n for n in G.CASES if _emu.fused_eligible(G.build(dict(G.CASES[n], w=64, h=32, out=None) if G.CASES[n]["w"] > 2000 else G.CASES[n])))
+
+
+def test_the_interpreter_covers_the_fused_cases_of_the_fixture():
+    assert len(FUSED) >= 38 and "c2_yuv422p16_3840x2160_rs" in FUSED, FUSED
+
+
+@pytest.mark.parametrize("name", FUSED)
+def test_kernel_source_reproduces_the_reference_kernels_output(name):
+    """gfw_frame.hip (host-interpreted) == tests/golden/ref_golden.json, i.e. what the reference's opencl_undistort.cl wrote — C2 at 3840x2160 included"""
+    fr = G.build(G.CASES[name])
+    planes = _emu.run_frame(fr)
+    assert [zlib.crc32(p.tobytes()) for p in planes] == GOLD[name]["planes"]
+
+
+def same_as_oracle(fr, mesh=None):
+    got = _emu.run_frame(fr, mesh)
+    for i, pl in enumerate(fr.planes):
+        ref = pl["dst"].copy()
+        assert O.undistort_image(pl["src"], pl["size"], ref, pl["out_size"], pl["params"], pl["pixel_type"], fr.model, fr.digital, fr.matrices, mesh=mesh) == 1
+        assert np.array_equal(ref, got[i]), "plane %d: %d bytes differ" % (i, int(np.count_nonzero(ref != got[i])))
+
+
+@pytest.mark.parametrize("fmt,interp", [("YUV422P16LE", 2), ("NV12", 2), ("P010LE", 8), ("YUV420P", 4), ("RGBA", 2), ("RGBAF32", 2)])
+@pytest.mark.parametrize("fov,hrs", [(1.7, False), (3.0, True)])
+def test_zoomed_out_frames_against_the_oracle(fmt, interp, fov, hrs):
+    """out-of-frame pixels, edge taps, negative coordinates (where the reference's GPU twin deviates from its CPU path and no fixture can exist)"""
+    same_as_oracle(S.SyntheticFrame(fmt, 322, 186, seed=0x51, fov=fov, horizontal_rs=hrs, interpolation=interp, readout_ms=25.0, background_rgba=(0.3, 0.6, 0.9, 1.0)))
+
+
+@pytest.mark.parametrize("model,k", [("opencv_standard", [0.12, -0.05, 0.001, 0.002, 0.01, 0.02, -0.01, 0.001, 0.0005, -0.0002, 0.0003, 0.0001]), ("poly3", [0.06]),
+                                     ("poly5", [0.08, -0.02]), ("insta360", [0.05, -0.01, 0.002, 0.001, -0.001, 0.6]), ("gopro", [0.0, 1.0, 0.01, -0.12, 0.02, 0.01, -0.004])])
+@pytest.mark.parametrize("lca", [1.0, 0.45])
+def test_lens_models_and_blend_against_the_oracle(model, k, lca):
+    lens = S.gopro_style_lens(320, 192)
+    lens["model"], lens["k"] = model, k + [0.0] * (12 - len(k))
+    if model == "gopro":
+        lens["r_limit"] = 2.5
+    same_as_oracle(S.SyntheticFrame("YUV422P16LE", 320, 192, seed=31, lens=lens, fov=1.2, base_overrides={"lens_correction_amount": lca}))
+
+
+def test_feature_bits_against_the_oracle():
+    w, h = 320, 192
+    lens = S.gopro_style_lens(w, h)
+    lens["r_limit"] = 0.9
+    same_as_oracle(S.SyntheticFrame("YUV422P16LE", w, h, seed=41, lens=lens, fov=1.6))                                          # r-limit
+    same_as_oracle(S.SyntheticFrame("YUV422P16LE", w, h, seed=82, base_overrides={"light_refraction_coefficient": 1.33}, flags=2048))   # refraction, NaN coordinates
+    same_as_oracle(S.SyntheticFrame("NV12", w, h, seed=78, fov=1.3, base_overrides={"background_mode": 3, "background_margin": 0.1, "background_margin_feather": 0.05}))
+    same_as_oracle(S.SyntheticFrame("YUV422P16LE", w, h, seed=78, fov=2.2, base_overrides={"background_mode": 2}))
+    lens = S.gopro_style_lens(w, h)
+    lens["digital"] = "gopro_hyperview"
+    same_as_oracle(S.SyntheticFrame("YUV422P16LE", w, h, seed=37, lens=lens, fov=1.3))                                          # a diverging digital-lens inverse
+
+
+@pytest.mark.parametrize("with_mesh,with_fpd,inverted", [(True, True, False), (True, True, True), (False, True, False)])
+def test_sony_mesh_against_the_oracle(with_mesh, with_fpd, inverted):
+    from test_ref_opencl_host import _mesh_block
+    w, h = 192, 128
+    fr = S.SyntheticFrame("NV12", w, h, seed=47, fov=1.1, flags=abi.FLAG_FRAMEBUFFER_INVERTED if inverted else 0)
+    same_as_oracle(fr, _mesh_block(w, h, with_fpd, with_mesh))
+
+
+def test_large_rotation_fills_the_first_pass_queue():
+    """a fast pan with a long readout: the certified first pass rejects many more pixels than usual; they go through the LDS queue and the exact pass"""
+    fr = S.SyntheticFrame("YUV422P16LE", 640, 360, seed=0x77, fov=1.1, readout_ms=60.0)
+    same_as_oracle(fr)
+    k = fr.planes[0]["params"].k
+    assert _emu.p1_table(fr.planes[0]["params"], fr.matrices, fr.planes[0]["params"].matrix_count) is not None and any(k[i] != 0.0 for i in range(4))
+
+
+def test_clip_launch_of_five_frames():
+    """gfw_undistort_clip's launch shape: the (frame, tile) pairs of several frames dealt to the persistent workgroups, every XCD slot taking another
+    region of each frame; per-frame plane pointers and matrix tables from the argument block"""
+    frames = [S.SyntheticFrame("YUV422P16LE", 384, 208, seed=0x9F10 + j, timestamp_ms=1000.0 + 33.3 * j) for j in range(5)]
+    outs = _emu.run_frames(frames)
+    for fr, got in zip(frames, outs):
+        ref = O.run_frame(fr)
+        assert all(np.array_equal(a, b) for a, b in zip(ref, got))
