@@ -36,10 +36,10 @@ CXX = "/opt/rocm/lib/llvm/bin/clang++" if os.path.exists("/opt/rocm/lib/llvm/bin
 P1_TABLE_N = 8192                 # GFW_P1_TABLE_N
 
 
-def kernel_source():
-    """gfw_frame.hip + headers as one text (gen_jit_source.expand, without its typedef prelude: the host has <stdint.h>), asm -> emu_*()."""
+def kernel_source(top="gfw_frame.hip", n_asm=7):
+    """`top` + the project headers it includes as one text (gen_jit_source.expand, without its typedef prelude: the host has <stdint.h>), asm -> emu_*()."""
     out = []
-    G.expand(os.path.join(G.CSRC, "gfw_frame.hip"), set(), out)
+    G.expand(os.path.join(G.CSRC, top), set(), out)
     src = "".join(out)
 
     def fix(m):
@@ -50,17 +50,17 @@ def kernel_source():
             return "/* asm(\"\"): an optimisation barrier */;"
         return "%s = emu_%s(%s);" % (dst, op, ", ".join(re.findall(r'"\w"\(([^)]+)\)', ins)))
     src, n = re.subn(r'asm\(.*\);', fix, src)
-    assert n == 7, "inline-asm statements in the kernel source: %d (the emulator knows 7)" % n
+    assert n == n_asm, "inline-asm statements in %s: %d (the emulator knows %d)" % (top, n, n_asm)
     return src
 
 
-def build(defs, header):
-    """-> path of the host library for these template arguments + bake header (cached under build/emu/ by content)."""
+def build(defs, header, top="gfw_frame.hip", n_asm=7, driver="emu_driver.inc", extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=1")):
+    """-> path of the host library for these template arguments (+ bake header) (cached under build/emu/ by content)."""
     os.makedirs(OUT, exist_ok=True)
-    text = ('#include "emu_prelude.h"\n' + header + "\n" + kernel_source() + '\n#include "emu_driver.inc"\n')
-    flags = ["-std=c++17", "-O1", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-Wno-everything", "-I" + EMU, "-DGFW_JIT=1", "-DGFW_BAKE=1"] + \
+    text = ('#include "emu_prelude.h"\n' + header + "\n" + kernel_source(top, n_asm) + '\n#include "%s"\n' % driver)
+    flags = ["-std=c++17", "-O1", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-Wno-everything", "-I" + EMU] + list(extra_flags) + \
             ["-D%s=%s" % kv for kv in sorted(defs.items())]
-    key = hashlib.sha256((text + " ".join(flags) + open(os.path.join(EMU, "emu_prelude.h")).read() + open(os.path.join(EMU, "emu_driver.inc")).read()).encode()).hexdigest()[:20]
+    key = hashlib.sha256((text + " ".join(flags) + "".join(open(os.path.join(EMU, f)).read() for f in sorted(os.listdir(EMU)))).encode()).hexdigest()[:20]
     so = os.path.join(OUT, "emu_%s.so" % key)
     if not os.path.exists(so):
         cpp = os.path.join(OUT, "emu_%s.cpp" % key)
@@ -219,3 +219,51 @@ def run_frames(frames, mesh=None):
 
 def run_frame(fr, mesh=None):
     return run_frames([fr], mesh)[0]
+
+
+# ---- the complete per-plane operator (gfw_plane_kernel.h): every PixelType, EWA, input rotation, stretches, the colour-range and fill flags ----------
+
+def common_for(fr, params, mesh=None):
+    """gfw_api.hip fill_common restated: lens ids and the uniforms the library evaluates with the host libm (f32 arithmetic, one rounding per operation)"""
+    libm = C.CDLL("libm.so.6")
+    for fn in ("tanf", "cosf", "sinf", "roundf"):
+        getattr(libm, fn).restype, getattr(libm, fn).argtypes = C.c_float, [C.c_float]
+    f = np.float32
+    com = Common(model=fr.model, digital=fr.digital, rot_cos=1.0, rot_sin=0.0, frame_w=float(params.width), frame_h=float(params.height), gopro_tt=libm.tanf(1.5533))
+    if params.input_rotation != 0.0:
+        rotation = f(params.input_rotation) * (f(3.14159265358979323846) / f(180.0))
+        rc, rs = f(libm.cosf(rotation)), f(libm.sinf(rotation))
+        s0, s1 = f(params.width), f(params.height)
+        fx = rc * (s0 - f(0.0)) - rs * (s1 - f(0.0)) + f(0.0)
+        fy = rs * (s0 - f(0.0)) + rc * (s1 - f(0.0)) + f(0.0)
+        com.rot_cos, com.rot_sin = float(rc), float(rs)
+        com.frame_w, com.frame_h = libm.roundf(abs(float(fx))), libm.roundf(abs(float(fy)))
+    return com
+
+
+def run_plane(fr, idx, mesh=None):
+    """Plane `idx` of the frame through the host-interpreted per-plane kernel -> output bytes."""
+    pl = fr.planes[idx]
+    p = pl["params"]
+    pix = abi.PIXEL_TYPES[pl["pixel_type"]][0]
+    mesh_len = 0 if mesh is None else len(mesh)
+    model = abi.MODELS["opencv_fisheye"] if (fr.model == abi.MODELS["opencv_fisheye"] and mesh_len == 0) else -1     # launch_plane_pi
+    interp = p.interpolation if p.interpolation in (2, 4, 8) else 0                                                      # launch_plane_p: 10..13 = EWA
+    lib = C.CDLL(build({"EMU_PIX": pix, "EMU_I": interp, "EMU_MODEL": model}, "", top="gfw_plane_kernel.h", n_asm=2, driver="emu_plane_driver.inc", extra_flags=()))
+    lib.gfw_emu_launch_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]
+    com = common_for(fr, p, mesh)
+    keep = None
+    if mesh_len:
+        keep = np.ascontiguousarray(mesh, dtype=np.float32)
+        com.mesh, com.mesh_len = keep.ctypes.data, keep.size
+    packed = warp.pack_matrices(fr.matrices)
+    src = np.concatenate([np.ascontiguousarray(pl["src"]), np.zeros(64, np.uint8)])
+    dst = pl["dst"].copy()
+    rc = lib.gfw_emu_launch_plane(C.cast(C.byref(p), C.c_void_p), src.ctypes.data, dst.ctypes.data, dst.size, pl["out_size"][2], packed.ctypes.data,
+                                  C.cast(C.byref(com), C.c_void_p))
+    assert rc == 0, "gfw_emu_launch_plane -> %d" % rc
+    return dst
+
+
+def run_frame_per_plane(fr, mesh=None):
+    return [run_plane(fr, i, mesh) for i in range(len(fr.planes))]

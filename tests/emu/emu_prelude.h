@@ -25,7 +25,12 @@ struct alignas(16) float4 { float x, y, z, w; };
 struct uint2 { unsigned x, y; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 struct int2 { int x, y; };
-struct dim3 { unsigned x, y, z; };
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+// what the launch templates behind the kernels mention (never called here: the interpreter is the launcher)
+typedef int hipError_t; typedef void *hipStream_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+#define hipLaunchKernelGGL(...) ((void)0)
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }

@@ -100,3 +100,54 @@ def test_clip_launch_of_five_frames():
     for fr, got in zip(frames, outs):
         ref = O.run_frame(fr)
         assert all(np.array_equal(a, b) for a, b in zip(ref, got))
+
+
+# ---- the complete per-plane operator (gfw_plane_kernel.h), which serves whatever the fused kernel does not ------------------------------
+
+PER_PLANE = sorted(n for n in G.CASES if n not in FUSED) + ["c2_yuv422p16_480x270_rs", "c1_nv12_1920x1080_constquat", "p010_lanczos4_640x360", "yuv420p_bilinear_642x362",
+                                                            "rgba64_bicubic_640x360", "gbrapf32_bicubic_640x360", "yuv422p16_mirror", "gopro_640x360", "hyperview_lca06_640x360",
+                                                            "ibis_terms_640x360"]
+
+
+def test_per_plane_cases_cover_what_the_fused_kernel_leaves():
+    assert {"yuv422p16_stretch", "yuv422p16_fill_background", "input_rotation_90_nv12", "input_rotation_180_640x360", "rgbaf16_bilinear_640x360"} <= set(PER_PLANE)
+
+
+@pytest.mark.parametrize("name", PER_PLANE)
+def test_per_plane_kernel_source_reproduces_the_reference_kernels_output(name):
+    fr = G.build(G.CASES[name])
+    assert [zlib.crc32(p.tobytes()) for p in _emu.run_frame_per_plane(fr)] == GOLD[name]["planes"]
+
+
+def per_plane_same_as_oracle(fr, mesh=None):
+    for i, pl in enumerate(fr.planes):
+        ref = pl["dst"].copy()
+        assert O.undistort_image(pl["src"], pl["size"], ref, pl["out_size"], pl["params"], pl["pixel_type"], fr.model, fr.digital, fr.matrices, mesh=mesh) == 1
+        got = _emu.run_plane(fr, i, mesh)
+        assert np.array_equal(ref, got), "plane %d: %d bytes differ" % (i, int(np.count_nonzero(ref != got)))
+
+
+@pytest.mark.parametrize("interp", [10, 11, 12, 13])
+def test_per_plane_ewa_against_the_oracle(interp):
+    per_plane_same_as_oracle(S.SyntheticFrame("YUV422P16LE", 160, 96, seed=5, fov=1.3, interpolation=interp))
+
+
+@pytest.mark.parametrize("fmt", ["RGB24", "RGB48BE", "AYUV64LE", "RGBAF16"])
+def test_per_plane_pixel_types_against_the_oracle(fmt):
+    per_plane_same_as_oracle(S.SyntheticFrame(fmt, 200, 120, seed=6, fov=1.5, background_rgba=(0.2, 0.4, 0.6, 0.8)))
+
+
+def test_per_plane_flags_rotation_and_mesh_against_the_oracle():
+    from test_ref_opencl_host import _mesh_block
+    w, h = 200, 120
+    per_plane_same_as_oracle(S.SyntheticFrame("NV12", w, h, seed=84, flags=abi.FLAG_FIX_COLOR_RANGE, limited_range=True))       # the CPU path's colour-range fix
+    fr = S.SyntheticFrame("YUV422P16LE", w, h, seed=43, fov=1.3)
+    for pl in fr.planes:
+        pl["params"].input_rotation = 17.5
+    per_plane_same_as_oracle(fr)
+    per_plane_same_as_oracle(S.SyntheticFrame("YUV422P16LE", w, h, seed=83, fov=1.4, base_overrides={"input_vertical_stretch": 1.1, "input_horizontal_stretch": 0.9}))
+    per_plane_same_as_oracle(S.SyntheticFrame("NV12", w, h, seed=47, fov=1.1), _mesh_block(w, h, True, True))
+    lens = S.gopro_style_lens(w, h)
+    lens["model"], lens["k"], lens["digital"] = "sony", [1.0, 0.01, -0.05, 0.02, 0.003, -0.001] + [0.0] * 6, "gopro_superview"
+    per_plane_same_as_oracle(S.SyntheticFrame("P010LE", w, h, seed=48, lens=lens, fov=1.2, base_overrides={"lens_correction_amount": 0.7, "background_mode": 3,
+                                                                                                       "background_margin": 0.1, "background_margin_feather": 0.05}))
