@@ -116,12 +116,16 @@ def p1_table(p0, matrices, matrix_count):
     return tab, rho_max, float(np.float32(n / rho_max)), float(np.float32(eps))
 
 
+SAMPLE_KIND = {"Luma8": (1, 1), "Luma16": (2, 1), "RGB8": (1, 3), "RGBA8": (1, 4), "BGRA8": (1, 4), "RGB16": (2, 3), "RGBA16": (2, 4), "AYUV16": (2, 4),
+               "RGBAf": (4, 4), "R32f": (4, 1)}          # plane 0's sample bytes and channel count (build_yuv_args); RGBAf16 / UV planes first: per-plane kernel
+
+
 def launch_shape(fr):
     """Template arguments of the frame's instantiation, as gfw_api.hip's build_yuv_args + jit_for choose them (fisheye, no extras)."""
     pls = fr.planes
     p0 = pls[0]["params"]
     t0 = pls[0]["pixel_type"]
-    bps, n0 = {"Luma8": (1, 1), "Luma16": (2, 1), "RGBA8": (1, 4), "BGRA8": (1, 4), "RGBA16": (2, 4), "AYUV16": (2, 4), "RGBAf": (4, 4), "R32f": (4, 1)}[t0]
+    bps, n0 = SAMPLE_KIND[t0]
     il = len(pls) == 2 and pls[1]["pixel_type"] in ("UV8", "UV16")
     dw = dh = 1
     if len(pls) >= 2:
@@ -155,16 +159,60 @@ def feature_bits(fr, mesh=None):
     return e
 
 
+def _int_products_exact(n_max, n):
+    if n <= 0 or n_max <= 0:
+        return False
+    odd = n
+    while odd % 2 == 0:
+        odd //= 2
+    return (n_max - 1) * odd < (1 << 24)
+
+
 def fused_eligible(fr):
-    """the conditions under which the library serves a frame with the fused kernel at all (build_yuv_args) — anything else is the per-plane kernel's"""
-    for pl in fr.planes:
+    """the conditions under which the library serves a frame with the fused kernel at all (gfw_api.hip build_yuv_args, restated) — anything else is
+    the per-plane kernel's"""
+    pls = fr.planes
+    p0 = pls[0]["params"]
+    if pls[0]["pixel_type"] not in SAMPLE_KIND or not 1 <= len(pls) <= 4:
+        return False
+    bps, n0 = SAMPLE_KIND[pls[0]["pixel_type"]]
+    if n0 > 1 and len(pls) != 1:
+        return False
+    interleaved = False
+    if len(pls) >= 2:
+        t1 = pls[1]["pixel_type"]
+        if bps != 4 and t1 == ("UV8" if bps == 1 else "UV16"):
+            if len(pls) != 2:
+                return False
+            interleaved = True
+        elif any(pl["pixel_type"] != pls[0]["pixel_type"] for pl in pls[1:]):
+            return False
+    for pl in pls:
         p = pl["params"]
         if p.input_rotation != 0.0 or (p.flags & (abi.FLAG_FIX_COLOR_RANGE | abi.FLAG_FILL_WITH_BACKGROUND)) or p.interpolation not in (2, 4, 8):
             return False
         for st in (p.input_horizontal_stretch, p.input_vertical_stretch):
             if st > 0.001 and st != 1.0:
                 return False
-    return fr.planes[0]["pixel_type"] in ("Luma8", "Luma16", "RGBA8", "BGRA8", "RGBA16", "AYUV16", "RGBAf", "R32f")
+        if bps == 2 and ((p.stride | pl["out_size"][2]) & 1):
+            return False
+        if bps == 4 and ((p.stride | pl["out_size"][2]) & 3):
+            return False
+    if len(pls) >= 2:
+        cw, ch = pls[1]["out_size"][0], pls[1]["out_size"][1]
+        if p0.output_width % cw or p0.output_height % ch:
+            return False
+        dw, dh = p0.output_width // cw, p0.output_height // ch
+        if (dw, dh) not in ((1, 1), (2, 1), (2, 2)) or (bps == 4 and (dw, dh) != (1, 1)):
+            return False
+        for pl in pls[1:]:
+            if pl["out_size"][:2] != (cw, ch) or pl["size"][0] * dw != p0.width or pl["size"][1] * dh != p0.height:
+                return False
+            if pl["params"].stride != pls[1]["params"].stride or pl["out_size"][2] != pls[1]["out_size"][2]:
+                return False
+        if not _int_products_exact(cw, p0.output_width) or not _int_products_exact(ch, p0.output_height):
+            return False
+    return _int_products_exact(p0.output_width, p0.output_width) and _int_products_exact(p0.output_height, p0.output_height) and p0.width <= 65535 and p0.height <= 65535
 
 
 def run_frames(frames, mesh=None):
