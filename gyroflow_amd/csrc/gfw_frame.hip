@@ -1114,8 +1114,12 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                 if (MODEL == GFW_MODEL_GENERIC_EXTRA && (AF(extras) & 16) && ok0 && AF(nplanes) > 1) {  // background mode 3 for the chroma site
                     const Feather f = feather_of(u0, v0, A);
                     if (INTERLEAVED_UV) feather_store<T, 2, I, true>(u0, v0, f, PL1, bg_c, lim_u, MP.mul_cx, MP.mul_cy, MP, cx, cy, s_lut);
-                    else for (int pi = 1; pi < AF(nplanes); ++pi)
-                        feather_store<T, 1, I, true>(u0, v0, f, A_in.pl[pi], A_in.pl[pi].bg, A_in.pl[pi].limit, MP.mul_cx, MP.mul_cy, MP, cx, cy, s_lut);
+                    else {
+                        // the named planes, not A_in.pl[]: in a clip launch they carry the CURRENT frame's pointers (the argument block's own are frame 0's)
+                        feather_store<T, 1, I, true>(u0, v0, f, PL1, PL1.bg, PL1.limit, MP.mul_cx, MP.mul_cy, MP, cx, cy, s_lut);
+                        if (AF(nplanes) > 2) feather_store<T, 1, I, true>(u0, v0, f, PL2, PL2.bg, PL2.limit, MP.mul_cx, MP.mul_cy, MP, cx, cy, s_lut);
+                        if (AF(nplanes) > 3) feather_store<T, 1, I, true>(u0, v0, f, PL3, PL3.bg, PL3.limit, MP.mul_cx, MP.mul_cy, MP, cx, cy, s_lut);
+                    }
                 } else
                 if (AF(nplanes) > 1 && !(AF(ablate) & 4)) {
                     float cu, cv;

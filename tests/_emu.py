@@ -236,8 +236,14 @@ def run_frames(frames, mesh=None):
     assert n1 == 1 and n2 == 1
     lib = C.CDLL(build(defs, header))
     lib.gfw_emu_launch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
-                                   C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int]
+                                   C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     n = len(frames)
+    pints, pfloats = np.zeros(16, np.int32), np.zeros(20, np.float32)        # the plane descriptors of the argument block (build_yuv_args)
+    for i, pl in enumerate(fr0.planes):
+        q = pl["params"]
+        pints[4 * i:4 * i + 4] = (q.stride, pl["out_size"][2], pl["size"][0], pl["size"][1])
+        pfloats[5 * i:5 * i + 4] = [np.float32(q.background[c]) * np.float32(q.max_pixel_value) for c in range(4)]
+        pfloats[5 * i + 4] = q.pixel_value_limit
     srcs, dsts, mats, keep, outs = (C.c_void_p * (4 * n))(), (C.c_void_p * (4 * n))(), (C.c_void_p * n)(), [], []
     for f, fr in enumerate(frames):
         packed = warp.pack_matrices(fr.matrices)
@@ -260,7 +266,7 @@ def run_frames(frames, mesh=None):
         com.mesh, com.mesh_len = mesh.ctypes.data, mesh.size
     kp = fr0.planes[0]["params"]
     rc = lib.gfw_emu_launch(n, srcs, dsts, mats, tab.ctypes.data, p1[1] if fast1 else 0.0, p1[2] if fast1 else 0.0, p1[3] if fast1 else 0.0,
-                            C.cast(C.byref(kp), C.c_void_p), C.cast(C.byref(com), C.c_void_p), 8)
+                            C.cast(C.byref(kp), C.c_void_p), C.cast(C.byref(com), C.c_void_p), 8, pints.ctypes.data, pfloats.ctypes.data)
     assert rc == 0, "gfw_emu_launch -> %d" % rc
     return outs
 

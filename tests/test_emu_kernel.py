@@ -102,6 +102,22 @@ def test_clip_launch_of_five_frames():
         assert all(np.array_equal(a, b) for a, b in zip(ref, got))
 
 
+@pytest.mark.parametrize("fmt,kw", [
+    ("YUV422P16LE", dict(fov=1.4, base_overrides={"background_mode": 3, "background_margin": 0.1, "background_margin_feather": 0.1})),
+    ("YUVA444P10LE", dict(fov=1.3, interpolation=4, base_overrides={"background_mode": 3, "background_margin": 0.13, "background_margin_feather": 0.24})),
+    ("YUV420P", dict(fov=1.2, base_overrides={"lens_correction_amount": 0.5})),
+    ("P010", dict(fov=1.5, base_overrides={"background_mode": 3, "background_margin": 0.05, "background_margin_feather": 0.05, "light_refraction_coefficient": 0.9}, flags=2048)),
+])
+def test_clip_launch_of_the_feature_bodies(fmt, kw):
+    """The interpreter's random sweep found it (seed 89 of tests/test_gpu_fuzz.py's generator, then a three-frame launch): background mode 3 on planar
+    chroma took the chroma planes' pointers from the argument block — frame 0's — for every frame of a clip launch.  Fixed in gfw_frame.hip (the named
+    plane objects carry the current frame's pointers); the GPU twin of this test is tests/test_gpu_jit.py::test_clip_launches_of_the_generic_model_bodies."""
+    frames = [S.SyntheticFrame(fmt, 192, 112, seed=100 + j, timestamp_ms=1000.0 + 33.3 * j, **kw) for j in range(3)]
+    for j, (fr, got) in enumerate(zip(frames, _emu.run_frames(frames))):
+        for p, (a, b) in enumerate(zip(O.run_frame(fr), got)):
+            assert np.array_equal(a, b), "frame %d plane %d: %d bytes differ" % (j, p, int(np.count_nonzero(a != b)))
+
+
 # ---- the complete per-plane operator (gfw_plane_kernel.h), which serves whatever the fused kernel does not ------------------------------
 
 PER_PLANE = sorted(n for n in G.CASES if n not in FUSED) + ["c2_yuv422p16_480x270_rs", "c1_nv12_1920x1080_constquat", "p010_lanczos4_640x360", "yuv420p_bilinear_642x362",

@@ -197,6 +197,25 @@ def test_clip_entry_point_matches_frame_by_frame_and_the_oracle(fmt, n):
             assert_plane_equal(a, c, fr.planes[p]["pixel_type"], "frame by frame, frame %d plane %d" % (j, p))
 
 
+@pytest.mark.parametrize("fmt,kw", [
+    ("YUV422P16LE", dict(fov=1.4, base_overrides={"background_mode": 3, "background_margin": 0.1, "background_margin_feather": 0.1})),
+    ("YUVA444P10LE", dict(fov=1.3, interpolation=4, base_overrides={"background_mode": 3, "background_margin": 0.13, "background_margin_feather": 0.24})),
+    ("YUV420P", dict(fov=1.2, base_overrides={"lens_correction_amount": 0.5})),
+    ("P010", dict(fov=1.5, base_overrides={"background_mode": 3, "background_margin": 0.05, "background_margin_feather": 0.05, "light_refraction_coefficient": 0.9}, flags=2048)),
+])
+def test_clip_launches_of_the_generic_model_bodies(fmt, kw):
+    """Several frames per launch through the feature-bit bodies (MODEL = -1 / -2).  Background mode 3 on planar chroma used to take the chroma
+    planes' pointers from the argument block — frame 0's — for every frame of the launch (found by the host interpreter's random sweep,
+    tests/test_emu_kernel.py::test_clip_launch_of_the_feature_bodies): every frame must land in its own planes."""
+    frames = [S.SyntheticFrame(fmt, 192, 112, seed=100 + j, timestamp_ms=1000.0 + 33.3 * j, pixels=False, **kw) for j in range(5)]
+    backend, status, (ms, launches, covered), outs, srcs = device_clip(frames, 2, True)
+    assert backend.endswith("_jit") and status[0] == 2 and launches == 1 and covered == 5, (backend, status, launches, covered)
+    for j, fr in enumerate(frames):
+        ref = O.run_frame(_View(fr, srcs[j]))
+        for p, (a, b) in enumerate(zip(ref, outs[j])):
+            assert_plane_equal(a, b, fr.planes[p]["pixel_type"], "clip launch, frame %d plane %d" % (j, p))
+
+
 def test_clip_frames_that_touch_a_pending_frames_buffers_leave_in_order():
     """The calls a clip stands for are ordered.  Frames that all write one destination go out one by one (the last one wins); a frame that
     reads the previous frame's output waits for it — same bytes as the frame-by-frame loop either way."""
