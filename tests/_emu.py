@@ -215,15 +215,19 @@ def fused_eligible(fr):
     return _int_products_exact(p0.output_width, p0.output_width) and _int_products_exact(p0.output_height, p0.output_height) and p0.width <= 65535 and p0.height <= 65535
 
 
-def run_frames(frames, mesh=None):
-    """One clip launch of the host-interpreted kernel over `frames` (same shape and constants, <= 16) -> [[plane outputs] per frame]."""
+def run_frames(frames, mesh=None, baked=True):
+    """One clip launch of the host-interpreted kernel over `frames` (same shape and constants, <= 16) -> [[plane outputs] per frame].
+    baked=False: the ahead-of-time form of the same body (every clip-invariant field read from the argument block instead of a literal; one frame)."""
     fr0 = frames[0]
     p0 = fr0.planes[0]["params"]
     assert fused_eligible(fr0), "not a frame the fused kernel serves"
     bps, n0, dw, dh, il = launch_shape(fr0)
     extras = feature_bits(fr0, mesh)
     fisheye = fr0.model == abi.MODELS["opencv_fisheye"]
-    jit_model = 1 if (fisheye and (extras & ~2) == 0) else (-2 if extras & (16 | 32) else -1)
+    # the specialised projection serves fisheye clips — also under a digital lens in a baked build, where the lens is a literal (jit_for); ahead of time
+    # any feature bit sends the frame to the generic-model instantiations (gfw_kernels.hip's dispatch)
+    lean = fisheye and ((extras & ~2) == 0 if baked else extras == 0)
+    jit_model = 1 if lean else (-2 if extras & (16 | 32) else -1)
     p1 = p1_table(p0, fr0.matrices, p0.matrix_count) if (fisheye and extras == 0) else None
     fast1 = p1 is not None
     rb = 4 if fast1 else 1
@@ -234,7 +238,7 @@ def run_frames(frames, mesh=None):
     header, n1 = re.subn(r"#define GFW_BK_extras \(0\)", "#define GFW_BK_extras (%d)" % extras, header)
     header, n2 = re.subn(r"#define GFW_BK_digital \(0\)", "#define GFW_BK_digital (%d)" % (fr0.digital if extras & 2 else 0), header)
     assert n1 == 1 and n2 == 1
-    lib = C.CDLL(build(defs, header))
+    lib = C.CDLL(build(defs, header, extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=%d" % (1 if baked else 0))))
     lib.gfw_emu_launch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
                                    C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     n = len(frames)
@@ -271,8 +275,8 @@ def run_frames(frames, mesh=None):
     return outs
 
 
-def run_frame(fr, mesh=None):
-    return run_frames([fr], mesh)[0]
+def run_frame(fr, mesh=None, baked=True):
+    return run_frames([fr], mesh, baked)[0]
 
 
 # ---- the complete per-plane operator (gfw_plane_kernel.h): every PixelType, EWA, input rotation, stretches, the colour-range and fill flags ----------

@@ -37,7 +37,17 @@ def test_kernel_source_reproduces_the_reference_kernels_output(name):
     assert [zlib.crc32(p.tobytes()) for p in planes] == GOLD[name]["planes"]
 
 
+@pytest.mark.parametrize("name", [n for n in FUSED if G.CASES[n]["w"] <= 1280])
+def test_ahead_of_time_form_reproduces_the_reference_kernels_output(name):
+    """the same body as the ahead-of-time kernels run it: every clip-invariant field read from the argument block (GFW_BAKE = 0), the generic-model
+    instantiation for any feature bit"""
+    fr = G.build(G.CASES[name])
+    assert [zlib.crc32(p.tobytes()) for p in _emu.run_frame(fr, baked=False)] == GOLD[name]["planes"]
+
+
 def same_as_oracle(fr, mesh=None):
+    for i, (a, b) in enumerate(zip(O.run_frame(fr) if mesh is None else [], _emu.run_frame(fr, mesh, baked=False) if mesh is None else [])):
+        assert np.array_equal(a, b), "ahead-of-time form, plane %d: %d bytes differ" % (i, int(np.count_nonzero(a != b)))
     got = _emu.run_frame(fr, mesh)
     for i, pl in enumerate(fr.planes):
         ref = pl["dst"].copy()
