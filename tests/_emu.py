@@ -325,3 +325,55 @@ def run_plane(fr, idx, mesh=None):
 
 def run_frame_per_plane(fr, mesh=None):
     return [run_plane(fr, i, mesh) for i in range(len(fr.planes))]
+
+
+# ---- the coordinate kernels of gfw_kernels.hip: STMap "undist" export and the inverse point map ------------------------------------------------------
+
+def _kernels_lib():
+    lib = C.CDLL(build({}, "", top="gfw_kernels.hip", n_asm=2, driver="emu_kernels_driver.inc", extra_flags=()))
+    lib.gfw_emu_stmap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.gfw_emu_points.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    return lib
+
+
+class _Lenses:
+    def __init__(self, model, digital):
+        self.model, self.digital = model, digital
+
+
+def stmap_undistort(params, model, digital, matrices, width, height):
+    """gfw_stmap_undistort through the host-interpreted gfw_stmap_kernel -> float32 [height][width][2] (0 where the ray is rejected)."""
+    coords = np.zeros((height, width, 2), dtype=np.float32)
+    com = common_for(_Lenses(model, digital), params)
+    packed = warp.pack_matrices(matrices)
+    rc = _kernels_lib().gfw_emu_stmap(C.cast(C.byref(params), C.c_void_p), C.cast(C.byref(com), C.c_void_p), packed.ctypes.data, width, height, coords.ctypes.data)
+    assert rc == 0
+    return coords
+
+
+def undistort_points(params, model, digital, rotations, points=None, grid=None, shifts=None, index_mode=0, mesh=None):
+    """gfw_undistort_points through the host-interpreted gfw_points_kernel (argument preparation as gfw_api.hip's: cos / sin of the roll by the host libm)."""
+    rot = np.ascontiguousarray(rotations, dtype=np.float32).reshape(-1, 9)
+    if points is not None:
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 2)
+        n, gw, pp, shape = pts.shape[0], 0, pts.ctypes.data, (pts.shape[0], 2)
+    else:
+        gw, gh = grid
+        n, pp, shape = gw * gh, None, (gh, gw, 2)
+    out = np.zeros(shape, dtype=np.float32)
+    sp, packed = None, None
+    if shifts is not None:
+        libm = C.CDLL("libm.so.6")
+        for fn in ("cosf", "sinf"):
+            getattr(libm, fn).restype, getattr(libm, fn).argtypes = C.c_float, [C.c_float]
+        s5 = np.ascontiguousarray(shifts, dtype=np.float32).reshape(-1, 5)
+        packed = np.array([[s[0], s[1], libm.cosf(s[2]), libm.sinf(s[2]), s[3], s[4]] for s in s5], dtype=np.float32)
+        sp = packed.ctypes.data
+    mp, mn = None, 0
+    if mesh is not None and len(mesh):
+        mesh = np.ascontiguousarray(mesh, dtype=np.float64)
+        mp, mn = mesh.ctypes.data, mesh.size
+    com = common_for(_Lenses(model, digital), params)
+    rc = _kernels_lib().gfw_emu_points(C.cast(C.byref(params), C.c_void_p), C.cast(C.byref(com), C.c_void_p), pp, n, gw, rot.ctypes.data, rot.shape[0], sp, index_mode, mp, mn, out.ctypes.data)
+    assert rc == 0
+    return out

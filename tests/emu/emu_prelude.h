@@ -89,3 +89,7 @@ static inline float min(float a, float b) { return fminf(a, b); }
 static inline float max(float a, float b) { return fmaxf(a, b); }
 template <typename T> static inline T atomicMax(T *p, T v) { emu_wave_atomic_point(); const T old = *p; if (v > old) *p = v; return old; }
 #define amdgpu_waves_per_eu(...)
+struct alignas(16) ulonglong2 { unsigned long long x, y; };
+// wave shuffles are not interpreted (only the verification checksum kernel uses one): a lane-at-a-time run has no neighbour to read
+[[noreturn]] void emu_unsupported(const char *what);
+template <typename T> static inline T __shfl_down(T, int, int = 64) { emu_unsupported("__shfl_down"); }
