@@ -215,8 +215,9 @@ def fused_eligible(fr):
     return _int_products_exact(p0.output_width, p0.output_width) and _int_products_exact(p0.output_height, p0.output_height) and p0.width <= 65535 and p0.height <= 65535
 
 
-def run_frames(frames, mesh=None, baked=True):
+def run_frames(frames, mesh=None, baked=True, grid=8):
     """One clip launch of the host-interpreted kernel over `frames` (same shape and constants, <= 16) -> [[plane outputs] per frame].
+    `grid`: persistent workgroups of the launch (a multiple of 8; the library launches num_cus x waves, capped at the tile count).
     baked=False: the ahead-of-time form of the same body (every clip-invariant field read from the argument block instead of a literal; one frame)."""
     fr0 = frames[0]
     p0 = fr0.planes[0]["params"]
@@ -270,7 +271,7 @@ def run_frames(frames, mesh=None, baked=True):
         com.mesh, com.mesh_len = mesh.ctypes.data, mesh.size
     kp = fr0.planes[0]["params"]
     rc = lib.gfw_emu_launch(n, srcs, dsts, mats, tab.ctypes.data, p1[1] if fast1 else 0.0, p1[2] if fast1 else 0.0, p1[3] if fast1 else 0.0,
-                            C.cast(C.byref(kp), C.c_void_p), C.cast(C.byref(com), C.c_void_p), 8, pints.ctypes.data, pfloats.ctypes.data)
+                            C.cast(C.byref(kp), C.c_void_p), C.cast(C.byref(com), C.c_void_p), grid, pints.ctypes.data, pfloats.ctypes.data)
     assert rc == 0, "gfw_emu_launch -> %d" % rc
     return outs
 

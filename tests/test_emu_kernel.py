@@ -177,3 +177,12 @@ def test_per_plane_flags_rotation_and_mesh_against_the_oracle():
     lens["model"], lens["k"], lens["digital"] = "sony", [1.0, 0.01, -0.05, 0.02, 0.003, -0.001] + [0.0] * 6, "gopro_superview"
     per_plane_same_as_oracle(S.SyntheticFrame("P010LE", w, h, seed=48, lens=lens, fov=1.2, base_overrides={"lens_correction_amount": 0.7, "background_mode": 3,
                                                                                                        "background_margin": 0.1, "background_margin_feather": 0.05}))
+
+
+@pytest.mark.parametrize("grid", [16, 24, 256, 2048])
+def test_tile_walk_under_other_launch_sizes(grid):
+    """the library launches num_cus x waves persistent workgroups capped at the tile count; the (frame, sub-band, tile) walk must cover every tile once for any multiple of 8"""
+    for fmt, w, h, n in (("YUV422P16LE", 384, 208, 5), ("NV12", 322, 186, 3), ("RGBA", 200, 120, 16)):
+        frames = [S.SyntheticFrame(fmt, w, h, seed=0x9F10 + j, timestamp_ms=1000.0 + 33.3 * j) for j in range(n)]
+        for fr, got in zip(frames, _emu.run_frames(frames, grid=grid)):
+            assert all(np.array_equal(a, b) for a, b in zip(O.run_frame(fr), got)), (fmt, grid)
