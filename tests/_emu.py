@@ -34,6 +34,26 @@ EMU = os.path.join(ROOT, "tests", "emu")
 OUT = os.path.join(ROOT, "build", "emu")
 CXX = "/opt/rocm/lib/llvm/bin/clang++" if os.path.exists("/opt/rocm/lib/llvm/bin/clang++") else "g++"
 P1_TABLE_N = 8192                 # GFW_P1_TABLE_N
+GUARD = False                     # memory-safety runs ("end" / "start"): the frame's own plane buffers as they are (the caller placed them against guard
+                                  # pages), no padding; matrix tables and the first-pass table go against guard pages here
+_guard_keep = []
+
+
+def guarded(data, at_end):
+    """a copy of `data` (any contiguous array) whose last (at_end) or first byte borders an inaccessible page"""
+    import mmap
+    raw = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+    page = mmap.PAGESIZE
+    body = (len(raw) + page - 1) // page * page
+    mm = mmap.mmap(-1, body + 2 * page)
+    base = C.addressof(C.c_char.from_buffer(mm))
+    libc = C.CDLL("libc.so.6")
+    libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    assert libc.mprotect(base, page, 0) == 0 and libc.mprotect(base + page + body, page, 0) == 0
+    arr = np.frombuffer(mm, dtype=np.uint8, count=len(raw), offset=page + (body - len(raw) if at_end else 0))
+    arr[:] = raw
+    _guard_keep.append(mm)
+    return arr
 
 
 def kernel_source(top="gfw_frame.hip", n_asm=7):
@@ -252,17 +272,24 @@ def run_frames(frames, mesh=None, baked=True, grid=8):
     srcs, dsts, mats, keep, outs = (C.c_void_p * (4 * n))(), (C.c_void_p * (4 * n))(), (C.c_void_p * n)(), [], []
     for f, fr in enumerate(frames):
         packed = warp.pack_matrices(fr.matrices)
+        if GUARD:
+            packed = guarded(packed, GUARD == "end")
         keep.append(packed)
         mats[f] = packed.ctypes.data
         planes = []
         for p, pl in enumerate(fr.planes):
-            src = np.concatenate([np.ascontiguousarray(pl["src"]), np.zeros(64, np.uint8)])        # the aligned tap-row fetches may read a few bytes past the plane
-            dst = pl["dst"].copy()
+            if GUARD:
+                src, dst = pl["src"], pl["dst"]
+            else:
+                src = np.concatenate([np.ascontiguousarray(pl["src"]), np.zeros(64, np.uint8)])    # slack behind the plane (see tests/test_emu_memory.py for the runs without it)
+                dst = pl["dst"].copy()
             keep.append(src)
             planes.append(dst)
             srcs[4 * f + p], dsts[4 * f + p] = src.ctypes.data, dst.ctypes.data
         outs.append(planes)
     tab = p1[0] if fast1 else np.zeros((2, 2), np.float32)
+    if GUARD:
+        tab = guarded(tab, GUARD == "end")
     libm = C.CDLL("libm.so.6")
     libm.tanf.restype, libm.tanf.argtypes = C.c_float, [C.c_float]
     com = Common(model=fr0.model, digital=fr0.digital, rot_cos=1.0, rot_sin=0.0, frame_w=float(p0.width), frame_h=float(p0.height), gopro_tt=libm.tanf(1.5533))
@@ -316,8 +343,12 @@ def run_plane(fr, idx, mesh=None):
         keep = np.ascontiguousarray(mesh, dtype=np.float32)
         com.mesh, com.mesh_len = keep.ctypes.data, keep.size
     packed = warp.pack_matrices(fr.matrices)
-    src = np.concatenate([np.ascontiguousarray(pl["src"]), np.zeros(64, np.uint8)])
-    dst = pl["dst"].copy()
+    if GUARD:
+        packed = guarded(packed, GUARD == "end")
+        src, dst = pl["src"], pl["dst"]
+    else:
+        src = np.concatenate([np.ascontiguousarray(pl["src"]), np.zeros(64, np.uint8)])
+        dst = pl["dst"].copy()
     rc = lib.gfw_emu_launch_plane(C.cast(C.byref(p), C.c_void_p), src.ctypes.data, dst.ctypes.data, dst.size, pl["out_size"][2], packed.ctypes.data,
                                   C.cast(C.byref(com), C.c_void_p))
     assert rc == 0, "gfw_emu_launch_plane -> %d" % rc
