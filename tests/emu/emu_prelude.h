@@ -50,8 +50,18 @@ void emu_wave_sync(int site);                 // a wavefront-scope fence: in har
 #define __builtin_amdgcn_fence(order, scope) emu_wave_sync(__LINE__)
 // wave votes: both outcomes of every vote in this source compute the same bits for a lane (they select a cheaper route when the whole
 // wave qualifies), so the lane's own predicate is a valid answer
+// (EMU_VOTES = 0, the default).  EMU_VOTES = 1 answers as a wave would in which some OTHER lane fails the test — __all false, __any true — so that
+// every lane takes the general route: the two settings together run both sides of each vote over all pixels.
+#ifndef EMU_VOTES
+#define EMU_VOTES 0
+#endif
+#if EMU_VOTES == 1
+#define __all(p) ((void)(p), 0)
+#define __any(p) ((void)(p), 1)
+#else
 #define __all(p) ((p) ? 1 : 0)
 #define __any(p) ((p) ? 1 : 0)
+#endif
 
 // A lane reaching an atomic waits until every other live lane of its wave has run as far as it can (to its own atomic, or to a fence): in
 // hardware the wave executes the instructions BEFORE the atomic in lockstep, so no lane may see its effect earlier (the first pass reads the

@@ -186,3 +186,12 @@ def test_tile_walk_under_other_launch_sizes(grid):
         frames = [S.SyntheticFrame(fmt, w, h, seed=0x9F10 + j, timestamp_ms=1000.0 + 33.3 * j) for j in range(n)]
         for fr, got in zip(frames, _emu.run_frames(frames, grid=grid)):
             assert all(np.array_equal(a, b) for a, b in zip(O.run_frame(fr), got)), (fmt, grid)
+
+
+@pytest.mark.parametrize("name", ["c2_yuv422p16_480x270_rs", "yuv420p10_320x192_rs", "nv12_horizontal_rs", "yuv422p16_fov05_hrs", "c1_nv12_1920x1080_constquat", "superview_640x360"])
+def test_the_general_side_of_every_wave_vote(name):
+    """`__all(x < 0.4375)` (atanf without its reduction), `__any(tiny)` (chroma coordinate as half the luma one): the interpreter normally answers a vote with
+    the lane's own predicate, so a lane only ever runs the side it qualifies for; here every vote is answered as if another lane had failed it, and all pixels
+    take the general side — which must produce the same bits (on the device a single lane decides for its 63 neighbours)."""
+    fr = G.build(G.CASES[name])
+    assert [zlib.crc32(p.tobytes()) for p in _emu.run_frames([fr], votes=1)[0]] == GOLD[name]["planes"]
