@@ -410,3 +410,46 @@ def undistort_points(params, model, digital, rotations, points=None, grid=None, 
     rc = _kernels_lib().gfw_emu_points(C.cast(C.byref(params), C.c_void_p), C.cast(C.byref(com), C.c_void_p), pp, n, gw, rot.ctypes.data, rot.shape[0], sp, index_mode, mp, mn, out.ctypes.data)
     assert rc == 0
     return out
+
+
+# ---- the per-row matrix builder (gfw_matrices.hip) ----------------------------------------------------------------------------------------------------
+
+def build_matrices(org, smoothed, nk, timestamps_ms, frame_readout_time_ms, rows, readout_dim, video_rotation_deg=0.0, framebuffer_inverted=False,
+                   per_frame_offset_ms=0.0, offsets=None, duration_ms=1.0, suppress_rotation=0, stab=None):
+    """gfw_build_matrices(_batch / _stab) through the host-interpreted kernels -> float32 [frames][rows][16] (packed rows).  Arguments as the Python
+    wrappers of gyroflow_amd/warp.py take them; `stab` as a dict(offset, sensor_size, crop_area, pixel_pitch, width, height, ibis, ois)."""
+    lib = C.CDLL(build({}, "", top="gfw_matrices.hip", n_asm=2, driver="emu_matrices_driver.inc", extra_flags=()))
+    ts_list = list(np.atleast_1d(timestamps_ms))
+    n = len(ts_list)
+    arr = (abi.FrameTiming * n)()
+    nkf = np.asarray(nk, dtype=np.float64).reshape(9)
+    for k, ts in enumerate(ts_list):
+        t = arr[k]
+        t.timestamp_ms, t.per_frame_time_offset_ms, t.frame_readout_time_ms = float(ts), per_frame_offset_ms, frame_readout_time_ms
+        for i in range(9):
+            t.new_k[i] = nkf[i]
+        t.video_rotation_deg, t.rows, t.readout_dim = video_rotation_deg, rows, readout_dim
+        t.framebuffer_inverted = 1 if framebuffer_inverted else 0
+        t.suppress_rotation = int(suppress_rotation)
+    ot, oq = np.ascontiguousarray(org[0], dtype=np.int64), np.ascontiguousarray(org[1], dtype=np.float64)
+    st, sq = np.ascontiguousarray(smoothed[0], dtype=np.int64), np.ascontiguousarray(smoothed[1], dtype=np.float64)
+    fts = np.ascontiguousarray(offsets[0] if offsets else [], dtype=np.int64)
+    fms = np.ascontiguousarray(offsets[1] if offsets else [], dtype=np.float64)
+    out = np.zeros((n, rows, 16), dtype=np.float32)
+    sd = ib = oi = None
+    if stab is not None:                        # gfw_api.hip gfw_build_matrices_stab: frame_transform.rs:234-241
+        inv = -1.0 if framebuffer_inverted else 1.0
+        sd = np.array([stab["offset"], stab["sensor_size"][1], stab["crop_area"][1], stab["crop_area"][3],
+                       stab["width"] / stab["crop_area"][2] / stab["pixel_pitch"][0], stab["height"] / stab["crop_area"][3] / stab["pixel_pitch"][1] * inv,
+                       stab["height"]], dtype=np.float64)
+        ib = np.ascontiguousarray(stab["ibis"], dtype=np.float64).reshape(-1, 4)
+        oi = np.ascontiguousarray(stab["ois"], dtype=np.float64).reshape(-1, 4)
+    lib.gfw_emu_build_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                                           C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    rc = lib.gfw_emu_build_matrices(ot.ctypes.data, oq.ctypes.data, len(ot), st.ctypes.data, sq.ctypes.data, len(st),
+                                    fts.ctypes.data if len(fts) else None, fms.ctypes.data if len(fts) else None, len(fts), float(duration_ms),
+                                    C.cast(arr, C.c_void_p), n, rows, out.ctypes.data, rows * 16,
+                                    sd.ctypes.data if sd is not None else None, ib.ctypes.data if ib is not None and len(ib) else None, len(ib) if ib is not None else 0,
+                                    oi.ctypes.data if oi is not None and len(oi) else None, len(oi) if oi is not None else 0)
+    assert rc == 0
+    return out
