@@ -235,9 +235,10 @@ def fused_eligible(fr):
     return _int_products_exact(p0.output_width, p0.output_width) and _int_products_exact(p0.output_height, p0.output_height) and p0.width <= 65535 and p0.height <= 65535
 
 
-def run_frames(frames, mesh=None, baked=True, grid=8, votes=0):
+def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0):
     """One clip launch of the host-interpreted kernel over `frames` (same shape and constants, <= 16) -> [[plane outputs] per frame].
     `votes`: 0 = a wave vote answers with the lane's own predicate, 1 = as if another lane of the wave failed it (every lane takes the general route).
+    `hw_ulp`: the stand-ins for v_rcp_f32 / v_sqrt_f32 return the correctly rounded value moved by this many ulps (the hardware's are 1-ulp approximations).
     `grid`: persistent workgroups of the launch (a multiple of 8; the library launches num_cus x waves, capped at the tile count).
     baked=False: the ahead-of-time form of the same body (every clip-invariant field read from the argument block instead of a literal; one frame)."""
     fr0 = frames[0]
@@ -260,7 +261,7 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0):
     header, n1 = re.subn(r"#define GFW_BK_extras \(0\)", "#define GFW_BK_extras (%d)" % extras, header)
     header, n2 = re.subn(r"#define GFW_BK_digital \(0\)", "#define GFW_BK_digital (%d)" % (fr0.digital if extras & 2 else 0), header)
     assert n1 == 1 and n2 == 1
-    lib = C.CDLL(build(defs, header, extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=%d" % (1 if baked else 0), "-DEMU_VOTES=%d" % votes)))
+    lib = C.CDLL(build(defs, header, extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=%d" % (1 if baked else 0), "-DEMU_VOTES=%d" % votes, "-DEMU_HW_ULP=%d" % hw_ulp)))
     lib.gfw_emu_launch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
                                    C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     n = len(frames)

@@ -75,8 +75,20 @@ static inline int emu_v_cvt_i32_f32(float v) { if (v != v) return 0; if (v >= 21
 static inline uint32_t emu_v_cvt_u32_f32(float v) { if (v != v || v <= 0.0f) return 0u; if (v >= 4294967296.0f) return 0xFFFFFFFFu; return (uint32_t)v; }
 static inline float emu_v_min_f32(float a, float b) { return fminf(a, b); }                  // IEEE mode: the non-NaN operand wins
 static inline int emu_v_mul_i32_i24(int a, int b) { return (int)((int64_t)((a << 8) >> 8) * (int64_t)((b << 8) >> 8)); }
-static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }                       // v_rcp_f32 is within 1 ulp of this; the callers refine it
-static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
+// v_rcp_f32 / v_sqrt_f32 are 1-ulp approximations; the callers refine them (gfw_fastmath.h).  Here they are the correctly rounded values, moved by
+// EMU_HW_ULP units in the last place (0, +1, -1) so that a run can show that the refinement does not depend on WHICH 1-ulp answer the hardware gives.
+#ifndef EMU_HW_ULP
+#define EMU_HW_ULP 0
+#endif
+static inline float emu_nudge(float v) {
+    if (EMU_HW_ULP == 0 || !(v == v) || v == 0.0f || isinf(v)) return v;
+    uint32_t u; memcpy(&u, &v, 4);
+    u += (uint32_t)(((u >> 31) ? -1 : 1) * EMU_HW_ULP);          // towards larger magnitude for +n on either sign: a step in the value's own ulp
+    memcpy(&v, &u, 4);
+    return v;
+}
+static inline float __builtin_amdgcn_rcpf(float x) { return emu_nudge(1.0f / x); }
+static inline float __builtin_amdgcn_sqrtf(float x) { return emu_nudge(sqrtf(x)); }
 static inline float __builtin_amdgcn_fractf(float x) { const float f = x - floorf(x); return f < 1.0f ? f : 0x1.fffffep-1f; }
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31u)); }
 static inline uint32_t __builtin_amdgcn_udot4(uint32_t a, uint32_t b, uint32_t c, bool) {

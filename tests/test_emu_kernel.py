@@ -195,3 +195,15 @@ def test_the_general_side_of_every_wave_vote(name):
     take the general side — which must produce the same bits (on the device a single lane decides for its 63 neighbours)."""
     fr = G.build(G.CASES[name])
     assert [zlib.crc32(p.tobytes()) for p in _emu.run_frames([fr], votes=1)[0]] == GOLD[name]["planes"]
+
+
+@pytest.mark.parametrize("name", ["c2_yuv422p16_480x270_rs", "nv12_horizontal_rs", "yuv422p16_fov05_hrs", "c4_rgbaf32_crop_1280x720", "sony_640x360"])
+def test_lean_primitives_do_not_depend_on_which_one_ulp_answer_the_hardware_gives(name):
+    """gfw_fastmath.h refines v_rcp_f32 / v_sqrt_f32 (1-ulp approximations) into correctly rounded quotients and roots.  The interpreter's stand-ins return
+    the correctly rounded value; moved by one ulp either way the frame must not change — moved by two it must (the refinement's reach, and the proof that
+    this run can see a wrong primitive)."""
+    fr = G.build(G.CASES[name])
+    for ulp in (1, -1):
+        assert [zlib.crc32(p.tobytes()) for p in _emu.run_frames([fr], hw_ulp=ulp)[0]] == GOLD[name]["planes"], ulp
+    if name == "c2_yuv422p16_480x270_rs":
+        assert [zlib.crc32(p.tobytes()) for p in _emu.run_frames([fr], hw_ulp=2)[0]] != GOLD[name]["planes"]
