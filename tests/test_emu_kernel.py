@@ -126,6 +126,8 @@ def test_clip_launch_of_the_feature_bodies(fmt, kw):
     for j, (fr, got) in enumerate(zip(frames, _emu.run_frames(frames))):
         for p, (a, b) in enumerate(zip(O.run_frame(fr), got)):
             assert np.array_equal(a, b), "frame %d plane %d: %d bytes differ" % (j, p, int(np.count_nonzero(a != b)))
+    for p, (a, b) in enumerate(zip(O.run_frame(frames[0]), _emu.run_frame(frames[0], baked=False))):          # and the ahead-of-time form of the same body
+        assert np.array_equal(a, b), "ahead-of-time form, plane %d: %d bytes differ" % (p, int(np.count_nonzero(a != b)))
 
 
 # ---- the complete per-plane operator (gfw_plane_kernel.h), which serves whatever the fused kernel does not ------------------------------
