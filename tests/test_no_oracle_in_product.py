@@ -27,6 +27,18 @@ def test_product_sources_never_reference_the_oracle():
     assert not hits, "\n".join(hits)
 
 
+def test_product_sources_never_reference_the_host_interpreter_or_the_reference_build():
+    """tests/_emu.py (the kernels' source interpreted on the host) and oracle/_ref (the reference's own kernel, host build) are test infrastructure too:
+    no product file may name them, and bench.py may touch neither (its only CPU legs are the oracle's parity check and cpu_baseline)."""
+    pat = re.compile(r"\b_emu\b|tests/emu|emu_prelude|gfw_emu_|EMU_VOTES|EMU_HW_ULP|oracle/_ref|gfw_ref_cl|ref_cl_host")
+    hits = []
+    for path in list(product_files()) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "include", "gfwarp.h"), os.path.join(ROOT, "include", "gfwarp.hpp")]:
+        for n, line in enumerate(open(path, errors="replace"), 1):
+            if pat.search(line):
+                hits.append("%s:%d: %s" % (os.path.relpath(path, ROOT), n, line.strip()))
+    assert not hits, "\n".join(hits)
+
+
 def test_shared_library_does_not_link_the_oracle():
     lib = os.path.join(PKG, "libgfwarp.so")
     if not os.path.exists(lib):
