@@ -56,6 +56,10 @@ Rtc &rtc() { static Rtc r; return r; }
 
 enum { ST_COMPILING = 1, ST_COMPILED = 2, ST_LOADED = 3, ST_FAILED = -1 };
 
+// An entry of the definition list becomes -D<entry>; one that starts with '-' is a compiler option passed as it is (experiments through
+// GFW_JIT_DEFS, e.g. "-fno-slp-vectorize": the options are part of the cache key like every definition).
+std::string jit_option(const std::string &d) { return (!d.empty() && d[0] == '-') ? d : "-D" + d; }
+
 struct Entry {
     std::atomic<int> state{ST_COMPILING};
     std::vector<char> code;
@@ -116,7 +120,7 @@ hipFunction_t gfw_jit_get(int device, const std::string &arch, const std::vector
             e = std::make_shared<Entry>();
             std::vector<std::string> opts = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed",
                                              "-Wno-cuda-compat", "-DGFW_JIT=1", "-DGFW_BAKE=1"};
-            for (const std::string &d : defines) opts.push_back("-D" + d);
+            for (const std::string &d : defines) opts.push_back(jit_option(d));
             std::string source = bake_header + "\n" + GFW_JIT_SOURCE;
             e->worker = std::thread(compile_entry, e.get(), std::move(source), std::move(opts));
             g_cache.emplace(key, e);
@@ -153,7 +157,7 @@ long gfw_jit_compile_only(const std::string &arch, const std::vector<std::string
     Entry e;
     std::vector<std::string> opts = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed", "-Wno-cuda-compat",
                                      "-DGFW_JIT=1", "-DGFW_BAKE=1"};
-    for (const std::string &d : defines) opts.push_back("-D" + d);
+    for (const std::string &d : defines) opts.push_back(jit_option(d));
     compile_entry(&e, bake_header + "\n" + GFW_JIT_SOURCE, opts);
     log = e.log;
     if (e.state.load() != ST_COMPILED) return -1;

@@ -107,3 +107,25 @@ def test_420_specialisation_keeps_eight_workgroups_per_cu(tmp_path):
     k = [k for k in KR.report(out) if k[".name"] == "gfw_jit_kernel"][0]
     assert k[".group_segment_fixed_size"] <= 20 * 1024 and k[".vgpr_count"] <= 64 and k[".private_segment_fixed_size"] == 0, k
     assert KR.workgroups_per_cu(k) >= 8, KR.workgroups_per_cu(k)
+
+
+def test_a_compiler_option_travels_through_the_definition_list(tmp_path):
+    """An entry of the definition list (GFW_JIT_DEFS at run time) that starts with '-' is a compiler option: `-fno-slp-vectorize` must reach hiprtc — the
+    build then holds no packed-f32 instruction (the default build packs ~150 multiplies / adds, each half rate and fed by register shuffles: the first
+    thing the next round measures, profiles/r03_slp_static.txt)."""
+    import subprocess
+    lib = abi.load_library()
+    header = open(os.path.join(ROOT, "tools", "bake_c2.h")).read()
+    counts = {}
+    for tag, extra in (("default", ""), ("noslp", ";-fno-slp-vectorize")):
+        out = str(tmp_path / ("jit_%s.co" % tag))
+        log = C.create_string_buffer(1 << 16)
+        n = lib.gfw_debug_jit_compile(b"gfx950", ((C2_DEFS % (2, 8)) + extra).encode(), header.encode(), out.encode(), log, len(log))
+        if n == -2:
+            pytest.skip("libhiprtc.so not available")
+        assert n > 0, log.value.decode(errors="replace")[-3000:]
+        dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "--mcpu=gfx950", out]).decode()
+        counts[tag] = sum(1 for l in dis.splitlines() if "\tv_pk_mul_f32" in l or "\tv_pk_add_f32" in l or "\tv_pk_fma_f32" in l)
+        k = [k for k in KR.report(out) if k[".name"] == "gfw_jit_kernel"][0]
+        assert k[".vgpr_count"] <= 64 and k[".private_segment_fixed_size"] == 0
+    assert counts["default"] > 50 and counts["noslp"] == 0, counts
