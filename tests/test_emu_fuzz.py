@@ -1,5 +1,5 @@
 """The GPU tier's seeded random sweep (tests/test_gpu_fuzz.py: format x interpolation x background mode x flags x lens model x digital lens x readout
-direction x odd sizes x blend x stretch x margins, the same 80 configurations) through the host-interpreted kernel sources (tests/_emu.py): the per-plane
+direction x odd sizes x blend x stretch x margins, every other of its 80 configurations; 1 300 more went through offline: profiles/r03_interpreter_hunts.txt) through the host-interpreted kernel sources (tests/_emu.py): the per-plane
 kernel on every configuration, the fused kernel wherever the library would use it — both bit-identical to the oracle."""
 import numpy as np
 import pytest
@@ -10,7 +10,7 @@ import _oracle as O
 from test_gpu_fuzz import random_case
 
 
-@pytest.mark.parametrize("seed", range(80))
+@pytest.mark.parametrize("seed", range(0, 80, 2))
 def test_random_configuration_through_the_interpreted_kernels(seed):
     fmt, w, h, kw = random_case(seed)
     fr = S.SyntheticFrame(fmt, w, h, **kw)

@@ -37,7 +37,11 @@ def test_kernel_source_reproduces_the_reference_kernels_output(name):
     assert [zlib.crc32(p.tobytes()) for p in planes] == GOLD[name]["planes"]
 
 
-@pytest.mark.parametrize("name", [n for n in FUSED if G.CASES[n]["w"] <= 1280])
+AOT_CASES = ["c2_yuv422p16_480x270_rs", "c1_nv12_1920x1080_constquat", "p010_lanczos4_640x360", "yuv420p_bilinear_642x362", "yuv444p16_bicubic_640x360", "rgba_lanczos4_640x360",
+             "gbrapf32_bicubic_640x360", "nv12_horizontal_rs", "yuv422p16_mirror", "gopro_640x360", "superview_nv12_lca06_640x360", "hyperview_lca06_640x360", "ibis_terms_640x360"]
+
+
+@pytest.mark.parametrize("name", AOT_CASES)
 def test_ahead_of_time_form_reproduces_the_reference_kernels_output(name):
     """the same body as the ahead-of-time kernels run it: every clip-invariant field read from the argument block (GFW_BAKE = 0), the generic-model
     instantiation for any feature bit"""
