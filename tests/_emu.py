@@ -235,14 +235,18 @@ def fused_eligible(fr):
     return _int_products_exact(p0.output_width, p0.output_width) and _int_products_exact(p0.output_height, p0.output_height) and p0.width <= 65535 and p0.height <= 65535
 
 
-def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0):
+def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=False):
     """One clip launch of the host-interpreted kernel over `frames` (same shape and constants, <= 16) -> [[plane outputs] per frame].
     `votes`: 0 = a wave vote answers with the lane's own predicate, 1 = as if another lane of the wave failed it (every lane takes the general route).
+    `audit`: the audit instantiation (ahead-of-time form, bilinear): -> (outputs, dict of the audit words: certificates issued / wrong, queued pixels,
+    largest |approximate - exact| first-pass coordinate, addresses outside the declared buffers).
     `hw_ulp`: the stand-ins for v_rcp_f32 / v_sqrt_f32 return the correctly rounded value moved by this many ulps (the hardware's are 1-ulp approximations).
     `grid`: persistent workgroups of the launch (a multiple of 8; the library launches num_cus x waves, capped at the tile count).
     baked=False: the ahead-of-time form of the same body (every clip-invariant field read from the argument block instead of a literal; one frame)."""
     fr0 = frames[0]
     p0 = fr0.planes[0]["params"]
+    if audit:
+        baked = False
     assert fused_eligible(fr0), "not a frame the fused kernel serves"
     bps, n0, dw, dh, il = launch_shape(fr0)
     extras = feature_bits(fr0, mesh)
@@ -261,16 +265,17 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0):
     header, n1 = re.subn(r"#define GFW_BK_extras \(0\)", "#define GFW_BK_extras (%d)" % extras, header)
     header, n2 = re.subn(r"#define GFW_BK_digital \(0\)", "#define GFW_BK_digital (%d)" % (fr0.digital if extras & 2 else 0), header)
     assert n1 == 1 and n2 == 1
-    lib = C.CDLL(build(defs, header, extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=%d" % (1 if baked else 0), "-DEMU_VOTES=%d" % votes, "-DEMU_HW_ULP=%d" % hw_ulp)))
+    lib = C.CDLL(build(defs, header, extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=%d" % (1 if baked else 0), "-DEMU_VOTES=%d" % votes, "-DEMU_HW_ULP=%d" % hw_ulp, "-DEMU_AUDIT=%d" % (1 if audit else 0))))
     lib.gfw_emu_launch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
                                    C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     n = len(frames)
-    pints, pfloats = np.zeros(16, np.int32), np.zeros(20, np.float32)        # the plane descriptors of the argument block (build_yuv_args)
+    pints, pfloats = np.zeros(24, np.int32), np.zeros(20, np.float32)        # the plane descriptors of the argument block (build_yuv_args); [16..23]: declared lengths
     for i, pl in enumerate(fr0.planes):
         q = pl["params"]
         pints[4 * i:4 * i + 4] = (q.stride, pl["out_size"][2], pl["size"][0], pl["size"][1])
         pfloats[5 * i:5 * i + 4] = [np.float32(q.background[c]) * np.float32(q.max_pixel_value) for c in range(4)]
         pfloats[5 * i + 4] = q.pixel_value_limit
+        pints[16 + 2 * i], pints[16 + 2 * i + 1] = len(pl["src"]), len(pl["dst"])
     srcs, dsts, mats, keep, outs = (C.c_void_p * (4 * n))(), (C.c_void_p * (4 * n))(), (C.c_void_p * n)(), [], []
     for f, fr in enumerate(frames):
         packed = warp.pack_matrices(fr.matrices)
@@ -302,6 +307,12 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0):
     rc = lib.gfw_emu_launch(n, srcs, dsts, mats, tab.ctypes.data, p1[1] if fast1 else 0.0, p1[2] if fast1 else 0.0, p1[3] if fast1 else 0.0,
                             C.cast(C.byref(kp), C.c_void_p), C.cast(C.byref(com), C.c_void_p), grid, pints.ctypes.data, pfloats.ctypes.data)
     assert rc == 0, "gfw_emu_launch -> %d" % rc
+    if audit:
+        words = (C.c_ulonglong * 8)()
+        lib.gfw_emu_audit(words, 1)
+        gap = float(np.array([int(words[4]) & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0])
+        return outs, {"certified": int(words[0]), "wrong": int(words[1]), "queued": int(words[2]), "queue_overflow": int(words[3]), "gap_px": gap,
+                      "out_of_range": int(words[5]), "eps_px": p1[3] if fast1 else None}
     return outs
 
 

@@ -1,0 +1,35 @@
+"""The first pass's certificate, audited on the CPU tier: the fused kernel's AUDIT instantiation (ahead-of-time form, host-interpreted: tests/_emu.py) re-derives
+the exact rolling-shutter row of every pixel whose approximate row it accepted and records the largest |approximate - exact| coordinate, and range-checks every
+tap, store, matrix row and table entry against the declared buffer lengths — over seeded random fisheye clips (lens coefficients, focal length, principal point,
+field of view 0.5-3, readout up to +-30 ms, both shutter directions, odd sizes).  The CPU twin of tests/test_gpu_pass1_sweep.py (same assertions: no wrong
+certificate, gap below half the certificate's half-width E, nothing out of range, the queue never overflows)."""
+import numpy as np
+import pytest
+
+from gyroflow_amd import synthetic as S
+import _emu
+import _oracle as O
+
+
+def random_clip(seed):
+    rng = np.random.default_rng(50000 + seed)
+    w, h = int(rng.integers(60, 330)) * 2, int(rng.integers(40, 190)) * 2
+    lens = S.gopro_style_lens(w, h)
+    lens["f"] = (float(rng.uniform(0.3, 1.2)) * w,) * 2
+    lens["c"] = (w / 2.0 + float(rng.uniform(-0.05, 0.05)) * w, h / 2.0 + float(rng.uniform(-0.05, 0.05)) * h)
+    lens["k"] = [float(rng.uniform(-0.08, 0.12)), float(rng.uniform(-0.05, 0.05)), float(rng.uniform(-0.03, 0.03)), float(rng.uniform(-0.01, 0.01))] + [0.0] * 8
+    fmt = ["NV12", "YUV422P16LE", "YUV420P", "P010LE"][seed % 4]
+    return S.SyntheticFrame(fmt, w, h, seed=int(rng.integers(1, 1 << 20)), lens=lens, fov=float(rng.uniform(0.5, 3.0)), readout_ms=float(rng.uniform(-30.0, 30.0)),
+                            horizontal_rs=bool(rng.random() < 0.3))
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_every_certificate_of_a_random_clip(seed):
+    fr = random_clip(seed)
+    p0 = fr.planes[0]["params"]
+    if _emu.p1_table(p0, fr.matrices, p0.matrix_count) is None:
+        pytest.skip("no certified first pass for this clip (E >= 0.2 px or a single matrix)")
+    outs, a = _emu.run_frames([fr], audit=True)
+    assert a["wrong"] == 0 and a["queue_overflow"] == 0 and a["out_of_range"] == 0, a
+    assert a["certified"] > 0 and a["gap_px"] < 0.5 * a["eps_px"], a
+    assert all(np.array_equal(x, y) for x, y in zip(O.run_frame(fr), outs[0]))
