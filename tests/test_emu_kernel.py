@@ -213,3 +213,30 @@ def test_lean_primitives_do_not_depend_on_which_one_ulp_answer_the_hardware_give
         assert [zlib.crc32(p.tobytes()) for p in _emu.run_frames([fr], hw_ulp=ulp)[0]] == GOLD[name]["planes"], ulp
     if name == "c2_yuv422p16_480x270_rs":
         assert [zlib.crc32(p.tobytes()) for p in _emu.run_frames([fr], hw_ulp=2)[0]] != GOLD[name]["planes"]
+
+
+@pytest.mark.parametrize("trial", range(6))
+def test_source_and_output_rects_three_ways(trial):
+    """HAS_SOURCE_RECT / HAS_OUTPUT_RECT (the buffer descriptions' rects, mod.rs:279-295): the per-plane kernel (host-interpreted), the oracle and — on the
+    luma plane, the field of view inside the frame — the reference's own kernel (host build) must all write the same bytes; pixels outside the output rect
+    keep the caller's content."""
+    from _refcl import run_reference_cl_host
+    rng = np.random.default_rng(700 + trial)
+    fmt = ["YUV422P16LE", "NV12", "RGBA", "RGBAF32", "P010LE", "YUV420P"][trial]
+    interp = [2, 4, 8][trial % 3]
+    w, h = int(rng.integers(60, 160)) * 2, int(rng.integers(40, 100)) * 2
+    fr = S.SyntheticFrame(fmt, w, h, seed=900 + trial, fov=0.85, interpolation=interp, horizontal_rs=bool(trial == 4))
+    for pl in fr.planes:
+        p = pl["params"]
+        (pw, ph), (ow, oh) = pl["size"][:2], pl["out_size"][:2]
+        x0, y0 = int(rng.integers(1, pw // 5)), int(rng.integers(1, ph // 5))
+        p.source_rect[0], p.source_rect[1], p.source_rect[2], p.source_rect[3] = x0, y0, pw - x0 - int(rng.integers(1, pw // 5)), ph - y0 - int(rng.integers(1, ph // 5))
+        x0, y0 = int(rng.integers(1, ow // 5)), int(rng.integers(1, oh // 5))
+        p.output_rect[0], p.output_rect[1], p.output_rect[2], p.output_rect[3] = x0, y0, ow - x0 - int(rng.integers(1, ow // 5)), oh - y0 - int(rng.integers(1, oh // 5))
+        p.flags |= abi.FLAG_HAS_SOURCE_RECT | abi.FLAG_HAS_OUTPUT_RECT
+    ref = O.run_frame(fr)
+    for i, (a, b) in enumerate(zip(ref, _emu.run_frame_per_plane(fr))):
+        assert np.array_equal(a, b), "plane %d: %d bytes differ" % (i, int(np.count_nonzero(a != b)))
+    assert np.count_nonzero(ref[0] == 0x5A) > 0                                          # the border outside the output rect kept the 0x5A fill
+    name = {"Luma16": "luma16", "Luma8": "luma8", "RGBA8": "rgba8", "RGBAf": "rgbaf"}[fr.planes[0]["pixel_type"]] + "_" + {2: "bilinear", 4: "bicubic", 8: "lanczos4"}[interp] + "_fisheye"
+    assert np.array_equal(run_reference_cl_host(name, fr.planes[0], fr.matrices), ref[0])
