@@ -76,6 +76,9 @@ def kernel_source(top="gfw_frame.hip", n_asm=7):
 
 def build(defs, header, top="gfw_frame.hip", n_asm=7, driver="emu_driver.inc", extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=1")):
     """-> path of the host library for these template arguments (+ bake header) (cached under build/emu/ by content)."""
+    if not CXX.endswith("clang++"):
+        import pytest
+        pytest.skip("the host interpreter is built with the ROCm clang++ (half-precision and vector extensions of the kernel headers); not found")
     os.makedirs(OUT, exist_ok=True)
     text = ('#include "emu_prelude.h"\n' + header + "\n" + kernel_source(top, n_asm) + '\n#include "%s"\n' % driver)
     flags = ["-std=c++17", "-O1", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-Wno-everything", "-I" + EMU] + list(extra_flags) + \
