@@ -74,14 +74,14 @@ def kernel_source(top="gfw_frame.hip", n_asm=7):
     return src
 
 
-def build(defs, header, top="gfw_frame.hip", n_asm=7, driver="emu_driver.inc", extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=1")):
+def build(defs, header, top="gfw_frame.hip", n_asm=7, driver="emu_driver.inc", extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=1"), opt="-O1"):
     """-> path of the host library for these template arguments (+ bake header) (cached under build/emu/ by content)."""
     if not CXX.endswith("clang++"):
         import pytest
         pytest.skip("the host interpreter is built with the ROCm clang++ (half-precision and vector extensions of the kernel headers); not found")
     os.makedirs(OUT, exist_ok=True)
     text = ('#include "emu_prelude.h"\n' + header + "\n" + kernel_source(top, n_asm) + '\n#include "%s"\n' % driver)
-    flags = ["-std=c++17", "-O1", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-Wno-everything", "-I" + EMU] + list(extra_flags) + \
+    flags = ["-std=c++17", opt, "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-Wno-everything", "-I" + EMU] + list(extra_flags) + \
             ["-D%s=%s" % kv for kv in sorted(defs.items())]
     key = hashlib.sha256((text + " ".join(flags) + "".join(open(os.path.join(EMU, f)).read() for f in sorted(os.listdir(EMU)))).encode()).hexdigest()[:20]
     so = os.path.join(OUT, "emu_%s.so" % key)
@@ -268,7 +268,8 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=F
     header, n1 = re.subn(r"#define GFW_BK_extras \(0\)", "#define GFW_BK_extras (%d)" % extras, header)
     header, n2 = re.subn(r"#define GFW_BK_digital \(0\)", "#define GFW_BK_digital (%d)" % (fr0.digital if extras & 2 else 0), header)
     assert n1 == 1 and n2 == 1
-    lib = C.CDLL(build(defs, header, extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=%d" % (1 if baked else 0), "-DEMU_VOTES=%d" % votes, "-DEMU_HW_ULP=%d" % hw_ulp, "-DEMU_AUDIT=%d" % (1 if audit else 0))))
+    small = len(frames) * p0.output_width * p0.output_height < 400000              # small launches: an unoptimised build compiles faster than it runs slower
+    lib = C.CDLL(build(defs, header, opt="-O0" if small else "-O1", extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=%d" % (1 if baked else 0), "-DEMU_VOTES=%d" % votes, "-DEMU_HW_ULP=%d" % hw_ulp, "-DEMU_AUDIT=%d" % (1 if audit else 0))))
     lib.gfw_emu_launch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
                                    C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     n = len(frames)
