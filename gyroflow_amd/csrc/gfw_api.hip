@@ -119,6 +119,7 @@ struct gfw_ctx {
     std::string jit_header; int jit_seen = 0;      // bake header of the frames being seen, and how many in a row
     GfwYuvArgs jit_key; int jit_key_misc[8] = {}; bool jit_key_valid = false;      // the clip those frames belong to (argument block, per-frame fields blanked)
     hipFunction_t jit_fn = nullptr; int jit_grid = 0;                               // its specialised kernel once loaded
+    bool jit_dead = false;                                                          // ... or the verdict that there will be none for this clip (build failed / cache full)
     GfwJitInfo jit_info = {GFW_JIT_UNAVAILABLE, 0.0, std::string()};
     static constexpr int kJitAfter = 3;
     bool profile = false;
@@ -234,7 +235,10 @@ gfw_ctx *gfw_create(const gfw_kernel_params *params, int pixel_type, int distort
     gfw_ctx *c = new gfw_ctx();
     c->device = g_current_device;
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, c->device) == hipSuccess && pr.multiProcessorCount > 0) { c->num_cus = pr.multiProcessorCount; c->arch = pr.gcnArchName; } }
-    if (const char *e = getenv("GFW_JIT")) c->jit_mode = atoi(e);          // deployment / test override of GFW_OPT_JIT's default
+    if (const char *e = getenv("GFW_JIT")) {                               // deployment / test override of GFW_OPT_JIT's default: 0, 1 or 2, anything else is ignored
+        char *end = nullptr; const long v = strtol(e, &end, 10);
+        if (end != e && *end == 0 && v >= 0 && v <= 2) c->jit_mode = (int)v;
+    }
     c->pixel_type = pixel_type; c->model = distortion_model; c->digital = digital_lens;
     c->src_len = buffers->input.len; c->dst_len = buffers->output.len;
     c->max_matrix_rows = ((params->flags & GFW_FLAG_HORIZONTAL_RS) ? params->width : params->height);   // opencl.rs:287
@@ -292,9 +296,10 @@ int gfw_set_option(gfw_ctx *c, int option, int64_t value) {
     case GFW_OPT_KERNEL_VARIANT: c->kernel_variant = (int)value; return GFW_OK;
     case GFW_OPT_PROFILE: c->profile = value != 0; return GFW_OK;
     case GFW_OPT_TUNE_ROWS: c->tune_rb = (int)value; return GFW_OK;
-    case GFW_OPT_TUNE_GRID: c->tune_grid = (int)value; c->jit_fn = nullptr; c->jit_key_valid = false; return GFW_OK;
+    case GFW_OPT_TUNE_GRID: c->tune_grid = (int)value; c->jit_fn = nullptr; c->jit_key_valid = false; c->jit_dead = false; return GFW_OK;
     case GFW_OPT_JIT: if (value < 0 || value > 2) { set_error("GFW_OPT_JIT %lld", (long long)value); return GFW_ERR_INVALID_ARGUMENT; }
-                      c->jit_mode = (int)value; c->jit_fn = nullptr; c->jit_key_valid = false; return GFW_OK;
+                      c->jit_mode = (int)value; c->jit_fn = nullptr; c->jit_key_valid = false; c->jit_dead = false;
+                      c->jit_info = GfwJitInfo{GFW_JIT_UNAVAILABLE, 0.0, std::string()}; return GFW_OK;
     default: set_error("unknown option %d", option); return GFW_ERR_INVALID_ARGUMENT;
     }
 }
@@ -896,9 +901,11 @@ static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps,
     if (same) {
         if (c->jit_seen < (1 << 30)) ++c->jit_seen;
         if (c->jit_fn) { *grid = c->jit_grid; return c->jit_fn; }                        // ready and loaded: nothing else to do
+        if (c->jit_dead) return nullptr;                                                 // decided: ahead of time for the rest of the clip, no lookup per frame
     } else {
         c->jit_key = K; memcpy(c->jit_key_misc, key_misc, sizeof(key_misc)); c->jit_key_valid = true;
-        c->jit_header = bake_header(Y); c->jit_seen = 1; c->jit_fn = nullptr;
+        c->jit_header = bake_header(Y); c->jit_seen = 1; c->jit_fn = nullptr; c->jit_dead = false;
+        c->jit_info = GfwJitInfo{GFW_JIT_UNAVAILABLE, 0.0, std::string()};
     }
     if (c->jit_mode == 1 && c->jit_seen < gfw_ctx::kJitAfter) return nullptr;          // one or two frames are not a clip
     const int waves = jit_waves(n0, Y.matrix_count, jit_model, Y.extras);
@@ -920,7 +927,7 @@ static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps,
         for (const char *p = extra; ; ++p) { if (*p == ';' || *p == 0) { if (!cur.empty()) defs.push_back(cur); cur.clear(); if (!*p) break; } else cur += *p; }
     }
     hipFunction_t fn = gfw_jit_get(c->device, c->arch, defs, c->jit_header, c->jit_mode == 2, &c->jit_info);
-    if (!fn) return nullptr;
+    if (!fn) { c->jit_dead = c->jit_info.state == GFW_JIT_FAILED || c->jit_info.state == GFW_JIT_UNAVAILABLE; return nullptr; }
     int g = c->tune_grid > 0 ? c->tune_grid : c->num_cus * waves;
     const int per_xcd = (Y.tiles_x * Y.tiles_y + 7) >> 3;
     if (g > per_xcd * 8) g = per_xcd * 8;
@@ -1084,9 +1091,13 @@ int gfw_undistort_clip(gfw_ctx *c, int n_frames, int nplanes, const gfw_buffers 
             continue;
         }
         const int rc = run_planes(c, nplanes, planes + (size_t)f * nplanes, params, pixel_types, matrices[f], matrix_count, nullptr, 0, &batch);
-        if (rc != GFW_OK) { (void)clip_flush(c, &batch); return rc; }
+        if (rc != GFW_OK) { (void)clip_flush(c, &batch); if (c->synchronous) (void)hipStreamSynchronize(c->stream); return rc; }
     }
-    return clip_flush(c, &batch);
+    const int frc = clip_flush(c, &batch);
+    // GFW_OPT_SYNCHRONOUS (the default) means what it means for gfw_undistort_frame: the outputs are complete when the call returns — a frame that
+    // joined a clip launch left run_planes before its own synchronisation point (round-3 advisor finding)
+    if (c->synchronous) { const hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess && frc == GFW_OK) { set_error("hipStreamSynchronize failed: %s", hipGetErrorString(e)); return GFW_ERR_HIP; } }
+    return frc;
 }
 
 }  // extern "C"

@@ -104,6 +104,28 @@ __device__ __forceinline__ float gfw_atanf_pos_tab(float x) {
     return gfw_atanf_tab_finish(gfw_div_lean(num, den), hl.x, hl.y);           // den in [1, 2^25.6], |num| <= 2^26: in range
 }
 
+// The record index without the five compares (round 4): for a positive float the reduction interval is a step function of the bit pattern, and
+// every threshold but the last is a multiple of 2^18 in it (0.4375 = 0x3ee00000, 0.6875 = 0x3f300000, 1.1875 = 0x3f980000, 2.4375 = 0x401c0000), so
+// key = clamp((bits >> 18) - 0xfb7, 0, 80) names the interval and an 81-byte LDS table turns it into the record's offset: three VALU
+// instructions and a byte read where the compare / select chain took ten and five VCC hazards.  x >= 2^25 (record 5) is NOT representable by
+// the key: callers keep such operands away (the branch-free row flags them as odd; rr < 2^50 there).
+#define GFW_ATAN_KEYS 81
+__device__ __forceinline__ unsigned char *gfw_atan_key_lds() { __shared__ unsigned char lut[GFW_ATAN_KEYS + 3]; return lut; }
+__device__ __forceinline__ void gfw_atan_key_lds_init(int tid) {                   // every thread of the workgroup, before the first use
+    if (tid < GFW_ATAN_KEYS) gfw_atan_key_lds()[tid] = (unsigned char)(gfw_atanf_tab_id(gfw_u2f((uint32_t)(tid + 0xfb7) << 18)) * 32);
+    __syncthreads();
+}
+__device__ __forceinline__ float gfw_atanf_pos_key(float x) {                      // finite x in [0, 2^25) (anything else: some record, garbage out, no fault)
+    int key = (int)(gfw_f2u(x) >> 18) - 0xfb7;
+    key = max(min(key, GFW_ATAN_KEYS - 1), 0);
+    const float *rec = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(gfw_atan_lds()) + gfw_atan_key_lds()[key]);
+    const float4 ab = *reinterpret_cast<const float4 *>(rec);
+    const float2 hl = *reinterpret_cast<const float2 *>(rec + 4);
+    const float pn = ab.x * x, pd = ab.z * x;
+    const float num = pn + ab.y, den = pd + ab.w;
+    return gfw_atanf_tab_finish(gfw_div_lean(num, den), hl.x, hl.y);
+}
+
 // RN(RN(x * mul) / den) for a constant (mul, den) pair: the reference's map_coord with in_min = out_min = 0,
 //   (x - 0) * (out_max - 0) / (in_max - 0) + 0            (util.rs:144-147)
 // evaluated with the precomputed RN(1/den).  The host validates (exhaustively over all 2^23 significands) that

@@ -72,10 +72,20 @@
                                  // and progress stays level.  0: off.  What it is worth depends on how long a wave lives: nothing on a lone 4K
                                  // frame at 6 waves (79.3 = 79.3 us), 4 us of 59 once a launch carries 8 frames at 8 waves per SIMD.
 #endif
+#ifndef GFW_PRIO_ROWS
+#define GFW_PRIO_ROWS 0          // 1: the priority is re-evaluated before every lane-row (round 3); 0: once per tile (4 rows) — the ~20 scalar instructions per row
+                                 // take issue slots like vector ones (tools/microbench_mix.hip)
+#endif
 #ifndef GFW_PRIO_SPAN
 #define GFW_PRIO_SPAN 6          // round 3, C2, 8 waves, 63 lane-rows per wave: fixed divisors 3 / 4 / 5 / 6 / 8 / 12 / 16 / 24 / 32 / 64 gave
                                  // 57.3 / 56.4 / 56.0 / 55.5 / 55.0 / 55.1 / 55.6 / 56.4 / 56.9 / 58.4 us; 1080p (18 rows per wave) wants 3, 8K
                                  // (253 rows) 16 or more: the step is a sixth of the wave's work (profiles/r03_ab_waves_priority.txt)
+#endif
+#ifndef GFW_FASTROW
+#define GFW_FASTROW 1            // the branch-free lane-row of phase 3 (rd_lean_nobranch + one `__any` / `__all` per stage); 0: the per-pixel divergent code only (A/B)
+#endif
+#ifndef GFW_FASTROW_JOINT
+#define GFW_FASTROW_JOINT 1      // a lane's two pixels through the projection side by side (one basic block, one small-angle vote) instead of one after the other
 #endif
 #ifndef GFW_BAKE
 #define GFW_BAKE 0               // 1: the clip-invariant arguments are the literals GFW_BK_<field> of the bake header in front of this file (read through AF())
@@ -268,6 +278,69 @@ __device__ __forceinline__ GfwPt rd(float px, float py, const float4 ma, const f
     // this kernel; any other value is routed to the per-plane kernel by the host.
     return o;
 }
+// The specialised fisheye projection WITHOUT a branch (round 4).  rd<>'s lean / generic split, the square root's tiny-operand case and the r == 0
+// case are each a divergent `if` in the pixel loop, i.e. s_and_saveexec / s_cbranch_execz / s_or exec scaffolding around code that practically
+// every lane runs: scalar instructions take the same issue slots as vector ones on MI355X (tools/microbench_mix.hip: one SALU per VALU doubles a
+// loop's time; an always-taken per-lane `if` costs ~9.5 SIMD-cycles), and the kernel carried 0.27 of them per VALU instruction.  Here every lane
+// evaluates the lean sequence — the very operations of rd<>'s lean branch, in its order — and reports in `rare` whether its operands were outside
+// what that sequence is proven for (the range test, rr < 2^-80 which includes the optical centre's r == 0, the r-limit); the caller asks the WAVE
+// once (`__any(rare)`: a uniform branch, no exec bookkeeping) and sends exactly those lanes through rd<> itself.  A rare lane's values here are
+// garbage by design (possibly NaN / inf) and are never used.
+template <int NP>
+__device__ __forceinline__ void rd_lean_nobranch(const float *px, const float *py, const float4 *ma, const float4 *mb, const float *m8, const Lens &L, const GfwYuvArgs &A,
+                                                 float *u, float *v, bool *rare) {
+    // the NP pixels of a lane side by side, stage by stage: one basic block, so the two dependency chains interleave (the VCC / packed-result hazards of
+    // one pixel are filled with the other's instructions instead of s_nop) and the arctangent's small-angle question is put to the wave once for all of them
+    float a[NP], b[NP], r[NP];
+    #pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const float X = (px[i] * ma[i].x) + (py[i] * ma[i].y) + ma[i].z;
+        const float Y = (px[i] * ma[i].w) + (py[i] * mb[i].x) + mb[i].y;
+        const float W = (px[i] * mb[i].z) + (py[i] * mb[i].w) + m8[i];
+        const float mag = fmaxf(fmaxf(fabsf(X), fabsf(Y)), W);
+        bool odd = !((mag <= 524288.0f) && (W >= 9.5367431640625e-07f));           // NaN operands fail the tests and are odd
+        if (L.rl2 > 0.0f) odd = odd | ((X * X + Y * Y) > L.rl2 * W);             // :139 — the side path answers "no point" with the reference's own test
+        LeanOps::div2(X, Y, W, a[i], b[i]);
+        rare[i] = odd;
+    }
+    if (!(AF(k_all_zero) != 0)) {
+        bool small = true;
+        #pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const float rr = a[i] * a[i] + b[i] * b[i];
+            // rr in [2^-80, 2^50): below, the generic sqrt and the optical centre's s = 1; above, atanf's r >= 2^25 record — one unsigned range test on the bit pattern (NaN fails it)
+            rare[i] = rare[i] | !((gfw_f2u(rr) - 0x17800000u) < (0x58800000u - 0x17800000u));
+            r[i] = gfw_sqrt_lean(rr);
+            small = small & (r[i] < 0.4375f);
+        }
+        float t[NP];
+        if (__all(small)) {
+            const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+                        aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+                        aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+            #pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const float x = r[i], z = x * x, w = z * z;
+                const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+                const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+                t[i] = x - x * (s1 + s2);
+            }
+        } else {
+            #pragma unroll
+            for (int i = 0; i < NP; ++i) t[i] = gfw_atanf_pos_key(r[i]);
+        }
+        #pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const float t2 = t[i] * t[i], t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+            const float td = t[i] * (1.0f + L.k0 * t2 + L.k1 * t4 + L.k2 * t6 + L.k3 * t8);
+            const float s = LeanOps::div(td, r[i]);
+            a[i] = a[i] * s; b[i] = b[i] * s;
+        }
+    }
+    #pragma unroll
+    for (int i = 0; i < NP; ++i) { u[i] = a[i] * L.f0 + L.c0; v[i] = b[i] * L.f1 + L.c1; }
+}
+
 template <int MODEL>
 __device__ __forceinline__ GfwPt rd_row(float px, float py, int idx, const float *matrices, const Lens &L, const GfwYuvArgs &A) {
     const float *m = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(matrices) + (uint32_t)idx * (uint32_t)(GFW_MAT_STRIDE * sizeof(float)));   // idx >= 0
@@ -556,8 +629,7 @@ __device__ __forceinline__ uint32_t hot_blend(uint32_t i0, uint32_t i1, uint32_t
 
 // ---- bilinear specialisation (I = 2): named weights, two-compare interior test — the hot configuration ---------------------------------------------------
 struct Bins2 { int sx, sy; float cx0, cx1, cy0, cy1; uint32_t kx, ky; };
-__device__ __forceinline__ Bins2 make_bins2(float u, float v) {
-    const int sx0 = round_i32(u * 32.0f), sy0 = round_i32(v * 32.0f);
+__device__ __forceinline__ Bins2 bins2_of(int sx0, int sy0) {             // from the two rounded 1/32-pixel coordinates
     Bins2 b;
     b.sx = sx0 >> 5; b.sy = sy0 >> 5;
     b.kx = (uint32_t)sx0 & 31u; b.ky = (uint32_t)sy0 & 31u;
@@ -565,6 +637,7 @@ __device__ __forceinline__ Bins2 make_bins2(float u, float v) {
     b.cy1 = (float)(sy0 & 31) * 0.03125f; b.cy0 = 1.0f - b.cy1;
     return b;
 }
+__device__ __forceinline__ Bins2 make_bins2(float u, float v) { return bins2_of(round_i32(u * 32.0f), round_i32(v * 32.0f)); }
 // Taps that straddle the source rect: out-of-rect taps read `bg`, out-of-rect rows contribute bg*cy
 // (cpu_undistort.rs:392-409), in the reference's exact operation order.
 template <typename T, int N>
@@ -621,13 +694,13 @@ __device__ __forceinline__ bool range_ok(unsigned long long *aud, int64_t off, i
     return false;
 }
 template <typename T, int N>
-__device__ __forceinline__ void sample_store2(float u, float v, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy,
-                                              unsigned long long *aud = nullptr) {
+__device__ __forceinline__ void sample_store2_bins(int bx, int by, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy,
+                                                   unsigned long long *aud = nullptr) {
     float out[N];
     #pragma unroll
     for (int c = 0; c < N; ++c) out[c] = bg[c];
     if (ok) {
-        const Bins2 b = make_bins2(u, v);
+        const Bins2 b = bins2_of(bx, by);
         if (__builtin_expect((unsigned)b.sx < (unsigned)(P.w - 1) && (unsigned)b.sy < (unsigned)(P.h - 1), 1)) {
             const int off0 = row_off(b.sy, P.src_stride) + b.sx * (int)(N * sizeof(T));
             if (range_ok(aud, off0, 2 * N * sizeof(T), P.src_len) && range_ok(aud, (int64_t)off0 + P.src_stride, 2 * N * sizeof(T), P.src_len)) {
@@ -660,6 +733,11 @@ __device__ __forceinline__ void sample_store2(float u, float v, bool ok, const G
     }
     const int doff = row_off(oy, P.dst_stride) + ox * (int)(N * sizeof(T));
     if (range_ok(aud, doff, N * sizeof(T), P.dst_len)) store_px<T, N>(P.dst, doff, out, px_needs_sat<T>(bg, N, limit));
+}
+template <typename T, int N>
+__device__ __forceinline__ void sample_store2(float u, float v, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy,
+                                              unsigned long long *aud = nullptr) {
+    sample_store2_bins<T, N>(round_i32(u * 32.0f), round_i32(v * 32.0f), ok, P, bg, limit, ox, oy, aud);       // (garbage bins of a point that is not ok are never used)
 }
 // Planar planes of identical geometry (U and V; or G,B,R,A of a planar float frame): one set of bins / weights /
 // offsets, one gather pair per plane.
@@ -745,6 +823,40 @@ __device__ __forceinline__ void sample_store_uv2(float u, float v, bool ok, cons
     if (!range_ok(aud, doff, sizeof(T), PU.dst_len < PV.dst_len ? PU.dst_len : PV.dst_len)) return;
     store_px<T, 1>(PU.dst, doff, &ou, px_needs_sat<T>(&bg_u, 1, lim_u));
     store_px<T, 1>(PV.dst, doff, &ov, px_needs_sat<T>(&bg_v, 1, lim_v));
+}
+
+// ---- branch-free sampling of a lane-row whose every tap is inside (round 4) -------------------------------------------------
+// The phase-3 loop asks the wave once whether all its samples of a row are interior (`__all`, a uniform branch) and then runs these: no `ok` /
+// inside / edge tests and no exec bookkeeping — the same loads, weights and operations as the interior branches of sample_store2 /
+// sample_store_uv2.  Waves that touch the frame border, background or an invalid point take those functions as before.
+__device__ __forceinline__ bool bins2_inside(const Bins2 &b, int w, int h) { return (unsigned)b.sx < (unsigned)(w - 1) && (unsigned)b.sy < (unsigned)(h - 1); }
+// the value of one interior sample of a single-channel plane, converted like `as u8 / u16` (integer types) or as its f32 bit pattern
+template <typename T>
+__device__ __forceinline__ uint32_t inside_value1(const uint8_t *src, int stride, const Bins2 &b, const float *bg, float limit) {
+    const int off0 = row_off(b.sy, stride) + b.sx * (int)sizeof(T);
+    if constexpr (!is_f32<T>::value && sizeof(T) == 1) {
+        typedef HotTap<T, false> Tap;
+        const uint32_t r0 = Tap::load(src, (uint32_t)off0), r1 = Tap::load(src, (uint32_t)off0 + (uint32_t)stride);
+        const uint32_t w = Tap::wpack(b.kx);
+        return hot_blend(Tap::dot(r0, w), Tap::dot(r1, w), b.ky, limit);
+    } else {
+        float o;
+        taps_inside2<T, 1>(src, off0, stride, b, limit, &o);
+        if constexpr (is_f32<T>::value) return gfw_f2u(o);
+        else return px_needs_sat<T>(bg, 1, limit) ? gfw_f2u_sat(o, 65535.0f) : gfw_f2u_trunc(o);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store_value1(uint8_t *dst, int off, uint32_t v) {
+    if constexpr (is_f32<T>::value) *reinterpret_cast<uint32_t *>(dst + (uint32_t)off) = v;
+    else *reinterpret_cast<T *>(dst + (uint32_t)off) = (T)v;
+}
+// two horizontally adjacent samples of an integer plane leave as ONE store (the pair's address need not be aligned to the pair: global memory takes it)
+template <typename T>
+__device__ __forceinline__ void store_pair1(uint8_t *dst, int off, uint32_t v0, uint32_t v1) {
+    if constexpr (sizeof(T) == 1) { typedef uint16_t u16u __attribute__((aligned(1))); *reinterpret_cast<u16u *>(dst + (uint32_t)off) = (uint16_t)(v0 | (v1 << 8)); }
+    else if constexpr (sizeof(T) == 2) { typedef uint32_t u32u __attribute__((aligned(2))); *reinterpret_cast<u32u *>(dst + (uint32_t)off) = v0 | (v1 << 16); }
+    else { typedef uint2 u2u __attribute__((aligned(4))); *reinterpret_cast<u2u *>(dst + (uint32_t)off) = uint2{v0, v1}; }
 }
 
 // ---- background mode 3 ("margin with feather", cpu_undistort.rs:576-613) ----------------------------------------------------
@@ -897,11 +1009,10 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     constexpr bool INF_COORDS = MODEL != GFW_MODEL_OPENCV_FISHEYE || GFW_BAKED_DIGITAL;
     __shared__ float q_x[FAST1 ? 4 : 1][FAST1 ? QCAP : 1], q_y[FAST1 ? 4 : 1][FAST1 ? QCAP : 1];
     __shared__ unsigned short q_dst[FAST1 ? 4 : 1][FAST1 ? QCAP : 1];           // (owner lane << 6) | slot in s_rows
-    __shared__ unsigned q_n[4];
     __shared__ unsigned short s_rows[RB * NPX][256];                             // phase-1 rows (< 65536: the host keeps larger frames off this path), one column per lane
     __shared__ float s_lut[I == 2 ? 1 : 448];                                    // bicubic / Lanczos4 tap table
     const int wave = threadIdx.y, lane = threadIdx.x, tid = wave * 64 + lane;
-    if (MODEL == GFW_MODEL_OPENCV_FISHEYE) gfw_atan_lds_init(tid);
+    if (MODEL == GFW_MODEL_OPENCV_FISHEYE) { gfw_atan_lds_init(tid); gfw_atan_key_lds_init(tid); }
     if (I != 2) {
         for (int i = tid; i < 448; i += 256) s_lut[i] = GFW_COEFFS[i];
         __syncthreads();
@@ -1001,26 +1112,24 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
 #endif
         // ---- phase 2 (inside phase 1): the wave resolves its queued pixels exactly, densely packed.  Flushed after the last row, or
         // earlier when the pixels up to the next look (<= 64*QSTEP new entries) could overflow the queue.
+        // The queue's length lives in a scalar register (round 4): the lanes that failed their certificate are counted with one wave ballot and take
+        // consecutive slots by their rank in it (v_mbcnt) — no LDS atomic with return, no read-back of the length, and the whole enqueue sits behind a
+        // uniform branch that the usual pixel (every lane certified) skips.
+        unsigned n_q = 0;
         auto flush_queue = [&](bool last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const unsigned qn = q_n[wave];
-            if (last || qn + 64u * QSTEP > (unsigned)QCAP) {
-                for (unsigned e = lane; e < qn; e += 64) {
+            if (last || n_q + 64u * QSTEP > (unsigned)QCAP) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // the entries the other lanes wrote
+                for (unsigned e = lane; e < n_q; e += 64) {
                     const int sy = pass1_exact<MODEL>(q_x[wave][e], q_y[wave][e], M, matrices, L, A);
                     const unsigned d = q_dst[wave][e];
                     s_rows[d & 63u][wave * 64 + (d >> 6)] = (unsigned short)sy;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (lane == 0) q_n[wave] = 0;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                n_q = 0;
             }
         };
         // ---- phase 1: rolling-shutter row of every luma pixel of this lane ----------------------------
         if (two_pass) {
-            if (FAST1) {
-                if (lane == 0) q_n[wave] = 0;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            }
             #pragma unroll 1
             for (int r = 0; r < RB; ++r) {
               {
@@ -1028,29 +1137,36 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                 for (int k = 0; k < NPX; ++k) {
                     const int i = k % DW, j = k / DW;
                     const int lx = cx * DW + i, ly = (cy0 + r) * DH + j;
+                    const bool live = WHOLE || (lane_ok && lx < AF(out_w) && ly < AF(out_h));
                     int sy = 0;
-                    if (WHOLE || (lane_ok && lx < AF(out_w) && ly < AF(out_h))) {
-                        float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
-                        if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (AF(extras) & 8)) gfw_lens_correction_blend<(MODEL == GFW_MODEL_GENERIC_EXTRA ? -1 : MODEL)>(ox, oy, A.kp, A.common, AF(model), GFW_CLIP_DIGITAL);   // :429-460
-                        if (FAST1) {
-                            float v_fast;
-                            const float ax = __builtin_fmaf(ox, M.m0, M.m2), ay = __builtin_fmaf(ox, M.m3, M.m5), aw = __builtin_fmaf(ox, M.m6, M.m8);
-                            if (!pass1_fast(ax, ay, aw, oy, M, Q, A.p1_table, hrs, L.rl2, sy, v_fast, AUDIT ? AF(audit) : nullptr)) {
-                                const unsigned slot = atomicAdd(&q_n[wave], 1u);      // < QCAP: flushed below before it can fill
+                    if (FAST1) {
+                        // every lane evaluates (a dead lane's coordinates are as good as any): the ballot below is in uniform control flow
+                        const float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
+                        float v_fast;
+                        const float ax = __builtin_fmaf(ox, M.m0, M.m2), ay = __builtin_fmaf(ox, M.m3, M.m5), aw = __builtin_fmaf(ox, M.m6, M.m8);
+                        const bool good = pass1_fast(ax, ay, aw, oy, M, Q, A.p1_table, hrs, L.rl2, sy, v_fast, AUDIT ? AF(audit) : nullptr) | !live;
+                        const unsigned long long undecided = __ballot(!good);
+                        if (undecided) {
+                            if (!good) {
+                                const unsigned slot = n_q + __builtin_amdgcn_mbcnt_hi((unsigned)(undecided >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)undecided, 0u));   // < QCAP: flushed before it can fill
                                 q_x[wave][slot] = ox; q_y[wave][slot] = oy;
                                 q_dst[wave][slot] = (unsigned short)((lane << 6) | (r * NPX + k));
                                 if (AUDIT) atomicAdd(&AF(audit)[2], 1ull);
-                            } else if (AUDIT) {                                       // audit: every certificate is checked
-                                atomicAdd(&AF(audit)[0], 1ull);
-                                if (pass1_exact<MODEL>(ox, oy, M, matrices, L, A) != sy) atomicAdd(&AF(audit)[1], 1ull);
-                                const GfwPt ex = rd<MODEL>(ox, oy, float4{M.m0, M.m1, M.m2, M.m3}, float4{M.m4, M.m5, M.m6, M.m7}, M.m8, matrices + (size_t)(AF(matrix_count) / 2) * GFW_MAT_STRIDE + 8, L, A);
-                                if (ex.ok) atomicMax(&AF(audit)[4], (unsigned long long)gfw_f2u(fabsf((hrs ? ex.x : ex.y) - v_fast)));
                             }
-                        } else {
-                            sy = pass1_exact<MODEL>(ox, oy, M, matrices, L, A);
+                            n_q += (unsigned)__popcll(undecided);
                         }
+                        if (AUDIT && good && live) {                                  // audit: every certificate is checked
+                            atomicAdd(&AF(audit)[0], 1ull);
+                            if (pass1_exact<MODEL>(ox, oy, M, matrices, L, A) != sy) atomicAdd(&AF(audit)[1], 1ull);
+                            const GfwPt ex = rd<MODEL>(ox, oy, float4{M.m0, M.m1, M.m2, M.m3}, float4{M.m4, M.m5, M.m6, M.m7}, M.m8, matrices + (size_t)(AF(matrix_count) / 2) * GFW_MAT_STRIDE + 8, L, A);
+                            if (ex.ok) atomicMax(&AF(audit)[4], (unsigned long long)gfw_f2u(fabsf((hrs ? ex.x : ex.y) - v_fast)));
+                        }
+                    } else if (live) {
+                        float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
+                        if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (AF(extras) & 8)) gfw_lens_correction_blend<(MODEL == GFW_MODEL_GENERIC_EXTRA ? -1 : MODEL)>(ox, oy, A.kp, A.common, AF(model), GFW_CLIP_DIGITAL);   // :429-460
+                        sy = pass1_exact<MODEL>(ox, oy, M, matrices, L, A);
                     }
-                    s_rows[r * NPX + k][tid] = (unsigned short)sy;
+                    s_rows[r * NPX + k][tid] = (unsigned short)(live ? sy : 0);
                     if (FAST1 && NPX > QSTEP && (k % QSTEP) == QSTEP - 1 && k != NPX - 1) flush_queue(false);      // 4:2:0: a look at the queue per pixel pair
                 }
               }
@@ -1065,12 +1181,90 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         if (lane_ok) {
             #pragma unroll 1
             for (int r = 0; r < RB; ++r) {
-#if GFW_PRIO_MODE == 1
+#if GFW_PRIO_MODE == 1 && GFW_PRIO_ROWS
                 set_prio((tiles_left * RB) - r);
 #endif
                 const int cy = cy0 + r;
                 if (!WHOLE && cy >= AF(ch)) break;
                 float u0 = 0.0f, v0 = 0.0f, lu0 = 0.0f, lv0 = 0.0f; bool ok0 = false;
+                // The branch-free row (round 4; specialised fisheye, bilinear, single-channel luma): a lane's DW pixels of one line are projected with
+                // rd_lean_nobranch, mapped and binned without a divergent branch; the wave is asked ONCE per stage — `__any(rare)` sends the odd lanes
+                // through rd<> itself, `__all(interior)` picks between the branch-free taps (pair stored as one word) and sample_store2.
+                constexpr bool FASTROW = GFW_FASTROW && MODEL == GFW_MODEL_OPENCV_FISHEYE && I == 2 && N0 == 1 && !AUDIT && !GFW_BAKED_DIGITAL;
+                if (FASTROW && !AF(ablate)) {
+                    #pragma unroll (NPX <= 2 ? DH : 1)
+                    for (int j = 0; j < DH; ++j) {
+                        const int ly = cy * DH + j;
+                        float pu[DW], pv[DW]; bool okp[DW], odd[DW]; bool any_odd = false;
+                        {
+                            float ox[DW], oy[DW], m8[DW]; float4 ma[DW], mb[DW];
+                            #pragma unroll
+                            for (int i = 0; i < DW; ++i) {
+                                const int lx = cx * DW + i;
+                                ox[i] = (float)lx + L.t2x; oy[i] = (float)ly + L.t2y;
+                                const int sy = two_pass ? s_rows[r * NPX + j * DW + i][tid] : default_row<MODEL>(ox[i], oy[i], A);
+                                const int row = min(sy, AF(matrix_count) - 1);
+                                const float *m = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(matrices) + (uint32_t)row * (uint32_t)(GFW_MAT_STRIDE * sizeof(float)));
+                                ma[i] = *reinterpret_cast<const float4 *>(m); mb[i] = *reinterpret_cast<const float4 *>(m + 4); m8[i] = m[8];
+                            }
+#if GFW_FASTROW_JOINT
+                            rd_lean_nobranch<DW>(ox, oy, ma, mb, m8, L, A, pu, pv, odd);
+#else
+                            #pragma unroll
+                            for (int i = 0; i < DW; ++i) rd_lean_nobranch<1>(ox + i, oy + i, ma + i, mb + i, m8 + i, L, A, pu + i, pv + i, odd + i);
+#endif
+                            #pragma unroll
+                            for (int i = 0; i < DW; ++i) { okp[i] = true; any_odd = any_odd | odd[i]; }
+                        }
+                        if (__builtin_expect(__any(any_odd), 0)) {
+                            #pragma unroll
+                            for (int i = 0; i < DW; ++i) if (odd[i]) {
+                                const int lx = cx * DW + i;
+                                const float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
+                                const int sy = two_pass ? s_rows[r * NPX + j * DW + i][tid] : default_row<MODEL>(ox, oy, A);
+                                const GfwPt p = rd_row<MODEL>(ox, oy, min(sy, AF(matrix_count) - 1), matrices, L, A);
+                                pu[i] = p.x; pv[i] = p.y; okp[i] = p.ok;
+                            }
+                        }
+                        int bx[DW], by[DW]; bool interior = true;      // (bx, by) = round(32 u), round(32 v): all a sample's bins and weights derive from them
+                        #pragma unroll
+                        for (int i = 0; i < DW; ++i) {
+                            const int lx = cx * DW + i;
+                            if (AF(background_mode) == 1) {                               // cpu_undistort.rs:495-509 (edge repeat / edge mirror), as below
+                                const float width_f = (float)AF(width), height_f = (float)AF(height);
+                                pu[i] = fminf(fmaxf(pu[i], 3.0f), width_f - 3.0f);
+                                pv[i] = fminf(fmaxf(pv[i], 3.0f), height_f - 3.0f);
+                            } else if (AF(background_mode) == 2) {
+                                const float width_f = (float)AF(width), height_f = (float)AF(height);
+                                const float rx = roundf(pu[i]), ry = roundf(pv[i]);
+                                const float width3 = width_f - 3.0f, height3 = height_f - 3.0f;
+                                if (rx > width3)  pu[i] = width3  - (rx - width3);
+                                if (rx < 3.0f)    pu[i] = 3.0f + width_f - (width3  + rx);
+                                if (ry > height3) pv[i] = height3 - (ry - height3);
+                                if (ry < 3.0f)    pv[i] = 3.0f + height_f - (height3 + ry);
+                            }
+                            const float lu = map_c<INF_COORDS>(pu[i], MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c<INF_COORDS>(pv[i], MP.mul_ly, MP.den_y, MP.rcp_y);   // :511-514
+                            if (j == 0 && i == 0) { u0 = pu[0]; v0 = pv[0]; ok0 = okp[0]; lu0 = lu; lv0 = lv; }
+                            bx[i] = round_i32(lu * 32.0f); by[i] = round_i32(lv * 32.0f);
+                            const bool live = WHOLE || (lx < AF(out_w) && ly < AF(out_h));
+                            interior = interior & (okp[i] & live & ((unsigned)(bx[i] >> 5) < (unsigned)(PL0.w - 1)) & ((unsigned)(by[i] >> 5) < (unsigned)(PL0.h - 1)));
+                        }
+                        if (__builtin_expect(__all(interior), 1)) {
+                            uint32_t val[DW];
+                            #pragma unroll
+                            for (int i = 0; i < DW; ++i) val[i] = inside_value1<T>(PL0.src, PL0.src_stride, bins2_of(bx[i], by[i]), bg_y, lim_y);
+                            const int doff = row_off(ly, PL0.dst_stride) + (cx * DW) * (int)sizeof(T);
+                            if constexpr (DW == 2) store_pair1<T>(PL0.dst, doff, val[0], val[1]);
+                            else store_value1<T>(PL0.dst, doff, val[0]);
+                        } else {
+                            #pragma unroll
+                            for (int i = 0; i < DW; ++i) {
+                                const int lx = cx * DW + i;
+                                if (WHOLE || (lx < AF(out_w) && ly < AF(out_h))) sample_store2_bins<T, N0>(bx[i], by[i], okp[i], PL0, bg_y, lim_y, lx, ly, nullptr);
+                            }
+                        }
+                    }
+                } else {
                 #pragma unroll (NPX <= 2 ? NPX : 1)
                 for (int k = 0; k < NPX; ++k) {
                     const int i = k % DW, j = k / DW;
@@ -1111,6 +1305,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     if (I == 2) sample_store2<T, N0>(lu, lv, p.ok, PL0, bg_y, lim_y, lx, ly, AUDIT ? AF(audit) : nullptr);
                     else sample_store<T, N0, I>(lu, lv, p.ok, PL0, bg_y, lim_y, lx, ly, s_lut);
                 }
+                }
                 if (MODEL == GFW_MODEL_GENERIC_EXTRA && (AF(extras) & 16) && ok0 && AF(nplanes) > 1) {  // background mode 3 for the chroma site
                     const Feather f = feather_of(u0, v0, A);
                     if (INTERLEAVED_UV) feather_store<T, 2, I, true>(u0, v0, f, PL1, bg_c, lim_u, MP.mul_cx, MP.mul_cy, MP, cx, cy, s_lut);
@@ -1131,7 +1326,38 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                         cu = map_c<INF_COORDS>(u0, MP.mul_cx, MP.den_x, MP.rcp_x);
                         cv = map_c<INF_COORDS>(v0, MP.mul_cy, MP.den_y, MP.rcp_y);
                     }
-                    if (I == 2) {
+                    bool chroma_done = false;
+                    if constexpr (FASTROW && !is_f32<T>::value) if (!AF(ablate) && (INTERLEAVED_UV || AF(nplanes) == 3)) {
+                        // the chroma site the same way: one question to the wave, then the branch-free interior taps of both chroma samples
+                        const Bins2 bc = make_bins2(cu, cv);
+                        if (__builtin_expect(__all(ok0 & bins2_inside(bc, PL1.w, PL1.h)), 1)) {
+                            if constexpr (INTERLEAVED_UV) {
+                                const int off0 = row_off(bc.sy, PL1.src_stride) + bc.sx * (int)(2 * sizeof(T));
+                                const int doff = row_off(cy, PL1.dst_stride) + cx * (int)(2 * sizeof(T));
+                                if constexpr (sizeof(T) == 1) {
+                                    typedef HotTap<T, true> Tap;
+                                    const auto r0 = Tap::load(PL1.src, (uint32_t)off0), r1 = Tap::load(PL1.src, (uint32_t)off0 + (uint32_t)PL1.src_stride);
+                                    const uint32_t w = Tap::wpack(bc.kx);
+                                    uint32_t ua, va, ub, vb;
+                                    Tap::dot(r0, w, ua, va); Tap::dot(r1, w, ub, vb);
+                                    store_pair1<T>(PL1.dst, doff, hot_blend(ua, ub, bc.ky, lim_u), hot_blend(va, vb, bc.ky, lim_u));
+                                } else {
+                                    float o[2];
+                                    taps_inside2<T, 2>(PL1.src, off0, PL1.src_stride, bc, lim_u, o);
+                                    const bool sat = px_needs_sat<T>(bg_c, 2, lim_u);
+                                    store_pair1<T>(PL1.dst, doff, sat ? gfw_f2u_sat(o[0], 65535.0f) : gfw_f2u_trunc(o[0]), sat ? gfw_f2u_sat(o[1], 65535.0f) : gfw_f2u_trunc(o[1]));
+                                }
+                            } else {
+                                const uint32_t vu = inside_value1<T>(PL1.src, PL1.src_stride, bc, &bg_c[0], lim_u);
+                                const uint32_t vv = inside_value1<T>(PL2.src, PL1.src_stride, bc, &bg_v, lim_v);
+                                const int doff = row_off(cy, PL1.dst_stride) + cx * (int)sizeof(T);
+                                store_value1<T>(PL1.dst, doff, vu); store_value1<T>(PL2.dst, doff, vv);
+                            }
+                            chroma_done = true;
+                        }
+                    }
+                    if (chroma_done) {}
+                    else if (I == 2) {
                         if (INTERLEAVED_UV) sample_store2<T, 2>(cu, cv, ok0, PL1, bg_c, lim_u, cx, cy, AUDIT ? AF(audit) : nullptr);
                         else if (AF(nplanes) == 3) sample_store_uv2<T>(cu, cv, ok0, PL1, PL2, bg_c[0], bg_v, lim_u, lim_v, cx, cy, AUDIT ? AF(audit) : nullptr);
                         else if (GFW_BAKE) sample_store_shared2_refs<T>(cu, cv, ok0, PL1, PL2, PL3, AF(nplanes) - 1, cx, cy);

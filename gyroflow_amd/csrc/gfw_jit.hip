@@ -52,7 +52,21 @@ struct Rtc {
         ok = create && compile && log_size && log && code_size && code && destroy;
     }
 };
-Rtc &rtc() { static Rtc r; return r; }
+void join_all_workers();
+// The worker threads run inside hiprtc / comgr / LLVM.  Those libraries were dlopen'ed AFTER libgfwarp's own statics were constructed, so at process exit
+// their globals are torn down BEFORE g_cache's destructor would join a still-running build (round-3 advisor finding: any context starts a ~0.3-1 s build
+// after three frames, and gfw_destroy does not wait for it).  This hook is registered right after the dlopen — later than hiprtc's own exit handlers, so it
+// runs before them — and joins every build in flight.
+Rtc &rtc() {
+    static Rtc r;
+    static const bool hooked = (r.ok ? (void)atexit(join_all_workers) : (void)0, true);
+    (void)hooked;
+    return r;
+}
+// -fno-slp-vectorize: LLVM's SLP pass packs scalar f32 operations into v_pk_* forms fed by register shuffles; with the branch-free lane-row the same kernel
+// runs 53.5 us per C2 frame with it and 46.2 without (profiles/r04_ab_fastrow.txt; packed ops issue in 4.7 cycles against 2 x 2.5, tools/microbench_mix.hip).
+// A "-fslp-vectorize" entry of GFW_JIT_DEFS comes later on the command line and wins.
+#define GFW_JIT_NO_SLP "-fno-slp-vectorize"
 
 enum { ST_COMPILING = 1, ST_COMPILED = 2, ST_LOADED = 3, ST_FAILED = -1 };
 
@@ -66,14 +80,22 @@ struct Entry {
     std::string log;
     double compile_ms = 0.0;
     std::thread worker;
+    std::mutex join_mu;                    // one joiner at a time; never held together with g_mu by a thread that waits for the build
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
-    ~Entry() { if (worker.joinable()) worker.join(); }
+    void join() { std::lock_guard<std::mutex> lk(join_mu); if (worker.joinable()) worker.join(); }
+    ~Entry() { join(); }
 };
 
 std::mutex g_mu;
 std::map<std::string, std::shared_ptr<Entry>> g_cache;       // key: device | arch | options | bake header
 constexpr size_t kMaxEntries = 256;
+
+void join_all_workers() {
+    std::vector<std::shared_ptr<Entry>> all;
+    { std::lock_guard<std::mutex> lk(g_mu); for (auto &kv : g_cache) all.push_back(kv.second); }
+    for (auto &e : all) e->join();
+}
 
 void compile_entry(Entry *e, std::string source, std::vector<std::string> opts) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -118,7 +140,7 @@ hipFunction_t gfw_jit_get(int device, const std::string &arch, const std::vector
             // any of them may be in flight); later clips run ahead of time
             if (g_cache.size() >= kMaxEntries) { if (info) { info->state = GFW_JIT_UNAVAILABLE; info->log = "specialisation cache full"; } return nullptr; }
             e = std::make_shared<Entry>();
-            std::vector<std::string> opts = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed",
+            std::vector<std::string> opts = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-ffp-contract=off", GFW_JIT_NO_SLP, "-Wno-pass-failed",
                                              "-Wno-cuda-compat", "-DGFW_JIT=1", "-DGFW_BAKE=1"};
             for (const std::string &d : defines) opts.push_back(jit_option(d));
             std::string source = bake_header + "\n" + GFW_JIT_SOURCE;
@@ -126,15 +148,12 @@ hipFunction_t gfw_jit_get(int device, const std::string &arch, const std::vector
             g_cache.emplace(key, e);
         } else e = it->second;
     }
-    if (wait && e->state.load(std::memory_order_acquire) == ST_COMPILING) {
-        std::lock_guard<std::mutex> lk(g_mu);            // one joiner
-        if (e->worker.joinable()) e->worker.join();
-    }
+    if (wait && e->state.load(std::memory_order_acquire) == ST_COMPILING) e->join();      // outside g_mu: other contexts keep polling their own entries meanwhile
     int st = e->state.load(std::memory_order_acquire);
     if (st == ST_COMPILED) {
         std::lock_guard<std::mutex> lk(g_mu);
         if (e->state.load() == ST_COMPILED) {
-            if (e->worker.joinable()) e->worker.join();
+            e->join();                                   // the worker has published its result: returns at once
             hipError_t err = hipModuleLoadData(&e->mod, e->code.data());
             if (err == hipSuccess) err = hipModuleGetFunction(&e->fn, e->mod, "gfw_jit_kernel");
             if (err != hipSuccess) { e->log += std::string("\nmodule load: ") + hipGetErrorString(err); e->state.store(ST_FAILED); }
@@ -144,7 +163,7 @@ hipFunction_t gfw_jit_get(int device, const std::string &arch, const std::vector
     }
     if (info) {
         info->state = st == ST_LOADED ? GFW_JIT_READY : st == ST_FAILED ? GFW_JIT_FAILED : GFW_JIT_COMPILING;
-        if (st != ST_COMPILING) { info->compile_ms = e->compile_ms; info->log = e->log; }
+        if (st != ST_COMPILING) { std::lock_guard<std::mutex> lk(g_mu); info->compile_ms = e->compile_ms; info->log = e->log; }      // (a module-load error is appended under g_mu)
     }
     return st == ST_LOADED ? e->fn : nullptr;
 }
@@ -155,7 +174,7 @@ long gfw_jit_compile_only(const std::string &arch, const std::vector<std::string
                           std::vector<char> *code_out) {
     if (!rtc().ok) { log = "libhiprtc.so not found"; return -2; }
     Entry e;
-    std::vector<std::string> opts = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed", "-Wno-cuda-compat",
+    std::vector<std::string> opts = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-ffp-contract=off", GFW_JIT_NO_SLP, "-Wno-pass-failed", "-Wno-cuda-compat",
                                      "-DGFW_JIT=1", "-DGFW_BAKE=1"};
     for (const std::string &d : defines) opts.push_back(jit_option(d));
     compile_entry(&e, bake_header + "\n" + GFW_JIT_SOURCE, opts);

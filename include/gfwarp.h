@@ -302,7 +302,7 @@ int   gfw_jit_status(gfw_ctx *ctx, double *compile_ms, char *log, size_t cap);
 /* With GFW_OPT_PROFILE on: accumulated warp-kernel time (ms, hipEventElapsedTime on the context stream)
  * and launch count since the last reset; synchronises the stream.  reset != 0 clears the accumulators. */
 int   gfw_get_profile(gfw_ctx *ctx, double *kernel_ms, int64_t *launches, int reset);
-/* the same, plus the number of frames the bracketed launches covered (a gfw_undistort_clip launch carries up to 8) */
+/* the same, plus the number of frames the bracketed launches covered (a gfw_undistort_clip launch carries up to GFW_CLIP_FRAMES_MAX) */
 int   gfw_get_profile_frames(gfw_ctx *ctx, double *kernel_ms, int64_t *launches, int64_t *frames, int reset);
 
 /* Thread-local, human-readable description of the last failure. */

@@ -63,6 +63,14 @@ void emu_wave_sync(int site);                 // a wavefront-scope fence: in har
 #define __any(p) ((p) ? 1 : 0)
 #endif
 
+// A ballot is a real wave operation (the first pass ranks its undecided lanes with it: every lane must see the SAME mask): the wave's live lanes
+// rendezvous, the mask is assembled from all of them, they rendezvous again (emu_fibers.inc).  Ballots therefore sit in uniform control flow.
+unsigned long long emu_ballot(int pred, int site);
+#define __ballot(p) emu_ballot((p) ? 1 : 0, __LINE__)
+#define __popcll(x) __builtin_popcountll(x)
+static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned m, unsigned base) { const unsigned l = threadIdx.x; return base + (unsigned)__builtin_popcount(l >= 32 ? m : (m & ((1u << l) - 1u))); }
+static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned m, unsigned base) { const unsigned l = threadIdx.x; return base + (l <= 32 ? 0u : (unsigned)__builtin_popcount(m & ((1u << (l - 32)) - 1u))); }
+
 // A lane reaching an atomic waits until every other live lane of its wave has run as far as it can (to its own atomic, or to a fence): in
 // hardware the wave executes the instructions BEFORE the atomic in lockstep, so no lane may see its effect earlier (the first pass reads the
 // queue length right after a fence, then lanes push new entries).

@@ -110,14 +110,14 @@ def test_420_specialisation_keeps_eight_workgroups_per_cu(tmp_path):
 
 
 def test_a_compiler_option_travels_through_the_definition_list(tmp_path):
-    """An entry of the definition list (GFW_JIT_DEFS at run time) that starts with '-' is a compiler option: `-fno-slp-vectorize` must reach hiprtc — the
-    build then holds no packed-f32 instruction (the default build packs ~150 multiplies / adds, each half rate and fed by register shuffles: the first
-    thing the next round measures, profiles/r03_slp_static.txt)."""
+    """An entry of the definition list (GFW_JIT_DEFS at run time) that starts with '-' is a compiler option and comes after the library's own.  Since
+    round 4 the library builds without LLVM's SLP vectoriser (46.2 against 53.5 us per C2 frame on MI355X, profiles/r04_ab_fastrow.txt): the default build
+    holds next to no packed-f32 instruction, and `-fslp-vectorize` through the list brings the packing back (dozens of v_pk_*)."""
     import subprocess
     lib = abi.load_library()
     header = open(os.path.join(ROOT, "tools", "bake_c2.h")).read()
     counts = {}
-    for tag, extra in (("default", ""), ("noslp", ";-fno-slp-vectorize")):
+    for tag, extra in (("default", ""), ("slp", ";-fslp-vectorize")):
         out = str(tmp_path / ("jit_%s.co" % tag))
         log = C.create_string_buffer(1 << 16)
         n = lib.gfw_debug_jit_compile(b"gfx950", ((C2_DEFS % (2, 8)) + extra).encode(), header.encode(), out.encode(), log, len(log))
@@ -127,5 +127,6 @@ def test_a_compiler_option_travels_through_the_definition_list(tmp_path):
         dis = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "--mcpu=gfx950", out]).decode()
         counts[tag] = sum(1 for l in dis.splitlines() if "\tv_pk_mul_f32" in l or "\tv_pk_add_f32" in l or "\tv_pk_fma_f32" in l)
         k = [k for k in KR.report(out) if k[".name"] == "gfw_jit_kernel"][0]
-        assert k[".vgpr_count"] <= 64 and k[".private_segment_fixed_size"] == 0
-    assert counts["default"] > 50 and counts["noslp"] == 0, counts
+        if tag == "default":
+            assert k[".vgpr_count"] <= 64 and k[".private_segment_fixed_size"] == 0, k
+    assert counts["default"] <= 8 and counts["slp"] > 50, counts
