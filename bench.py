@@ -110,6 +110,10 @@ def parse_args(argv):
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2, 4),
                     help="contexts (each with its own HIP stream) the frames are dealt to in turn: consecutive frames are independent, so the "
                          "occupancy tail of one frame's kernel can be filled by the next frame's workgroups (resident-matrices workloads only)")
+    ap.add_argument("--per-plane", action="store_true",
+                    help="the reference's own call sequence: one gfw_undistort_image per plane, each plane through a backend object (context) of its own "
+                         "(rendering/mod.rs:494-545), asynchronous device buffers — GFW_OPT_COALESCE_PLANES turns the calls of a frame into one fused launch; "
+                         "--clip N holds N assembled frames for one launch of the specialised kernel (GFW_OPT_COALESCE_FRAMES)")
     ap.add_argument("--build-matrices", action="store_true",
                     help="build every frame's per-row matrices on the device from quaternion tracks (gfw_build_matrices, "
                          "the 'next' row f-1) inside the timed region instead of using pre-packed resident tables")
@@ -344,12 +348,30 @@ def worker(args):
         d_mat = [torch.from_numpy(warp.pack_matrices(fr.matrices)).to(dev) for fr in frames]
         be.set_option(abi.OPT_MATRICES_ON_DEVICE, 2)
         calls = [warp.FrameCall(be, bufsets[j * N_DST + (j % N_DST)], tmpl, types, d_mat[j].data_ptr(), rows_n) for j in range(NR)]
+    plane_bes = []
+    if args.per_plane:
+        # the render loop's shape: plane p has a backend object of its own (plane 0's is `be`); the steps are per-plane gfw_undistort_image calls
+        if device_built or args.host_buffers or args.streams > 1:
+            raise SystemExit("bench.py: --per-plane runs with resident or per-frame uploaded matrices on one stream")
+        hold = max(1, min(args.clip, CLIP_FRAMES, N_DST))
+        for p in range(1, nplanes):
+            b2 = warp.Backend(tmpl[p], types[p], frames[0].model, frames[0].digital, bufsets[0][p])
+            b2.set_stream(stream.cuda_stream)
+            b2.set_option(abi.OPT_SYNCHRONOUS, 0)
+            if not args.upload_matrices:
+                b2.set_option(abi.OPT_MATRICES_ON_DEVICE, 2)
+            b2.set_option(abi.OPT_JIT, args.jit)
+            plane_bes.append(b2)
+        for b2 in [be] + plane_bes:
+            b2.set_option(abi.OPT_COALESCE_FRAMES, hold)
+        calls = [warp.PlaneCalls([be] + plane_bes, bufsets[j * N_DST + (j % N_DST)], tmpl,
+                                 frames[j].matrices if args.upload_matrices else d_mat[j].data_ptr(), rows_n) for j in range(NR)]
     # --streams S: S contexts, each on a stream of its own, take the frames in turn.  Frame k writes destination set k mod N_DST and
     # S divides N_DST, so two frames that share a destination set always share a stream (ordered); everything else may overlap.
     n_streams = args.streams if not (device_built or args.upload_matrices or args.host_buffers or args.c5) else 1
     if n_streams > 1 and (NR % N_DST or N_DST % n_streams):
         raise SystemExit("bench.py: --streams %d needs --resident to be a multiple of %d (two streams would write one destination set unordered)" % (n_streams, N_DST))
-    extra_bes, extra_streams, calls_by_stream = [], [], [calls]
+    extra_bes, extra_streams, calls_by_stream = list(plane_bes), [], [calls]
     for _ in range(1, n_streams):
         st = torch.cuda.Stream(device=dev)
         b2 = warp.Backend(tmpl[0], types[0], frames[0].model, frames[0].digital, bufsets[0][0])
@@ -371,6 +393,8 @@ def worker(args):
     if args.upload_matrices or args.host_buffers or (device_built and not args.c5) or (NR % clip_n and not device_built):
         clip_n = 1
     if args.c5 and BATCH % clip_n:
+        clip_n = 1
+    if args.per_plane:
         clip_n = 1
 
     # what step k of this rank reads and writes: (global frame, source set, destination set)
@@ -482,6 +506,8 @@ def worker(args):
         else:
             for k in range(n):
                 step(k)
+        if args.per_plane:
+            be.flush()                                   # frames still held for a launch (GFW_OPT_COALESCE_FRAMES) leave now: the region ends with a raw device synchronise
 
     run_steps(n_warm)
     torch.cuda.synchronize(dev)
@@ -497,6 +523,8 @@ def worker(args):
     if args.c5:
         d_sums.zero_()                                # gfw_checksum64 accumulates
     pe = args.profile_every
+    if args.per_plane and pe != 1:
+        pe = 0                                        # a launch happens inside the call of a frame's last plane (or later): brackets per step make no sense; --profile-every 1 brackets all
     for b in all_bes:
         b.set_option(abi.OPT_PROFILE, 1 if (pe == 1 and clip_n == 1) else 0)
         b.get_profile(reset=True)
@@ -555,6 +583,9 @@ def worker(args):
         workload += "; %d-frame clip dealt round-robin to %d rank(s), one 64-bit checksum per frame" % (total, world)
     if clip_n > 1:
         workload += "; steps handed to the library as gfw_undistort_clip calls of %d frames" % clip_n
+    if args.per_plane:
+        workload += ("; the reference's call sequence: %d gfw_undistort_image calls per frame (one per plane, each plane its own context), asynchronous, coalesced by the "
+                     "library into one fused launch per %d frame(s)" % (nplanes, max(1, min(args.clip, CLIP_FRAMES, N_DST))))
     out = {
         "metric": "Mpix/s (4K u16 YUV, rolling-shutter warp)" if not args.c1 else "Mpix/s (1080p u8 NV12 warp)",
         "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": n_steps, "warmup": n_warm,
@@ -564,7 +595,7 @@ def worker(args):
                    "streams_per_rank": n_streams, "frames_per_rank": n_steps, "frames_total": frames_done, "parallelism": "frame-sharded x%d" % world,
                    "backend": warp.last_backend(), "checksum": crc, "rank_checksums": rank_crcs,
                    "host_enqueue_ms_per_step": round(t_enq / max(enq_steps, 1) * 1e3, 5),
-                   "clip_frames_per_call": clip_n, "preheat_ms": round(preheat_ms, 1),
+                   "clip_frames_per_call": clip_n, "per_plane_calls": bool(args.per_plane), "preheat_ms": round(preheat_ms, 1),
                    "jit": {"mode": args.jit, "state": {0: "none", 1: "compiling", 2: "ready", 3: "failed"}.get(jit_state[0], str(jit_state[0])),
                            "compile_ms": round(jit_state[1], 1), "log": jit_state[2][-300:] if jit_state[0] == 3 else ""},
                    "device": info.value.decode(), "collectives": (args.backend if dist is not None else "none (1 rank)")},

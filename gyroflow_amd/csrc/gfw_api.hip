@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <map>
 #include <mutex>
+#include <thread>
 
 static_assert(sizeof(gfw_kernel_params) == 368, "KernelParams must be 368 bytes (stabilization/mod.rs:101-150)");
 static_assert(offsetof(gfw_kernel_params, background) == 48, "layout");
@@ -122,12 +123,25 @@ struct gfw_ctx {
     bool jit_dead = false;                                                          // ... or the verdict that there will be none for this clip (build failed / cache full)
     GfwJitInfo jit_info = {GFW_JIT_UNAVAILABLE, 0.0, std::string()};
     static constexpr int kJitAfter = 3;
+    // plane coalescing (round 4): the render loop warps a frame one plane per call, each plane through its own backend object (rendering/mod.rs:494-545);
+    // asynchronous device-buffer calls are held until the frame's planes have arrived and leave as ONE fused launch (see PlaneGroup below)
+    int coalesce_planes = 1;                       // GFW_OPT_COALESCE_PLANES
+    int coalesce_frames = 1;                       // GFW_OPT_COALESCE_FRAMES: assembled frames held for one clip launch (1 = each frame leaves when complete)
+    hipEvent_t group_done = nullptr;               // orders a member context's stream behind the owner's launch
+    struct ClipBatch *held = nullptr;              // frames assembled from per-plane calls, waiting for their launch (owner context only)
+    gfw_ctx *frame_owner = nullptr; bool needs_order = false;   // a member context: whose stream its planes were launched on, and whether its own stream has been ordered behind that yet
+    std::vector<gfw_buffers> held_planes;          // ... and the descriptions those frames were validated with
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;   // recorded, not yet harvested
     size_t ev_used = 0;
     double prof_ms = 0.0; int64_t prof_launches = 0, prof_frames = 0;
     std::vector<int> ev_frames;                   // frames covered by each bracketed launch
 };
+
+extern "C" int gfw_flush(gfw_ctx *c);
+int flush_if_pending(gfw_ctx *c);
+static void gfw_forget_context(gfw_ctx *c);
+static void gfw_register_context(gfw_ctx *c);
 
 static void prof_begin(gfw_ctx *c) {
     if (!c->profile) return;
@@ -239,6 +253,7 @@ gfw_ctx *gfw_create(const gfw_kernel_params *params, int pixel_type, int distort
         char *end = nullptr; const long v = strtol(e, &end, 10);
         if (end != e && *end == 0 && v >= 0 && v <= 2) c->jit_mode = (int)v;
     }
+    if (const char *e = getenv("GFW_COALESCE_PLANES")) { if (e[0] == '0' && e[1] == 0) c->coalesce_planes = 0; }      // deployment override of GFW_OPT_COALESCE_PLANES' default
     c->pixel_type = pixel_type; c->model = distortion_model; c->digital = digital_lens;
     c->src_len = buffers->input.len; c->dst_len = buffers->output.len;
     c->max_matrix_rows = ((params->flags & GFW_FLAG_HORIZONTAL_RS) ? params->width : params->height);   // opencl.rs:287
@@ -262,13 +277,17 @@ gfw_ctx *gfw_create(const gfw_kernel_params *params, int pixel_type, int distort
     if (ok && buffers->input.kind == GFW_BUF_HOST) ok = c->stage_src[0].ensure(c->src_len) == hipSuccess;
     if (ok && buffers->output.kind == GFW_BUF_HOST) ok = c->stage_dst[0].ensure(c->dst_len) == hipSuccess;
     if (!ok) { set_error("device allocation failed: %s", hipGetErrorString(hipGetLastError())); gfw_destroy(c); return nullptr; }
+    gfw_register_context(c);
     return c;
 }
 
 void gfw_destroy(gfw_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)gfw_flush(c);
+    gfw_forget_context(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->group_done) (void)hipEventDestroy(c->group_done);
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &b : c->stage_src) b.release();
     for (auto &b : c->stage_dst) b.release();
@@ -291,7 +310,7 @@ void gfw_destroy(gfw_ctx *c) {
 int gfw_set_option(gfw_ctx *c, int option, int64_t value) {
     if (!c) return GFW_ERR_INVALID_ARGUMENT;
     switch (option) {
-    case GFW_OPT_SYNCHRONOUS: c->synchronous = value != 0; return GFW_OK;
+    case GFW_OPT_SYNCHRONOUS: { const int frc = gfw_flush(c); if (frc != GFW_OK) return frc; } c->synchronous = value != 0; return GFW_OK;
     case GFW_OPT_MATRICES_ON_DEVICE: c->matrices_on_device = (int)value; return GFW_OK;
     case GFW_OPT_KERNEL_VARIANT: c->kernel_variant = (int)value; return GFW_OK;
     case GFW_OPT_PROFILE: c->profile = value != 0; return GFW_OK;
@@ -300,6 +319,9 @@ int gfw_set_option(gfw_ctx *c, int option, int64_t value) {
     case GFW_OPT_JIT: if (value < 0 || value > 2) { set_error("GFW_OPT_JIT %lld", (long long)value); return GFW_ERR_INVALID_ARGUMENT; }
                       c->jit_mode = (int)value; c->jit_fn = nullptr; c->jit_key_valid = false; c->jit_dead = false;
                       c->jit_info = GfwJitInfo{GFW_JIT_UNAVAILABLE, 0.0, std::string()}; return GFW_OK;
+    case GFW_OPT_COALESCE_PLANES: { const int frc = gfw_flush(c); if (frc != GFW_OK) return frc; c->coalesce_planes = value != 0; return GFW_OK; }
+    case GFW_OPT_COALESCE_FRAMES: if (value < 1 || value > GFW_CLIP_FRAMES_MAX) { set_error("GFW_OPT_COALESCE_FRAMES %lld (1..%d)", (long long)value, GFW_CLIP_FRAMES_MAX); return GFW_ERR_INVALID_ARGUMENT; }
+                                  { const int frc = gfw_flush(c); if (frc != GFW_OK) return frc; } c->coalesce_frames = (int)value; return GFW_OK;
     default: set_error("unknown option %d", option); return GFW_ERR_INVALID_ARGUMENT;
     }
 }
@@ -309,6 +331,7 @@ int gfw_set_stream(gfw_ctx *c, void *s) {
     // the previous stream is drained first: frames still in flight on it use this context's staging buffers and matrix slots,
     // and nothing orders the new stream behind them
     HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
+    { const int frc = gfw_flush(c); if (frc != GFW_OK) return frc; }
     (void)hipStreamSynchronize(c->stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)s; c->own_stream = false;
@@ -316,6 +339,7 @@ int gfw_set_stream(gfw_ctx *c, void *s) {
 }
 int gfw_synchronize(gfw_ctx *c) {
     if (!c) return GFW_ERR_INVALID_ARGUMENT;
+    { const int frc = gfw_flush(c); if (frc != GFW_OK) return frc; }      // planes / frames held for a fused launch leave first
     HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
     return GFW_OK;
 }
@@ -328,6 +352,8 @@ int gfw_jit_status(gfw_ctx *c, double *compile_ms, char *log, size_t cap) {
 }
 int gfw_get_audit(gfw_ctx *c, unsigned long long *counters8, int reset) {
     if (!c || !counters8) return GFW_ERR_INVALID_ARGUMENT;
+    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }
+
     HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
     const bool fresh = c->d_audit.cap == 0;
     HIP_TRY(c->d_audit.ensure(8 * sizeof(unsigned long long)), GFW_ERR_HIP);
@@ -340,6 +366,8 @@ int gfw_get_audit(gfw_ctx *c, unsigned long long *counters8, int reset) {
 }
 int gfw_get_profile(gfw_ctx *c, double *kernel_ms, int64_t *launches, int reset) {
     if (!c) return GFW_ERR_INVALID_ARGUMENT;
+    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }
+
     HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
     prof_harvest(c);
     if (kernel_ms) *kernel_ms = c->prof_ms;
@@ -349,6 +377,7 @@ int gfw_get_profile(gfw_ctx *c, double *kernel_ms, int64_t *launches, int reset)
 }
 int gfw_get_profile_frames(gfw_ctx *c, double *kernel_ms, int64_t *launches, int64_t *frames, int reset) {
     if (!c) return GFW_ERR_INVALID_ARGUMENT;
+    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }
     if (frames) { HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP); prof_harvest(c); *frames = c->prof_frames; }
     return gfw_get_profile(c, kernel_ms, launches, reset);
 }
@@ -1045,6 +1074,115 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
     return GFW_OK;
 }
 
+// ---- plane coalescing (GFW_OPT_COALESCE_PLANES) --------------------------------------------------------------------------------------
+// The reference's render loop warps a frame plane by plane: three process_pixels<T> calls (Y, U, V) with the same FrameTransform, each plane through its own
+// Stabilization and therefore its own backend object (src/rendering/mod.rs:494-545).  Bound as INTEGRATION.md shows, that is three gfw_undistort_image
+// calls on three contexts per frame — which used to mean three launches of the per-plane kernel (373 us per C2 frame) while the fused frame kernel does
+// the same work in 46-52.  A PlaneGroup collects those calls: a call that is stream-ordered anyway (asynchronous context, device buffers both sides) is
+// validated, copied and held; when the frame's last plane arrives the group goes through run_planes exactly as one gfw_undistort_frame call would —
+// on the context that took plane 0 (it owns the clip state: specialised kernel, first-pass table), with every other member's stream ordered behind
+// that launch by an event.  Groups are per calling thread; anything else asked of a member context flushes its group first.
+struct PendingPlane { gfw_ctx *c; gfw_buffers b; gfw_kernel_params p; int pixel_type; };
+struct PlaneGroup {
+    std::thread::id thread;
+    int n = 0;
+    PendingPlane pl[4];
+    const float *d_matrices = nullptr;           // device-resident tables (GFW_OPT_MATRICES_ON_DEVICE != 0): the pointer every plane must repeat
+    std::vector<float> h_matrices;               // host rows: a copy of plane 0's, which later planes must equal
+    int matrix_count = 0, matrices_on_device = 0;
+};
+static std::mutex g_group_mu;
+static std::vector<PlaneGroup *> g_groups;       // at most one per thread that ever coalesced
+static std::vector<gfw_ctx *> g_live;            // every context alive (frame_owner links are cleared when their target goes)
+static thread_local PlaneGroup *t_group = nullptr;
+
+// Orders the streams of the owner's member contexts behind everything enqueued on the owner's stream so far.
+static int order_members_behind(gfw_ctx *owner) {
+    bool recorded = false;
+    for (gfw_ctx *m : g_live) {
+        if (m == owner || m->frame_owner != owner || !m->needs_order) continue;
+        m->needs_order = false;
+        m->last_backend = owner->last_backend;
+        if (m->stream == owner->stream) continue;
+        if (!recorded) {
+            if (!owner->group_done && hipEventCreateWithFlags(&owner->group_done, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return GFW_ERR_HIP; }
+            HIP_TRY(hipEventRecord(owner->group_done, owner->stream), GFW_ERR_HIP);
+            recorded = true;
+        }
+        HIP_TRY(hipStreamWaitEvent(m->stream, owner->group_done, 0), GFW_ERR_HIP);
+    }
+    return GFW_OK;
+}
+static int flush_held_frames(gfw_ctx *owner) {
+    if (!owner->held || owner->held->n == 0) return GFW_OK;
+    HIP_TRY(select_device(owner->device), GFW_ERR_HIP);
+    const int rc = clip_flush(owner, owner->held);
+    const int orc = order_members_behind(owner);
+    return rc != GFW_OK ? rc : orc;
+}
+// Sends the group through run_planes (as one frame).  g_group_mu held by the caller.
+static int group_launch(PlaneGroup *g) {
+    if (g->n == 0) return GFW_OK;
+    gfw_ctx *owner = g->pl[0].c;
+    gfw_buffers local[4]; gfw_kernel_params params[4]; int types[4];
+    const int n = g->n;
+    gfw_buffers *planes = local;
+    if (owner->coalesce_frames > 1) {
+        // the assembled frame may wait for more of its clip — one launch of the specialised kernel for up to coalesce_frames frames, as gfw_undistort_clip
+        // issues them; the descriptions a pending launch was validated with must outlive this call
+        if (!owner->held) owner->held = new ClipBatch();
+        if (owner->held_planes.size() < (size_t)4 * GFW_CLIP_FRAMES_MAX) owner->held_planes.resize((size_t)4 * GFW_CLIP_FRAMES_MAX);
+        planes = owner->held_planes.data() + (size_t)4 * (owner->held->n % GFW_CLIP_FRAMES_MAX);
+    }
+    for (int i = 0; i < n; ++i) { planes[i] = g->pl[i].b; params[i] = g->pl[i].p; types[i] = g->pl[i].pixel_type; }
+    for (int i = 1; i < n; ++i) { g->pl[i].c->frame_owner = owner; g->pl[i].c->needs_order = true; }
+    g->n = 0;
+    const float *mats = g->matrices_on_device ? g->d_matrices : g->h_matrices.data();
+    int rc;
+    if (owner->coalesce_frames > 1) {
+        rc = run_planes(owner, n, planes, params, types, mats, g->matrix_count, nullptr, 0, owner->held);
+        if (rc == GFW_OK && owner->held->n >= owner->coalesce_frames) rc = flush_held_frames(owner);
+        if (rc != GFW_OK) (void)flush_held_frames(owner);
+    } else {
+        rc = run_planes(owner, n, planes, params, types, mats, g->matrix_count, nullptr, 0);
+    }
+    if (!(owner->held && owner->held->n > 0)) { const int orc = order_members_behind(owner); if (rc == GFW_OK) rc = orc; }
+    return rc;
+}
+// Everything pending that involves `c`: the frame it is a plane of, the frames it holds as an owner, the frames its owner holds.  g_group_mu held.
+static int flush_context_locked(gfw_ctx *c) {
+    int rc = GFW_OK;
+    for (PlaneGroup *g : g_groups) {
+        bool member = false;
+        for (int i = 0; i < g->n; ++i) member = member || g->pl[i].c == c;
+        if (member) { const int r = group_launch(g); if (rc == GFW_OK) rc = r; }
+    }
+    { const int r = flush_held_frames(c); if (rc == GFW_OK) rc = r; }
+    if (c->frame_owner && c->frame_owner != c && c->needs_order) { const int r = flush_held_frames(c->frame_owner); if (rc == GFW_OK) rc = r; }
+    return rc;
+}
+static void gfw_forget_context(gfw_ctx *c) {
+    std::lock_guard<std::mutex> lk(g_group_mu);
+    if (c->held) { delete c->held; c->held = nullptr; }
+    for (size_t i = 0; i < g_live.size(); ++i) if (g_live[i] == c) { g_live[i] = g_live.back(); g_live.pop_back(); break; }
+    for (gfw_ctx *m : g_live) if (m->frame_owner == c) { m->frame_owner = nullptr; m->needs_order = false; }
+}
+static void gfw_register_context(gfw_ctx *c) { std::lock_guard<std::mutex> lk(g_group_mu); g_live.push_back(c); }
+
+extern "C" {
+
+int gfw_flush(gfw_ctx *c) {
+    if (!c) return GFW_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(g_group_mu);
+    return flush_context_locked(c);
+}
+}  // extern "C"
+// Entry points other than gfw_undistort_image keep their place in the order of calls: whatever is being held leaves first (no lock when nothing is)
+int flush_if_pending(gfw_ctx *c) {
+    if (!c) return GFW_OK;
+    if (!(t_group && t_group->n > 0) && !(c->held && c->held->n > 0) && !c->needs_order) return GFW_OK;
+    return gfw_flush(c);
+}
 extern "C" {
 
 int gfw_undistort_image(gfw_ctx *c, const gfw_buffers *buffers, const gfw_kernel_params *params,
@@ -1055,7 +1193,48 @@ int gfw_undistort_image(gfw_ctx *c, const gfw_buffers *buffers, const gfw_kernel
     if (buffers && buffers->input.kind == GFW_BUF_HOST && buffers->input.len != c->src_len) {
         set_error("Buffer size mismatch input! %zu vs %zu", c->src_len, buffers->input.len); return GFW_ERR_BUFFER_SIZE_MISMATCH; }   // opencl.rs:358
     const int pt = c->pixel_type;
-    return run_planes(c, 1, buffers, params, &pt, matrices, matrix_count, mesh, mesh_len);
+    // Can this call wait for the rest of its frame?  Only if nothing about it has to happen before the call returns.
+    const bool single_channel = pt == GFW_PIX_LUMA8 || pt == GFW_PIX_LUMA16 || pt == GFW_PIX_R32F || pt == GFW_PIX_UV8 || pt == GFW_PIX_UV16;
+    const bool holdable = c->coalesce_planes && !c->synchronous && buffers && params && matrices && single_channel && c->kernel_variant == 0 &&
+                          buffers->input.kind == GFW_BUF_HIP_DEVICE && buffers->output.kind == GFW_BUF_HIP_DEVICE && (!mesh || mesh_len == 0) &&
+                          params->plane_index >= 0 && params->plane_index < 4 && matrix_count >= 1;
+    // (a context that never took part in a held frame, called by a thread that holds nothing: the round-3 path, no lock)
+    if (!holdable && !(t_group && t_group->n > 0) && !(c->held && c->held->n > 0) && !c->needs_order)
+        return run_planes(c, 1, buffers, params, &pt, matrices, matrix_count, mesh, mesh_len);
+    std::lock_guard<std::mutex> lk(g_group_mu);
+    PlaneGroup *g = t_group;
+    if (!g && holdable) { g = t_group = new PlaneGroup(); g->thread = std::this_thread::get_id(); g_groups.push_back(g); }
+    bool cont = false;
+    if (g && g->n > 0) {
+        // does the call continue the frame being assembled?
+        cont = holdable && params->plane_index == g->n && g->pl[0].c->device == c->device && g->pl[0].c->model == c->model && g->pl[0].c->digital == c->digital &&
+               g->matrix_count == matrix_count && g->matrices_on_device == c->matrices_on_device;
+        if (cont) cont = g->matrices_on_device ? (matrices == g->d_matrices) : (memcmp(matrices, g->h_matrices.data(), (size_t)matrix_count * 14 * sizeof(float)) == 0);
+        if (!cont) { const int frc = group_launch(g); if (frc != GFW_OK) return frc; }
+    }
+    const bool starts = holdable && !cont && params->plane_index == 0;
+    // whatever else involves this context leaves first, unless the call is the next plane of the frame or opens the next frame of the clip its context holds
+    if (!cont && !(starts && c->coalesce_frames > 1)) { const int frc = flush_context_locked(c); if (frc != GFW_OK) return frc; }
+    if (!cont && !starts)
+        return run_planes(c, 1, buffers, params, &pt, matrices, matrix_count, mesh, mesh_len);
+    {   // the errors of this plane belong to this call
+        const int vrc = validate_plane(buffers, params, pt);
+        if (vrc != GFW_OK) { (void)group_launch(g); return vrc; }
+        if (params->matrix_count != matrix_count) { (void)group_launch(g); set_error("plane %d: matrix_count %d != %d", g->n, params->matrix_count, matrix_count); return GFW_ERR_INVALID_ARGUMENT; }
+        if (matrix_count > c->max_matrix_rows) { (void)group_launch(g); set_error("Buffer size mismatch matrices! %d vs %d", c->max_matrix_rows, matrix_count); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
+    }
+    if (g->n == 0) {
+        g->matrix_count = matrix_count; g->matrices_on_device = c->matrices_on_device;
+        if (c->matrices_on_device) g->d_matrices = matrices;
+        else g->h_matrices.assign(matrices, matrices + (size_t)matrix_count * 14);
+    }
+    PendingPlane &P = g->pl[g->n++];
+    P.c = c; P.b = *buffers; P.p = *params; P.pixel_type = pt;
+    c->last_backend = "held_for_frame";
+    // complete?  An interleaved chroma plane ends a frame; planar 8/16-bit frames have three planes (a fourth — alpha — goes by itself), planar float four
+    const bool complete = pt == GFW_PIX_UV8 || pt == GFW_PIX_UV16 || ((pt == GFW_PIX_LUMA8 || pt == GFW_PIX_LUMA16) && g->n == 3) || g->n == 4;
+    if (complete) return group_launch(g);
+    return GFW_OK;
 }
 
 int gfw_undistort_frame(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params,
@@ -1063,6 +1242,7 @@ int gfw_undistort_frame(gfw_ctx *c, int nplanes, const gfw_buffers *planes, cons
     if (!planes || !params || !pixel_types) { set_error("null plane arrays"); return GFW_ERR_INVALID_ARGUMENT; }
     for (int i = 0; i < nplanes; ++i)
         if (pixel_types[i] < 0 || pixel_types[i] >= GFW_PIX_COUNT) { set_error("plane %d: unknown pixel type %d", i, pixel_types[i]); return GFW_ERR_INVALID_ARGUMENT; }
+    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }
     return run_planes(c, nplanes, planes, params, pixel_types, matrices, matrix_count, mesh, mesh_len);
 }
 
@@ -1070,6 +1250,8 @@ int gfw_undistort_clip(gfw_ctx *c, int n_frames, int nplanes, const gfw_buffers 
                        const int *pixel_types, const float *const *matrices, int matrix_count) {
     if (!c) { set_error("null context"); return GFW_ERR_INVALID_ARGUMENT; }
     if (n_frames < 0 || !planes || !params || !pixel_types || !matrices) { set_error("null clip arrays"); return GFW_ERR_INVALID_ARGUMENT; }
+    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }
+
     for (int i = 0; i < nplanes; ++i)
         if (pixel_types[i] < 0 || pixel_types[i] >= GFW_PIX_COUNT) { set_error("plane %d: unknown pixel type %d", i, pixel_types[i]); return GFW_ERR_INVALID_ARGUMENT; }
     // the frame loop of a render (rendering/mod.rs:487-547 calls process_pixels once per frame), here on the library side: frames that
@@ -1156,6 +1338,8 @@ extern "C" long gfw_debug_jit_compile(const char *arch, const char *defines, con
 
 extern "C" int gfw_checksum64(gfw_ctx *c, const void *d_buf, size_t bytes, unsigned long long *d_out) {
     if (!c || !d_buf || !d_out || (bytes & 7) || ((uintptr_t)d_buf & 15)) { set_error("bad checksum arguments"); return GFW_ERR_INVALID_ARGUMENT; }
+    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }
+
     HIP_TRY(gfw_launch_checksum64(d_buf, bytes, d_out, c->stream), GFW_ERR_HIP);
     return GFW_OK;
 }
@@ -1231,6 +1415,7 @@ int gfw_build_matrices(gfw_ctx *c, const gfw_frame_timing *t, float *rows16_out,
 int gfw_build_matrices_stab(gfw_ctx *c, const gfw_frame_timing *t, const gfw_frame_stab *stab, float *rows16_out, float **out_ptr) {
     if (!c || !t) { set_error("null context/timing"); return GFW_ERR_INVALID_ARGUMENT; }
     if (!timing_ok(t)) { set_error("rows %d, readout_dim %d, suppress_rotation %d", t->rows, t->readout_dim, t->suppress_rotation); return GFW_ERR_INVALID_ARGUMENT; }
+    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }
     HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
     GfwStab S, *Sp = nullptr;
     gfw_ctx::StabSlot *stab_slot = nullptr; size_t stab_bytes = 0;
@@ -1304,8 +1489,9 @@ int gfw_build_matrices_batch(gfw_ctx *c, const gfw_frame_timing *t, int count, f
         if (!timing_ok(&t[i])) { set_error("frame %d: rows %d, readout_dim %d, suppress_rotation %d", i, t[i].rows, t[i].readout_dim, t[i].suppress_rotation); return GFW_ERR_INVALID_ARGUMENT; }
         if (t[i].rows > max_rows) max_rows = t[i].rows;
     }
+    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }
     HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
-    // two batches alternate: the stream is in order, so the batch being overwritten was consumed by launches enqueued before this one
+    // two batches alternate: the stream is in order, so the batch being overwritten was consumed by launches enqueued before this one (held frames have just left)
     DevBuf &buf = c->d_batch[c->batch_next];
     c->batch_next ^= 1;
     const size_t table_floats = (size_t)max_rows * GFW_MAT_STRIDE;
@@ -1330,6 +1516,7 @@ extern "C" int gfw_undistort_points(gfw_ctx *c, const gfw_kernel_params *p, cons
     if (mesh_len > GFW_MESH_MAX) { set_error("mesh too large"); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
     { const int mrc = validate_mesh(mesh, mesh_len); if (mrc != GFW_OK) return mrc; }
     if (n == 0) return GFW_OK;                                               // :637 `if distorted.is_empty() { return Vec::new(); }`
+    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }
     HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
     GfwPointsArgs A;
     memset(&A, 0, sizeof(A));
@@ -1382,6 +1569,7 @@ extern "C" int gfw_stmap_undistort(gfw_ctx *c, const gfw_kernel_params *p, const
     if (p->matrix_count != matrix_count || matrix_count < 1) { set_error("matrix_count %d != %d", p->matrix_count, matrix_count); return GFW_ERR_INVALID_ARGUMENT; }
     if (mesh_len > GFW_MESH_MAX) { set_error("mesh too large"); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
     { const int mrc = validate_mesh(mesh, mesh_len); if (mrc != GFW_OK) return mrc; }
+    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }
     HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
     const float *d_mat = nullptr;
     int rc = upload_matrices(c, matrices, matrix_count, &d_mat);

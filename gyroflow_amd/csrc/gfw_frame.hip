@@ -117,6 +117,33 @@
 
 namespace {
 
+// Wave votes as one compare into a scalar pair and one scalar compare with EXEC: the library's __all / __any go through a 0/1 select and a second
+// compare (two more vector instructions and a VCC hazard per vote; the branch-free row votes three times per pixel pair).
+#if defined(GFW_HOST_INTERPRETER)
+#define gfw_all(p) __all(p)
+#define gfw_any(p) __any(p)
+#else
+__device__ __forceinline__ bool gfw_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
+__device__ __forceinline__ bool gfw_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+#endif
+// A vote over a conjunction, assembled from the ballots of its terms (each a compare straight into a scalar pair; the conjunction itself would be
+// rebuilt as a 0/1 select and compared again): `v &= gfw_lanes(test)` per term, then gfw_all_lanes(v).
+#if defined(GFW_HOST_INTERPRETER)
+typedef bool GfwVote;
+#define GFW_VOTE_ALL true
+#define gfw_lanes(p) (p)
+#define gfw_all_lanes(v) __all(v)
+#define gfw_vote_select(cur, cond, val) ((cond) ? (val) : (cur))
+#define gfw_vote_lane(v, lane) (v)
+#else
+typedef unsigned long long GfwVote;
+#define GFW_VOTE_ALL (~0ull)
+#define gfw_lanes(p) __builtin_amdgcn_ballot_w64(p)
+__device__ __forceinline__ bool gfw_all_lanes(GfwVote v) { const GfwVote e = __builtin_amdgcn_ballot_w64(true); return (v & e) == e; }
+__device__ __forceinline__ GfwVote gfw_vote_select(GfwVote cur, GfwVote cond, GfwVote val) { return (cur & ~cond) | (cond & val); }     // per lane: cond ? val : cur
+__device__ __forceinline__ bool gfw_vote_lane(GfwVote v, int lane) { return ((v >> (unsigned)lane) & 1ull) != 0ull; }
+#endif
+
 // 32-phase bicubic / Lanczos4 tap table (one constant copy per translation unit)
 __device__
 #include "gfw_coeffs.inc"
@@ -184,7 +211,7 @@ __device__ __forceinline__ float chroma_from_luma(float l, float x, float mul_c,
     if (mul_c == mul_l) return l;
     if (2.0f * mul_c == mul_l) {
         const bool tiny = fabsf(l) < 0x1p-100f && l != 0.0f;
-        if (__builtin_expect(!__any(tiny), 1)) return 0.5f * l;
+        if (__builtin_expect(!gfw_any(tiny), 1)) return 0.5f * l;
     }
     return map_c<INF_SAFE>(x, mul_c, den, rcp);
 }
@@ -304,17 +331,17 @@ __device__ __forceinline__ void rd_lean_nobranch(const float *px, const float *p
         rare[i] = odd;
     }
     if (!(AF(k_all_zero) != 0)) {
-        bool small = true;
+        GfwVote small = GFW_VOTE_ALL;
         #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const float rr = a[i] * a[i] + b[i] * b[i];
             // rr in [2^-80, 2^50): below, the generic sqrt and the optical centre's s = 1; above, atanf's r >= 2^25 record — one unsigned range test on the bit pattern (NaN fails it)
             rare[i] = rare[i] | !((gfw_f2u(rr) - 0x17800000u) < (0x58800000u - 0x17800000u));
             r[i] = gfw_sqrt_lean(rr);
-            small = small & (r[i] < 0.4375f);
+            small = small & gfw_lanes(r[i] < 0.4375f);
         }
         float t[NP];
-        if (__all(small)) {
+        if (gfw_all_lanes(small)) {
             const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
                         aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
                         aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
@@ -1187,6 +1214,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                 const int cy = cy0 + r;
                 if (!WHOLE && cy >= AF(ch)) break;
                 float u0 = 0.0f, v0 = 0.0f, lu0 = 0.0f, lv0 = 0.0f; bool ok0 = false;
+                GfwVote okm0 = GFW_VOTE_ALL;              // the branch-free row's form of ok0
                 // The branch-free row (round 4; specialised fisheye, bilinear, single-channel luma): a lane's DW pixels of one line are projected with
                 // rd_lean_nobranch, mapped and binned without a divergent branch; the wave is asked ONCE per stage — `__any(rare)` sends the odd lanes
                 // through rd<> itself, `__all(interior)` picks between the branch-free taps (pair stored as one word) and sample_store2.
@@ -1195,7 +1223,8 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     #pragma unroll (NPX <= 2 ? DH : 1)
                     for (int j = 0; j < DH; ++j) {
                         const int ly = cy * DH + j;
-                        float pu[DW], pv[DW]; bool okp[DW], odd[DW]; bool any_odd = false;
+                        float pu[DW], pv[DW]; bool odd[DW]; bool any_odd = false;
+                        GfwVote okp[DW];                 // which lanes hold a valid point: a wave mask in scalar registers (a per-lane bool would live in a VGPR across the vote below)
                         {
                             float ox[DW], oy[DW], m8[DW]; float4 ma[DW], mb[DW];
                             #pragma unroll
@@ -1214,19 +1243,23 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                             for (int i = 0; i < DW; ++i) rd_lean_nobranch<1>(ox + i, oy + i, ma + i, mb + i, m8 + i, L, A, pu + i, pv + i, odd + i);
 #endif
                             #pragma unroll
-                            for (int i = 0; i < DW; ++i) { okp[i] = true; any_odd = any_odd | odd[i]; }
+                            for (int i = 0; i < DW; ++i) { okp[i] = GFW_VOTE_ALL; any_odd = any_odd | odd[i]; }
                         }
-                        if (__builtin_expect(__any(any_odd), 0)) {
+                        if (__builtin_expect(gfw_any(any_odd), 0)) {
                             #pragma unroll
-                            for (int i = 0; i < DW; ++i) if (odd[i]) {
-                                const int lx = cx * DW + i;
-                                const float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
-                                const int sy = two_pass ? s_rows[r * NPX + j * DW + i][tid] : default_row<MODEL>(ox, oy, A);
-                                const GfwPt p = rd_row<MODEL>(ox, oy, min(sy, AF(matrix_count) - 1), matrices, L, A);
-                                pu[i] = p.x; pv[i] = p.y; okp[i] = p.ok;
+                            for (int i = 0; i < DW; ++i) {
+                                bool ok_i = true;
+                                if (odd[i]) {
+                                    const int lx = cx * DW + i;
+                                    const float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
+                                    const int sy = two_pass ? s_rows[r * NPX + j * DW + i][tid] : default_row<MODEL>(ox, oy, A);
+                                    const GfwPt p = rd_row<MODEL>(ox, oy, min(sy, AF(matrix_count) - 1), matrices, L, A);
+                                    pu[i] = p.x; pv[i] = p.y; ok_i = p.ok;
+                                }
+                                okp[i] = gfw_vote_select(okp[i], gfw_lanes(odd[i]), gfw_lanes(ok_i));
                             }
                         }
-                        int bx[DW], by[DW]; bool interior = true;      // (bx, by) = round(32 u), round(32 v): all a sample's bins and weights derive from them
+                        int bx[DW], by[DW]; GfwVote interior = GFW_VOTE_ALL;      // (bx, by) = round(32 u), round(32 v): all a sample's bins and weights derive from them
                         #pragma unroll
                         for (int i = 0; i < DW; ++i) {
                             const int lx = cx * DW + i;
@@ -1244,12 +1277,12 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                                 if (ry < 3.0f)    pv[i] = 3.0f + height_f - (height3 + ry);
                             }
                             const float lu = map_c<INF_COORDS>(pu[i], MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c<INF_COORDS>(pv[i], MP.mul_ly, MP.den_y, MP.rcp_y);   // :511-514
-                            if (j == 0 && i == 0) { u0 = pu[0]; v0 = pv[0]; ok0 = okp[0]; lu0 = lu; lv0 = lv; }
+                            if (j == 0 && i == 0) { u0 = pu[0]; v0 = pv[0]; okm0 = okp[0]; lu0 = lu; lv0 = lv; }
                             bx[i] = round_i32(lu * 32.0f); by[i] = round_i32(lv * 32.0f);
                             const bool live = WHOLE || (lx < AF(out_w) && ly < AF(out_h));
-                            interior = interior & (okp[i] & live & ((unsigned)(bx[i] >> 5) < (unsigned)(PL0.w - 1)) & ((unsigned)(by[i] >> 5) < (unsigned)(PL0.h - 1)));
+                            interior = interior & okp[i] & gfw_lanes(live) & gfw_lanes((unsigned)(bx[i] >> 5) < (unsigned)(PL0.w - 1)) & gfw_lanes((unsigned)(by[i] >> 5) < (unsigned)(PL0.h - 1));
                         }
-                        if (__builtin_expect(__all(interior), 1)) {
+                        if (__builtin_expect(gfw_all_lanes(interior), 1)) {
                             uint32_t val[DW];
                             #pragma unroll
                             for (int i = 0; i < DW; ++i) val[i] = inside_value1<T>(PL0.src, PL0.src_stride, bins2_of(bx[i], by[i]), bg_y, lim_y);
@@ -1260,7 +1293,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                             #pragma unroll
                             for (int i = 0; i < DW; ++i) {
                                 const int lx = cx * DW + i;
-                                if (WHOLE || (lx < AF(out_w) && ly < AF(out_h))) sample_store2_bins<T, N0>(bx[i], by[i], okp[i], PL0, bg_y, lim_y, lx, ly, nullptr);
+                                if (WHOLE || (lx < AF(out_w) && ly < AF(out_h))) sample_store2_bins<T, N0>(bx[i], by[i], gfw_vote_lane(okp[i], lane), PL0, bg_y, lim_y, lx, ly, nullptr);
                             }
                         }
                     }
@@ -1330,7 +1363,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     if constexpr (FASTROW && !is_f32<T>::value) if (!AF(ablate) && (INTERLEAVED_UV || AF(nplanes) == 3)) {
                         // the chroma site the same way: one question to the wave, then the branch-free interior taps of both chroma samples
                         const Bins2 bc = make_bins2(cu, cv);
-                        if (__builtin_expect(__all(ok0 & bins2_inside(bc, PL1.w, PL1.h)), 1)) {
+                        if (__builtin_expect(gfw_all_lanes(okm0 & gfw_lanes((unsigned)bc.sx < (unsigned)(PL1.w - 1)) & gfw_lanes((unsigned)bc.sy < (unsigned)(PL1.h - 1))), 1)) {
                             if constexpr (INTERLEAVED_UV) {
                                 const int off0 = row_off(bc.sy, PL1.src_stride) + bc.sx * (int)(2 * sizeof(T));
                                 const int doff = row_off(cy, PL1.dst_stride) + cx * (int)(2 * sizeof(T));
@@ -1356,6 +1389,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                             chroma_done = true;
                         }
                     }
+                    if (FASTROW && !AF(ablate) && !chroma_done) ok0 = gfw_vote_lane(okm0, lane);       // the edge-aware samplers below take the per-lane form
                     if (chroma_done) {}
                     else if (I == 2) {
                         if (INTERLEAVED_UV) sample_store2<T, 2>(cu, cv, ok0, PL1, bg_c, lim_u, cx, cy, AUDIT ? AF(audit) : nullptr);

@@ -76,6 +76,11 @@ class Backend:
             raise GfwError(rc, self.lib.gfw_last_error().decode())
         _last_backend = self.lib.gfw_last_backend(self.ctx).decode()
 
+    @staticmethod
+    def last_backend_of(be):
+        """gfw_last_backend of this context (the module-level last_backend() names whichever context was called last)."""
+        return be.lib.gfw_last_backend(be.ctx).decode()
+
     def set_option(self, opt, value):
         self._check(self.lib.gfw_set_option(self.ctx, opt, value))
 
@@ -217,6 +222,10 @@ class Backend:
     def synchronize(self):
         self._check(self.lib.gfw_synchronize(self.ctx))
 
+    def flush(self):
+        """Enqueue whatever plane coalescing holds for a frame this context belongs to (gfw_flush); does not wait for the GPU."""
+        self._check(self.lib.gfw_flush(self.ctx))
+
     def undistort_image(self, buffers, params, matrices, mesh=None, matrix_count=None):
         """One plane (OclWrapper::undistort_image).  ``matrices``: numpy [rows][14] f32, or a device pointer int."""
         if isinstance(matrices, np.ndarray):
@@ -279,6 +288,28 @@ class FrameCall:
         rc = self.fn(self.be.ctx, self.n, self.barr, self.parr, self.tarr, self.mp, self.mc, None, 0)
         if rc != 0:
             self.be._check(rc)
+
+
+class PlaneCalls:
+    """Pre-marshalled per-plane ``gfw_undistort_image`` calls of ONE frame, plane p through backend p — the call sequence of the reference's render loop
+    (one process_pixels per plane, each plane its own Stabilization / backend object, src/rendering/mod.rs:494-545)."""
+
+    def __init__(self, backends, planes, params, matrices, matrix_count=None):
+        if isinstance(matrices, np.ndarray):
+            self.m = np.ascontiguousarray(matrices, dtype=np.float32)
+            mp, mc = self.m.ctypes.data, self.m.shape[0]
+        else:
+            mp, mc = matrices, matrix_count
+        self.keep = [(abi.Buffers.from_buffer_copy(b), abi.KernelParams.from_buffer_copy(p)) for b, p in zip(planes, params)]
+        for i, (_, p) in enumerate(self.keep):
+            p.plane_index = i
+        self.items = [(be.lib.gfw_undistort_image, be.ctx, C.byref(b), C.byref(p), mp, mc, be) for be, (b, p) in zip(backends, self.keep)]
+
+    def __call__(self):
+        for fn, ctx, b, p, mp, mc, be in self.items:
+            rc = fn(ctx, b, p, mp, mc, None, 0, None, 0)
+            if rc != 0:
+                be._check(rc)
 
 
 class ClipCall:

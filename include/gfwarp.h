@@ -278,13 +278,29 @@ enum {
     GFW_OPT_PROFILE            = 4,  /* 1: bracket every warp-kernel launch with hipEvents on the context stream */
     GFW_OPT_TUNE_ROWS          = 5,  /* reserved (ignored) */
     GFW_OPT_TUNE_GRID          = 6,  /* tuning: persistent workgroups of the fused kernel (0 = 6 per CU) */
-    GFW_OPT_JIT                = 7   /* per-clip specialised kernel, compiled at run time the way the reference compiles its OpenCL source per clip
+    GFW_OPT_JIT                = 7,  /* per-clip specialised kernel, compiled at run time the way the reference compiles its OpenCL source per clip
                                         (opencl.rs:181-214): 0 never; 1 (default) built in the background once the context has warped three
                                         frames with the same clip constants, frames run ahead-of-time until it is ready; 2 built at the first
                                         frame, which waits for it (~1 s).  Same results bit for bit; the environment variable GFW_JIT sets
                                         the default of new contexts.  Without libhiprtc.so the option has no effect. */
+    GFW_OPT_COALESCE_PLANES    = 8,  /* 1 (default): the planes of a frame that arrive one per gfw_undistort_image call — the reference's render loop issues
+                                        process_pixels once per plane, each plane through its own Stabilization / backend object
+                                        (src/rendering/mod.rs:494-545) — leave as ONE fused launch.  Applies to calls that are stream-ordered anyway:
+                                        GFW_OPT_SYNCHRONOUS = 0, HIP_DEVICE buffers on both sides.  Such a call validates its arguments, keeps a copy and
+                                        returns; the frame is enqueued (on the stream of the context that took plane_index 0, every other member's stream
+                                        ordered behind it) when its last plane arrives — a UV8 / UV16 plane, the third Luma plane, the fourth R32f plane —
+                                        or when anything else is asked of a member context (gfw_synchronize, gfw_flush, an option, a plane that does not
+                                        continue the frame, gfw_destroy).  COMPLETION CONTRACT: observe completion through gfw_synchronize / gfw_flush of any
+                                        member context (or events recorded after them), not by synchronising the raw stream alone.  Results are bit-identical
+                                        to the per-plane launches.  0: every call launches its own plane (round-3 behaviour). */
+    GFW_OPT_COALESCE_FRAMES    = 9   /* frames assembled by GFW_OPT_COALESCE_PLANES that are held for one launch of the run-time specialised kernel
+                                        (1..GFW_CLIP_FRAMES_MAX; default 1: a frame leaves when it is complete).  Larger values trade latency for the
+                                        throughput of gfw_undistort_clip (the occupancy tail of one frame filled by the next). */
 };
 int   gfw_set_option(gfw_ctx *ctx, int option, int64_t value);
+/* Enqueues whatever gfw_undistort_image calls GFW_OPT_COALESCE_PLANES / _FRAMES are holding for a frame or launch this context belongs to
+ * (no-op otherwise).  Does not wait for the GPU: gfw_synchronize does both. */
+int   gfw_flush(gfw_ctx *ctx);
 /* hipStream_t the context enqueues on (as void*); caller may substitute its
  * own stream (e.g. the decoder's) — mirrors passing the cl_command_queue in
  * BufferSource::OpenCL{queue} (gpu/mod.rs:37-40). */

@@ -6,6 +6,7 @@
 // library never loads it, and it is as slow as it sounds.  The source text is not edited for this — the only transformation is the
 // seven inline-asm statements (AMD mnemonics) turned into calls of the emu_v_* functions below (tests/emu/build_emu.py).
 #pragma once
+#define GFW_HOST_INTERPRETER 1
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>

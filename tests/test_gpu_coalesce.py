@@ -1,0 +1,186 @@
+"""The reference's own call sequence — one process_pixels per plane, each plane through its own backend object (src/rendering/mod.rs:494-545) — through
+gfw_undistort_image with GFW_OPT_COALESCE_PLANES: asynchronous device-buffer calls are held until the frame's planes have arrived and leave as ONE
+launch of the fused frame kernel.  Checked here: the backend that ran (no per-plane kernel), bit-exact planes against the oracle, the completion
+contract (gfw_synchronize of ANY member context), host matrices as well as device-resident tables, frames held for a clip launch, and everything
+that must break a group apart (a synchronous context, another frame's plane, an error).
+"""
+import numpy as np
+import pytest
+
+from gyroflow_amd import abi, synthetic as S, warp
+import _oracle as O
+from test_gpu_parity import assert_plane_equal
+from test_gpu_fullsize import _View
+
+pytestmark = pytest.mark.gpu
+
+
+class PlaneLoop:
+    """What the render loop holds per plane: a backend object (context) of its own; `frame()` issues the per-plane calls of one frame in order."""
+
+    def __init__(self, frames, device_matrices=True, jit=0, frames_per_launch=1, shared_stream=False, synchronous=False):
+        import torch
+        self.torch, self.dev = torch, torch.device("cuda", 0)
+        assert abi.load_library().gfw_set_device(0) == 0
+        self.frames = frames
+        self.d_src = [fr.device_planes(self.dev) for fr in frames]
+        self.d_dst = [fr.device_outputs(self.dev) for fr in frames]
+        self.d_mat = [torch.from_numpy(warp.pack_matrices(fr.matrices)).to(self.dev) for fr in frames] if device_matrices else None
+        torch.cuda.synchronize(self.dev)
+        fr0 = frames[0]
+        self.bufs = [[warp.device_buffers(self.d_src[j][p].data_ptr(), self.d_src[j][p].numel(), pl["size"], self.d_dst[j][p].data_ptr(), self.d_dst[j][p].numel(), pl["out_size"])
+                      for p, pl in enumerate(fr.planes)] for j, fr in enumerate(frames)]
+        self.be = []
+        stream = torch.cuda.Stream(self.dev) if shared_stream else None
+        self.stream = stream
+        for p, pl in enumerate(fr0.planes):
+            be = warp.Backend(pl["params"], pl["pixel_type"], fr0.model, fr0.digital, self.bufs[0][p])
+            if stream is not None:
+                be.set_stream(stream.cuda_stream)
+            be.set_option(abi.OPT_SYNCHRONOUS, 1 if synchronous else 0)
+            if device_matrices:
+                be.set_option(abi.OPT_MATRICES_ON_DEVICE, 2)
+            be.set_option(abi.OPT_JIT, jit)
+            if frames_per_launch > 1:
+                be.set_option(abi.OPT_COALESCE_FRAMES, frames_per_launch)
+            self.be.append(be)
+
+    def frame(self, j, planes=None):
+        fr = self.frames[j]
+        for p, pl in enumerate(fr.planes):
+            if planes is not None and p not in planes:
+                continue
+            prm = pl["params"]
+            assert prm.plane_index == p
+            if self.d_mat is not None:
+                self.be[p].undistort_image(self.bufs[j][p], prm, self.d_mat[j].data_ptr(), matrix_count=fr.matrices.shape[0])
+            else:
+                self.be[p].undistort_image(self.bufs[j][p], prm, fr.matrices)
+
+    def outputs(self, j):
+        return [t.cpu().numpy() for t in self.d_dst[j]]
+
+    def check(self, j, what=""):
+        fr = self.frames[j]
+        ref = O.run_frame(_View(fr, [t.cpu().numpy() for t in self.d_src[j]]))
+        for p, (a, b) in enumerate(zip(ref, self.outputs(j))):
+            assert_plane_equal(a, b, fr.planes[p]["pixel_type"], "%s frame %d plane %d" % (what, j, p))
+
+    def close(self):
+        for be in self.be:
+            be.close()
+
+
+def clip(fmt, w, h, n, **kw):
+    return [S.SyntheticFrame(fmt, w, h, seed=0xC0A1 + j, timestamp_ms=1000.0 + 33.3 * j, **kw) for j in range(n)]
+
+
+@pytest.mark.parametrize("fmt", ["YUV422P16LE", "NV12", "YUV420P", "P010LE", "YUV444P16LE", "GBRAPF32LE"])
+@pytest.mark.parametrize("device_matrices", [True, False])
+def test_planes_of_a_frame_leave_as_one_fused_launch(fmt, device_matrices):
+    loop = PlaneLoop(clip(fmt, 640, 360, 3), device_matrices=device_matrices)
+    try:
+        for j in range(3):
+            loop.frame(j)
+            # the last plane's call enqueued the frame: every member context names the fused kernel, none the per-plane one
+            names = [warp.Backend.last_backend_of(be) for be in loop.be]
+            assert all(n.startswith("yuv_fused") for n in names), names
+        loop.be[-1].synchronize()                        # ANY member: its stream is ordered behind the owner's launch
+        for j in range(3):
+            loop.check(j, fmt)
+    finally:
+        loop.close()
+
+
+def test_synchronize_of_a_member_flushes_an_incomplete_frame():
+    """Y and U were issued, V never comes: gfw_synchronize of either context must still deliver both planes (per-plane kernel or fused, but complete)."""
+    loop = PlaneLoop(clip("YUV422P16LE", 320, 192, 1))
+    try:
+        loop.frame(0, planes=(0, 1))
+        assert warp.Backend.last_backend_of(loop.be[1]) == "held_for_frame"
+        loop.be[1].synchronize()
+        assert warp.Backend.last_backend_of(loop.be[0]) != "held_for_frame"
+        fr = loop.frames[0]
+        ref = O.run_frame(_View(fr, [t.cpu().numpy() for t in loop.d_src[0]]))
+        out = loop.outputs(0)
+        for p in (0, 1):
+            assert_plane_equal(ref[p], out[p], fr.planes[p]["pixel_type"], "incomplete frame, plane %d" % p)
+        assert np.all(out[2] == 0x5A)                    # nobody asked for V
+    finally:
+        loop.close()
+
+
+def test_the_next_frames_first_plane_sends_a_luma_only_frame_on_its_way():
+    loop = PlaneLoop(clip("YUV422P16LE", 320, 192, 2))
+    try:
+        loop.frame(0, planes=(0,))
+        loop.frame(1)
+        loop.be[0].synchronize()
+        fr = loop.frames[0]
+        ref = O.run_frame(_View(fr, [t.cpu().numpy() for t in loop.d_src[0]]))
+        assert_plane_equal(ref[0], loop.outputs(0)[0], "Luma16", "luma-only frame")
+        loop.check(1, "frame behind a luma-only frame")
+    finally:
+        loop.close()
+
+
+def test_synchronous_contexts_and_host_buffers_are_never_held():
+    loop = PlaneLoop(clip("NV12", 320, 192, 1), synchronous=True)
+    try:
+        loop.frame(0)
+        assert all(warp.Backend.last_backend_of(be) != "held_for_frame" for be in loop.be)
+        loop.check(0, "synchronous")                     # no synchronize call: the default contract
+    finally:
+        loop.close()
+    fr = S.SyntheticFrame("NV12", 320, 192, seed=5)
+    assert all(np.array_equal(a, b) for a, b in zip(O.run_frame(fr), warp.run_frame(fr, per_plane=True)))
+
+
+def test_an_invalid_plane_reports_its_own_error_and_releases_the_frame():
+    loop = PlaneLoop(clip("YUV422P16LE", 320, 192, 1))
+    try:
+        loop.frame(0, planes=(0,))
+        bad = abi.KernelParams.from_buffer_copy(loop.frames[0].planes[1]["params"])
+        bad.interpolation = 7
+        with pytest.raises(Exception):
+            loop.be[1].undistort_image(loop.bufs[0][1], bad, loop.d_mat[0].data_ptr(), matrix_count=loop.frames[0].matrices.shape[0])
+        assert warp.Backend.last_backend_of(loop.be[0]) != "held_for_frame"      # plane 0 went out on its own
+        loop.be[0].synchronize()
+        fr = loop.frames[0]
+        ref = O.run_frame(_View(fr, [t.cpu().numpy() for t in loop.d_src[0]]))
+        assert_plane_equal(ref[0], loop.outputs(0)[0], "Luma16", "plane 0 after plane 1 failed")
+    finally:
+        loop.close()
+
+
+@pytest.mark.parametrize("shared_stream", [False, True])
+def test_frames_held_for_a_clip_launch_of_the_specialised_kernel(shared_stream):
+    """GFW_OPT_COALESCE_FRAMES = 4: the per-plane calls of four frames become ONE launch of the run-time specialised kernel (what gfw_undistort_clip does
+    for callers that own the frame loop); a member's gfw_synchronize delivers frames the owner still holds."""
+    n = 10
+    loop = PlaneLoop(clip("YUV422P16LE", 384, 208, n), jit=2, frames_per_launch=4, shared_stream=shared_stream)
+    try:
+        for j in range(n):
+            loop.frame(j)
+        loop.be[2].synchronize()                         # frames 8, 9 are still held by the owner (context of plane 0): a member's synchronise sends them
+        assert warp.Backend.last_backend_of(loop.be[0]).endswith("_jit")
+        ms, launches, frames = (0.0, 0, 0)
+        for j in range(n):
+            loop.check(j, "clip launch")
+    finally:
+        loop.close()
+
+
+def test_option_off_restores_the_per_plane_launches():
+    loop = PlaneLoop(clip("YUV422P16LE", 320, 192, 1))
+    try:
+        for be in loop.be:
+            be.set_option(abi.OPT_COALESCE_PLANES, 0)
+        loop.frame(0)
+        names = [warp.Backend.last_backend_of(be) for be in loop.be]
+        assert "held_for_frame" not in names and names[1] == names[2] == "plane_generic", names      # (a lone luma plane is a frame the fused kernel serves)
+        for be in loop.be:
+            be.synchronize()
+        loop.check(0, "coalescing off")
+    finally:
+        loop.close()

@@ -30,7 +30,7 @@ def compile_isa(defs, header, workdir):
     d = dict(kv.split("=", 1) for kv in C2_DEFS.split(";"))
     flags = [kv for kv in defs.split(";") if kv.startswith("-")]              # compiler options travel like GFW_JIT_DEFS entries that start with '-'
     d.update(kv.split("=", 1) for kv in defs.split(";") if kv and not kv.startswith("-"))
-    cmd = ["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed",
+    cmd = ["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-Wno-pass-failed",
            "-Wno-cuda-compat", "-gline-tables-only", "-DGFW_JIT=1", "-DGFW_BAKE=1"] + flags + ["-D%s=%s" % kv for kv in d.items()] + [hip, "-o", asm]
     subprocess.run(cmd, check=True, capture_output=True)
     return open(asm).read().splitlines(), open(hip).read().splitlines()
