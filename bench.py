@@ -193,6 +193,33 @@ def launcher(args, argv):
 
 
 # ---------------------------------------------------------------------------------------------- worker
+def host_threads():
+    """(threads, why): the CPUs this process may actually use — the scheduler affinity, capped by the container's CFS quota (cgroup v2 cpu.max / v1
+    cfs_quota_us).  More OpenMP threads than that only fight over the quota (profiles/r04_cpu_baseline_scan.txt: 61 Mpix/s on 16 threads, 42 on 128)."""
+    n = os.cpu_count() or 1
+    why = "%d hardware threads visible" % n
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n = max(1, int(quota + 0.5))
+        why += ", CFS quota of the container: %.1f CPUs" % quota
+    return n, why
+
+
 class _FrameView:
     """What tests/_oracle.run_frame needs of a frame, with the pixels downloaded from the device."""
 
@@ -672,20 +699,38 @@ def worker(args):
             out["config"]["parity_vs_reference_kernel"] = ("bit-exact: CRC32 of all %d planes of frame 0 = tests/golden/ref_golden.json[c2_yuv422p16_3840x2160_rs], written by "
                                                            "the reference's opencl_undistort.cl compiled for the host" % nplanes) if crcs == want else "MISMATCH %s != %s" % (crcs, want)
         if world == 1 and not args.no_cpu_baseline:
-            cores = O.lib().gfw_oracle_num_threads()
-            views = [c[3] for c in checks]
+            # The reference's CPU path as this box's host cores run it: oracle/gfw_oracle.c, its row loop instantiated per (sampler, pixel type) like the
+            # Rust original's <I, T>, all planes of a frame in ONE parallel region (static chunks of 4 rows), one thread per CPU the container may use
+            # (host_threads: the GPU boxes show 256 hardware threads and grant a CFS quota of 16 — round 3 ran 128 threads into that quota and reported
+            # 0.32 Mpix/s per thread where a thread does 3.8-4.6).  profiles/r04_cpu_baseline_scan.txt: how it scales.
+            hw, why = host_threads()
+            runners = [O.FrameRunner(c[3], nthreads=hw) for c in checks]
             for i in range(2):
-                O.run_frame(views[i % len(views)])                        # warm-up
+                runners[i % len(runners)].run()                           # warm-up: first touch of the outputs by the threads that keep writing them
+            if not args.no_parity:
+                for (k, f, d, view), r in zip(checks, runners):           # the timed form must write what the checker's form wrote (bytes the warp never writes aside)
+                    outs = r.run()
+                    for p in range(nplanes):
+                        w_, h_, st_ = view.planes[p]["out_size"]
+                        bpp_ = view.planes[p]["params"].bytes_per_pixel
+                        a = outs[p].reshape(h_, st_)[:, :w_ * bpp_]; b2 = refs[k][p].reshape(h_, st_)[:, :w_ * bpp_]
+                        assert np.array_equal(a, b2), "cpu_baseline: the whole-frame entry point differs from the per-plane oracle (plane %d)" % p
             times = []
             c0 = time.perf_counter()
             while len(times) < 5 or (time.perf_counter() - c0 < 10.0 and len(times) < 64):
                 a = time.perf_counter()
-                O.run_frame(views[len(times) % len(views)])
+                runners[len(times) % len(runners)].run()
                 times.append(time.perf_counter() - a)
             med = float(np.median(times))
-            out["cpu_baseline"] = {"value": round(luma_px / med / 1e6, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
-                                   "sample": "median of %d frames of the same workload (2 warm-ups) through oracle/gfw_oracle.c, OpenMP rows on %d threads "
-                                             "(nproc %d); mean %.3f Mpix/s" % (len(times), cores, os.cpu_count() or 0, luma_px * len(times) / sum(times) / 1e6)}
+            # one thread, for the per-thread figure (a bounded sample: 1/16 of the frame's rows would need another entry point; one full frame instead, once)
+            one = O.FrameRunner(checks[0][3], nthreads=1)
+            a = time.perf_counter(); one.run(); t_one = time.perf_counter() - a
+            O.FrameRunner(checks[0][3], nthreads=hw).run()               # (the thread count is a process-wide setting of the OpenMP runtime: back to all)
+            out["cpu_baseline"] = {"value": round(luma_px / med / 1e6, 3), "unit": "Mpix/s", "cores": hw, "kind": "port",
+                                   "per_thread": round(luma_px / med / 1e6 / hw, 4), "one_thread": round(luma_px / t_one / 1e6, 3),
+                                   "sample": "median of %d frames of the same workload (2 warm-ups) through oracle/gfw_oracle.c's whole-frame entry point: row loop instantiated per "
+                                             "(sampler, pixel type), one OpenMP region over all planes, static chunks of 4 rows, %d threads (%s); "
+                                             "mean %.3f Mpix/s; the same frame on ONE thread: %.2f Mpix/s" % (len(times), hw, why, luma_px * len(times) / sum(times) / 1e6, luma_px / t_one / 1e6)}
     for b in extra_bes:
         b.close()
     be.close()

@@ -140,6 +140,8 @@ def bind(lib):
     lib.gfw_set_stream.argtypes = [vp, vp]; lib.gfw_set_stream.restype = i32
     lib.gfw_synchronize.argtypes = [vp]; lib.gfw_synchronize.restype = i32
     lib.gfw_flush.argtypes = [vp]; lib.gfw_flush.restype = i32
+    lib.gfw_import_external_fd.argtypes = [i32, C.c_size_t, C.c_ulonglong, C.POINTER(vp), C.POINTER(vp)]; lib.gfw_import_external_fd.restype = i32
+    lib.gfw_release_external.argtypes = [vp]; lib.gfw_release_external.restype = i32
     lib.gfw_last_backend.argtypes = [vp]; lib.gfw_last_backend.restype = C.c_char_p
     lib.gfw_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]; lib.gfw_get_profile.restype = i32
     lib.gfw_get_profile_frames.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64), i32]; lib.gfw_get_profile_frames.restype = i32
@@ -167,7 +169,7 @@ def bind(lib):
 
 EXPORTS = ["gfw_abi_version", "gfw_list_devices", "gfw_set_device", "gfw_get_info", "gfw_is_buffer_supported",
            "gfw_create", "gfw_destroy", "gfw_undistort_image", "gfw_undistort_frame", "gfw_set_option",
-           "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_flush", "gfw_last_backend", "gfw_get_profile", "gfw_last_error", "gfw_debug_math", "gfw_debug_selftest", "gfw_get_audit", "gfw_pack_matrices", "gfw_checksum64", "gfw_set_quaternion_tracks", "gfw_build_matrices", "gfw_build_matrices_stab", "gfw_set_sync_offsets", "gfw_build_matrices_batch", "gfw_stmap_undistort", "gfw_undistort_points",
+           "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_flush", "gfw_import_external_fd", "gfw_release_external", "gfw_last_backend", "gfw_get_profile", "gfw_last_error", "gfw_debug_math", "gfw_debug_selftest", "gfw_get_audit", "gfw_pack_matrices", "gfw_checksum64", "gfw_set_quaternion_tracks", "gfw_build_matrices", "gfw_build_matrices_stab", "gfw_set_sync_offsets", "gfw_build_matrices_batch", "gfw_stmap_undistort", "gfw_undistort_points",
            "gfw_pixel_type_info", "gfw_undistort_clip", "gfw_jit_status", "gfw_get_profile_frames", "gfw_debug_jit_compile"]
 
 

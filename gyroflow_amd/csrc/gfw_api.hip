@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/gfwarp.h"
+#include "../../include/gfwarp_testing.h"
 #include "gfw_launch.h"
 #include "gfw_frame.h"
 #include "gfw_matrices.h"
@@ -43,6 +44,7 @@ static void set_error(const char *fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
     g_last_error = buf;
 }
+void gfw_set_error_text(const char *text) { g_last_error = text ? text : ""; }      // other translation units of the library (gfw_interop.hip)
 #define HIP_TRY(expr, code)                                                                   \
     do { hipError_t e_ = (expr); if (e_ != hipSuccess) {                                      \
         set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return (code); } } while (0)
@@ -1290,27 +1292,28 @@ int gfw_debug_math(int op, const float *a, const float *b, float *out, size_t n)
     if (!a || !out || n == 0) { set_error("null/empty arrays"); return GFW_ERR_INVALID_ARGUMENT; }
     if (device_count() == 0) { set_error("no HIP device visible"); return GFW_ERR_NO_DEVICE; }
     HIP_TRY(hipSetDevice(g_current_device), GFW_ERR_HIP);
-    float *da = nullptr, *db = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc(&da, n * sizeof(float)), GFW_ERR_HIP);
-    HIP_TRY(hipMalloc(&dout, n * sizeof(float)), GFW_ERR_HIP);
-    if (b) HIP_TRY(hipMalloc(&db, n * sizeof(float)), GFW_ERR_HIP);
-    HIP_TRY(hipMemcpy(da, a, n * sizeof(float), hipMemcpyHostToDevice), GFW_ERR_HIP);
-    if (b) HIP_TRY(hipMemcpy(db, b, n * sizeof(float), hipMemcpyHostToDevice), GFW_ERR_HIP);
-    HIP_TRY(gfw_launch_debug_math(op, da, db, dout, n, nullptr), GFW_ERR_HIP);
-    HIP_TRY(hipMemcpy(out, dout, n * sizeof(float), hipMemcpyDeviceToHost), GFW_ERR_HIP);
-    (void)hipFree(da); (void)hipFree(dout); if (db) (void)hipFree(db);
+    DevBuf da, db, dout;                                   // released on every path
+    struct Release { DevBuf &x, &y, &z; ~Release() { x.release(); y.release(); z.release(); } } release{da, db, dout};
+    HIP_TRY(da.ensure(n * sizeof(float)), GFW_ERR_HIP);
+    HIP_TRY(dout.ensure(n * sizeof(float)), GFW_ERR_HIP);
+    if (b) HIP_TRY(db.ensure(n * sizeof(float)), GFW_ERR_HIP);
+    HIP_TRY(hipMemcpy(da.ptr, a, n * sizeof(float), hipMemcpyHostToDevice), GFW_ERR_HIP);
+    if (b) HIP_TRY(hipMemcpy(db.ptr, b, n * sizeof(float), hipMemcpyHostToDevice), GFW_ERR_HIP);
+    HIP_TRY(gfw_launch_debug_math(op, (const float *)da.ptr, (const float *)db.ptr, (float *)dout.ptr, n, nullptr), GFW_ERR_HIP);
+    HIP_TRY(hipMemcpy(out, dout.ptr, n * sizeof(float), hipMemcpyDeviceToHost), GFW_ERR_HIP);
     return GFW_OK;
 }
 long long gfw_debug_selftest(int test, unsigned long long n, unsigned long long seed) {
     if (device_count() == 0) { set_error("no HIP device visible"); return GFW_ERR_NO_DEVICE; }
     HIP_TRY(hipSetDevice(g_current_device), GFW_ERR_HIP);
     if (test == 2 && n == 0) n = 1ull << 31;
-    unsigned long long *dbad = nullptr, bad = 0;
-    HIP_TRY(hipMalloc(&dbad, sizeof(bad)), GFW_ERR_HIP);
-    HIP_TRY(hipMemset(dbad, 0, sizeof(bad)), GFW_ERR_HIP);
-    HIP_TRY(gfw_launch_debug_selftest(test, n, seed, dbad, nullptr), GFW_ERR_HIP);
-    HIP_TRY(hipMemcpy(&bad, dbad, sizeof(bad), hipMemcpyDeviceToHost), GFW_ERR_HIP);
-    (void)hipFree(dbad);
+    DevBuf dbad, none1, none2;
+    struct Release { DevBuf &x, &y, &z; ~Release() { x.release(); y.release(); z.release(); } } release{dbad, none1, none2};
+    unsigned long long bad = 0;
+    HIP_TRY(dbad.ensure(sizeof(bad)), GFW_ERR_HIP);
+    HIP_TRY(hipMemset(dbad.ptr, 0, sizeof(bad)), GFW_ERR_HIP);
+    HIP_TRY(gfw_launch_debug_selftest(test, n, seed, (unsigned long long *)dbad.ptr, nullptr), GFW_ERR_HIP);
+    HIP_TRY(hipMemcpy(&bad, dbad.ptr, sizeof(bad), hipMemcpyDeviceToHost), GFW_ERR_HIP);
     return (long long)bad;
 }
 }

@@ -272,7 +272,7 @@ enum {
                                         GFW_FLAG_HAS_IBIS_DATA is set in params->flags (get_kernel_flags, mod.rs:226-251,
                                         sets it for every clip that has such data); with 1 the roll's cos/sin are
                                         evaluated on the device with the host libm's own routines (gfw_math.h). */
-    GFW_OPT_KERNEL_VARIANT     = 3,  /* 0 auto; 1 generic per-plane kernel; 2 fused kernel with the exact first pass;
+    GFW_OPT_KERNEL_VARIANT     = 3,  /* (further values: gfwarp_testing.h)  0 auto; 1 generic per-plane kernel; 2 fused kernel with the exact first pass;
                                         3 fused kernel, certified first pass in audit mode (see gfw_get_audit);
                                         16 + bits: timing ablations of the fused kernel (wrong output by design) */
     GFW_OPT_PROFILE            = 4,  /* 1: bracket every warp-kernel launch with hipEvents on the context stream */
@@ -329,6 +329,19 @@ const char *gfw_last_error(void);
  * knows its FrameTransforms ahead of time packs them once, keeps them in HBM and passes the device pointer with
  * GFW_OPT_MATRICES_ON_DEVICE = 2. */
 int   gfw_pack_matrices(const float *rows14, int count, float *rows16);
+
+/* ---- decoder / interop surfaces without the host ("next" row f-4) ----
+ * The reference's zero-copy path imports memory another API owns and maps it to a device pointer of the compute API
+ * (src/core/gpu/wgpu_interop_cuda.rs:181-215: cuImportExternalMemory -> cuExternalMemoryGetMappedBuffer; plane descriptors
+ * src/rendering/zero_copy.rs:67-112; BufferSource::CUDABuffer, src/core/gpu/mod.rs:67-70).  gfw_import_external_fd does the same for a POSIX
+ * file descriptor that names a device allocation (a dma-buf exported by the decoder / VA-API / Vulkan, or another process's
+ * hipMemExportToShareableHandle): `*dev_ptr_out` is a device pointer to `size` bytes, to be used in GFW_BUF_HIP_DEVICE buffer descriptions —
+ * plane offsets and the row pitch are the caller's (`data + offset`, `stride`).  `drm_format_modifier` states the surface layout: only
+ * DRM_FORMAT_MOD_LINEAR (0) can be warped in place, anything else returns GFW_ERR_UNSUPPORTED_BUFFER.  The caller keeps its fd.
+ * gfw_release_external unmaps (after the device has drained). */
+typedef struct gfw_external gfw_external;
+int   gfw_import_external_fd(int fd, size_t size, unsigned long long drm_format_modifier, void **dev_ptr_out, gfw_external **handle_out);
+int   gfw_release_external(gfw_external *handle);
 
 /* Verification helper for frame-sharded clip runs (no reference counterpart; SURVEY.md 8e: one 8-byte checksum per frame,
  * all-gathered across ranks): adds the sum of the u64 words of a device buffer (mod 2^64) to *d_out, enqueued in order
@@ -418,25 +431,14 @@ int   gfw_undistort_points(gfw_ctx *ctx, const gfw_kernel_params *params, const 
                            const float *rotations, int rotation_count, const float *shifts, int index_mode,
                            const double *mesh, size_t mesh_len, float *out, int out_on_device);
 
-/* ---- test hooks (used by tests/test_gpu_math.py; not part of the operator surface) ---------------
- * gfw_debug_math: out[i] = f(a[i], b[i]) evaluated ON THE DEVICE with the kernels' own routines; host arrays.
- *   op 0 gfw_atanf  1 gfw_tanf  2 gfw_atanf_pos  3 lean a/b  4 generic a/b  5 lean sqrt  6 generic sqrt
- *      7 (float)(i32)`as i32`  8 (float)`as u16`  9 round-half-away  10 (float)`as u8`
- * gfw_debug_selftest: compares a lean routine with its generic twin on `n` device-generated operands
- *   (test 0: divide, operands in the proven range; 1: sqrt; 2: atanf_pos vs atanf over ALL non-negative floats
- *   when n == 0) and returns the number of mismatching results (0 expected), or a negative GFW_ERR_*. */
 /* First-pass audit of the fused kernel (GFW_OPT_KERNEL_VARIANT = 3): counters8 = {certified pixels,
  * certified-but-different-from-exact (must stay 0), queued to the exact path, queue overflows,
  * max |approximate - exact| coordinate over certified pixels as f32 bits, addresses outside their buffer (audit mode range-checks),
  * the certificate half-width E of the last frame as f32 bits, 1 spare}.  Call with reset = 1 before
  * the frames to be audited. */
 int   gfw_get_audit(gfw_ctx *ctx, unsigned long long *counters8, int reset);
-/* Build check of the run-time specialisation path without a device: compiles the kernel source embedded in the library for `arch`
- * ("gfx950") with ';'-separated definitions and a bake header; returns the code object's size in bytes (written to out_path when
- * given), -1 on a compile error (log), -2 when libhiprtc.so is absent. */
-long  gfw_debug_jit_compile(const char *arch, const char *defines, const char *bake_header_text, const char *out_path, char *log, size_t cap);
-int   gfw_debug_math(int op, const float *a, const float *b, float *out, size_t n);
-long long gfw_debug_selftest(int test, unsigned long long n, unsigned long long seed);
+/* (test hooks — device-side math probes, the host-side build check of the run-time specialisation path, the timing ablations of
+ * GFW_OPT_KERNEL_VARIANT >= 16 — are declared in include/gfwarp_testing.h: they are not part of the operator surface) */
 
 /* Static tables the reference exposes through PixelType (pixel_formats.rs):
  * bytes per pixel, element count, default_max_value (0 => None). */

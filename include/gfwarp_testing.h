@@ -1,0 +1,35 @@
+/* gfwarp_testing.h — TEST HOOKS of libgfwarp.  Not part of the operator surface (include/gfwarp.h): nothing a binder of the reference's render loop
+ * needs is declared here.  The symbols live in the same shared library so that the GPU tier of the test suite can hold the kernels' own device routines
+ * to libm and to their generic twins (tests/test_gpu_math.py), and so that the CPU tier can build the embedded kernel source without a device
+ * (tests/test_jit_host.py).
+ *
+ * Timing ablations: gfw_set_option(ctx, GFW_OPT_KERNEL_VARIANT, 16 + bits) switches parts of the fused kernel OFF for profiling — bit 1 no first pass,
+ * 2 no luma taps, 4 no chroma, 8 no projection.  THE OUTPUT IS WRONG BY DESIGN; the run-time specialised kernel ignores them (it is never built for an
+ * ablated context). */
+#ifndef GFWARP_TESTING_H
+#define GFWARP_TESTING_H
+#include "gfwarp.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- device-side math probes ----
+ * gfw_debug_math: out[i] = f(a[i], b[i]) evaluated ON THE DEVICE with the kernels' own routines; host arrays.
+ *   op 0 gfw_atanf  1 gfw_tanf  2 gfw_atanf_pos  3 lean a/b  4 generic a/b  5 lean sqrt  6 generic sqrt
+ *      7 (float)(i32)`as i32`  8 (float)`as u16`  9 round-half-away  10 (float)`as u8`
+ * gfw_debug_selftest: compares a lean routine with its generic twin on `n` device-generated operands
+ *   (test 0: divide, operands in the proven range; 1: sqrt; 2: atanf_pos vs atanf over ALL non-negative floats
+ *   when n == 0) and returns the number of mismatching results (0 expected), or a negative GFW_ERR_*. */
+int   gfw_debug_math(int op, const float *a, const float *b, float *out, size_t n);
+long long gfw_debug_selftest(int test, unsigned long long n, unsigned long long seed);
+
+/* Build check of the run-time specialisation path without a device: compiles the kernel source embedded in the library for `arch`
+ * ("gfx950") with ';'-separated definitions and a bake header; returns the code object's size in bytes (written to out_path when
+ * given), -1 on a compile error (log), -2 when libhiprtc.so is absent. */
+long  gfw_debug_jit_compile(const char *arch, const char *defines, const char *bake_header_text, const char *out_path, char *log, size_t cap);
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFWARP_TESTING_H */

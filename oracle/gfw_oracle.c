@@ -847,7 +847,7 @@ static opt2 undistort_coord(float opx, float opy, const wctx *c) {
 }
 
 /* ------------------------------------------------ PixelType load / store */
-static inline v4 px_to_float(int t, const uint8_t *b) {  /* pixel_formats.rs to_float */
+static inline __attribute__((always_inline)) v4 px_to_float(int t, const uint8_t *b) {  /* pixel_formats.rs to_float */
     v4 r = {0, 0, 0, 0};
     uint16_t h[4]; float f[4];
     switch (t) {
@@ -867,7 +867,7 @@ static inline v4 px_to_float(int t, const uint8_t *b) {  /* pixel_formats.rs to_
     }
     return r;
 }
-static inline void px_from_float(int t, v4 v, uint8_t *b) {  /* pixel_formats.rs from_float */
+static inline __attribute__((always_inline)) void px_from_float(int t, v4 v, uint8_t *b) {  /* pixel_formats.rs from_float */
     uint16_t h[4]; float f[4];
     switch (t) {
     case GFW_PIX_LUMA8:  b[0] = f2u8(v.x); break;
@@ -932,7 +932,7 @@ static float bc2(float x, const KP *p) {
 }
 
 /* cpu_undistort.rs:329-419 */
-static v4 sample_input_at(int I, int t, float uvx, float uvy, const float *jac, const uint8_t *input, size_t in_len, const KP *p, v4 bg, int *oob) {
+static inline __attribute__((always_inline)) v4 sample_input_at(int I, int t, float uvx, float uvy, const float *jac, const uint8_t *input, size_t in_len, const KP *p, v4 bg, int *oob) {
     v4 sum = {0, 0, 0, 0};
     const int bpp = p->bytes_per_pixel;
     if (I > 8) {
@@ -1020,47 +1020,30 @@ static void wctx_init(wctx *c, const KP *p, int model, int digital, const float 
     c->out_f[1] = p->f[1] / p->fov / factor;
 }
 
-/* ------------------------------------------------------------ public API */
-/* undistort_image_cpu::<I,T>: cpu_undistort.rs:233-633.
- * I = params->interpolation (set from Stabilization.interpolation at mod.rs:266,706-714).
- * Returns 1 (true) on success, 0 when a buffer is missing (the `false` arms
- * at :627-632), -1 if the reference would have panicked on an out-of-range
- * slice index. nthreads <= 0: all cores (rayon par_chunks_mut, :543). */
-int gfw_oracle_undistort_image(const gfw_buffers *buffers, const gfw_kernel_params *p, int pixel_type,
-                               int distortion_model, int digital_lens,
-                               const float *matrices, const float *mesh_f32, size_t mesh_len, int nthreads)
-{
-    if (!buffers || !p || pixel_type < 0 || pixel_type >= GFW_PIX_COUNT) return 0;
-    if (buffers->input.kind != GFW_BUF_HOST || buffers->output.kind != GFW_BUF_HOST) return 0;
-    if (buffers->output.stride <= 0) return 0;                            /* :534-537 */
-    if (p->bytes_per_pixel != PIX_BPP[pixel_type]) return -1;             /* assert_eq! :541 */
-    const uint8_t *input = (const uint8_t *)buffers->input.data;
-    uint8_t *output = (uint8_t *)buffers->output.data;
-    const size_t in_len = buffers->input.len, out_len = buffers->output.len;
-    const int I = p->interpolation;
-    const int t = pixel_type;
-    const int bpp = p->bytes_per_pixel;
+/* ------------------------------------------------------------ the row loop */
+/* Rows [y0, y1) of one plane: the body of undistort_image_cpu::<I,T>'s par_chunks_mut closure (cpu_undistort.rs:543-626).
+ * `I` and `t` reach every use as arguments of an always-inline function: called with literals (WARP_ROWS_INST below) the sampler's tap count and
+ * the pixel type's load / store fold at compile time, which is what the Rust original's monomorphisation over <I, T> does; called with run-time
+ * values it is the generic form.  Returns the out-of-bounds flag. */
+typedef struct {
+    const gfw_kernel_params *p; wctx c;
+    const uint8_t *input; size_t in_len; uint8_t *output; size_t out_len, ostride;
+    int t, I, bpp; int64_t rows;
+} plane_job;
 
-    double *mesh = NULL;
-    if (mesh_len) { mesh = (double *)malloc(mesh_len * sizeof(double)); for (size_t i = 0; i < mesh_len; ++i) mesh[i] = (double)mesh_f32[i]; }  /* :539 */
-    wctx c; wctx_init(&c, p, distortion_model, digital_lens, matrices, mesh, mesh_len);
-
+static inline __attribute__((always_inline)) int warp_rows(const int I, const int t, const plane_job *J, int64_t y0, int64_t y1) {
+    const gfw_kernel_params *p = J->p;
+    const wctx *c = &J->c;
+    const uint8_t *input = J->input; const size_t in_len = J->in_len;
+    const size_t ostride = J->ostride, out_len = J->out_len;
+    const int bpp = J->bpp;
     v4 bg = { p->background[0] * p->max_pixel_value, p->background[1] * p->max_pixel_value,
               p->background[2] * p->max_pixel_value, p->background[3] * p->max_pixel_value };     /* :523 */
     const int fill_bg = (p->flags & 4) == 4, fix_range = (p->flags & 1) == 1, is_y = p->plane_index == 0;
-
-    const size_t ostride = (size_t)buffers->output.stride;               /* par_chunks_mut(buffers.output.size.2) */
-    const int64_t rows = (int64_t)((out_len + ostride - 1) / ostride);
     int oob_any = 0;
-#ifdef _OPENMP
-    if (nthreads > 0) omp_set_num_threads(nthreads);
-#else
-    (void)nthreads;
-#endif
-    #pragma omp parallel for schedule(dynamic, 4) reduction(|:oob_any)
-    for (int64_t y = 0; y < rows; ++y) {
+    for (int64_t y = y0; y < y1; ++y) {
         size_t row_len = ostride; if ((size_t)(y + 1) * ostride > out_len) row_len = out_len - (size_t)y * ostride;
-        uint8_t *row = output + (size_t)y * ostride;
+        uint8_t *row = J->output + (size_t)y * ostride;
         const int64_t cols = (int64_t)(row_len / (size_t)bpp);  /* a trailing partial chunk can never be a valid pixel */
         for (int64_t x = 0; x < cols; ++x) {
             float opx = map_coord((float)x, (float)p->output_rect[0], (float)(p->output_rect[0] + p->output_rect[2]), 0.0f, (float)p->output_width);
@@ -1070,13 +1053,13 @@ int gfw_oracle_undistort_image(const gfw_buffers *buffers, const gfw_kernel_para
             v4 pixel = bg;
             if (fill_bg) { px_from_float(t, bg, pix_out); continue; }
             int oob = 0;
-            opt2 uv = undistort_coord((float)x, (float)y, &c);
+            opt2 uv = undistort_coord((float)x, (float)y, c);
             if (uv.ok) {
                 float jac[4] = {1.0f, 0.0f, 0.0f, 1.0f};
                 if (I > 8) {                                               /* :567-572 */
                     const float eps = 0.01f;
-                    opt2 a = undistort_coord((float)x + eps, (float)y, &c);
-                    opt2 b = undistort_coord((float)x, (float)y + eps, &c);
+                    opt2 a = undistort_coord((float)x + eps, (float)y, c);
+                    opt2 b = undistort_coord((float)x, (float)y + eps, c);
                     float xyx0 = (a.ok ? a.x : 0.0f) - uv.x, xyx1 = (a.ok ? a.y : 0.0f) - uv.y;
                     float xyy0 = (b.ok ? b.x : 0.0f) - uv.x, xyy1 = (b.ok ? b.y : 0.0f) - uv.y;
                     jac[0] = xyx0 / eps; jac[1] = xyy0 / eps; jac[2] = xyx1 / eps; jac[3] = xyy1 / eps;
@@ -1120,7 +1103,99 @@ int gfw_oracle_undistort_image(const gfw_buffers *buffers, const gfw_kernel_para
             oob_any |= oob;
         }
     }
+    return oob_any;
+}
+/* the instantiations a render meets: the three LUT samplers x the pixel types of the render loop's plane table (rendering/mod.rs:565-649);
+ * everything else (EWA, three-channel pixels, RGBAf16 ...) takes the generic form */
+typedef int (*warp_rows_fn)(const plane_job *, int64_t, int64_t);
+#define WARP_ROWS_INST(I_, T_) static int warp_rows_##I_##_##T_(const plane_job *J, int64_t y0, int64_t y1) { return warp_rows(I_, T_, J, y0, y1); }
+#define WARP_ROWS_TYPES(I_) WARP_ROWS_INST(I_, GFW_PIX_LUMA8) WARP_ROWS_INST(I_, GFW_PIX_LUMA16) WARP_ROWS_INST(I_, GFW_PIX_UV8) WARP_ROWS_INST(I_, GFW_PIX_UV16) \
+    WARP_ROWS_INST(I_, GFW_PIX_RGBA8) WARP_ROWS_INST(I_, GFW_PIX_RGBA16) WARP_ROWS_INST(I_, GFW_PIX_RGBAF) WARP_ROWS_INST(I_, GFW_PIX_R32F)
+WARP_ROWS_TYPES(2) WARP_ROWS_TYPES(4) WARP_ROWS_TYPES(8)
+static int warp_rows_generic(const plane_job *J, int64_t y0, int64_t y1) { return warp_rows(J->I, J->t, J, y0, y1); }
+static warp_rows_fn warp_rows_pick(int I, int t) {
+    if (getenv("GFW_ORACLE_GENERIC")) return warp_rows_generic;          /* tests: the generic form and the instantiations must agree */
+#define WARP_ROWS_CASE(I_, T_) if (I == I_ && t == T_) return warp_rows_##I_##_##T_;
+#define WARP_ROWS_CASES(I_) WARP_ROWS_CASE(I_, GFW_PIX_LUMA8) WARP_ROWS_CASE(I_, GFW_PIX_LUMA16) WARP_ROWS_CASE(I_, GFW_PIX_UV8) WARP_ROWS_CASE(I_, GFW_PIX_UV16) \
+    WARP_ROWS_CASE(I_, GFW_PIX_RGBA8) WARP_ROWS_CASE(I_, GFW_PIX_RGBA16) WARP_ROWS_CASE(I_, GFW_PIX_RGBAF) WARP_ROWS_CASE(I_, GFW_PIX_R32F)
+    WARP_ROWS_CASES(2) WARP_ROWS_CASES(4) WARP_ROWS_CASES(8)
+    return warp_rows_generic;
+}
+/* validation of one plane's call + its job; 1 ok, 0 / -1 as gfw_oracle_undistort_image documents */
+static int plane_job_init(plane_job *J, const gfw_buffers *buffers, const gfw_kernel_params *p, int pixel_type, int model, int digital, const float *matrices,
+                          const double *mesh, size_t mesh_len) {
+    if (!buffers || !p || pixel_type < 0 || pixel_type >= GFW_PIX_COUNT) return 0;
+    if (buffers->input.kind != GFW_BUF_HOST || buffers->output.kind != GFW_BUF_HOST) return 0;
+    if (buffers->output.stride <= 0) return 0;                            /* :534-537 */
+    if (p->bytes_per_pixel != PIX_BPP[pixel_type]) return -1;             /* assert_eq! :541 */
+    J->p = p; J->input = (const uint8_t *)buffers->input.data; J->output = (uint8_t *)buffers->output.data;
+    J->in_len = buffers->input.len; J->out_len = buffers->output.len;
+    J->I = p->interpolation; J->t = pixel_type; J->bpp = p->bytes_per_pixel;
+    J->ostride = (size_t)buffers->output.stride;                          /* par_chunks_mut(buffers.output.size.2) */
+    J->rows = (int64_t)((J->out_len + J->ostride - 1) / J->ostride);
+    wctx_init(&J->c, p, model, digital, matrices, mesh, mesh_len);
+    return 1;
+}
+
+/* ------------------------------------------------------------ public API */
+/* undistort_image_cpu::<I,T>: cpu_undistort.rs:233-633.
+ * I = params->interpolation (set from Stabilization.interpolation at mod.rs:266,706-714).
+ * Returns 1 (true) on success, 0 when a buffer is missing (the `false` arms
+ * at :627-632), -1 if the reference would have panicked on an out-of-range
+ * slice index. nthreads <= 0: all cores (rayon par_chunks_mut, :543). */
+int gfw_oracle_undistort_image(const gfw_buffers *buffers, const gfw_kernel_params *p, int pixel_type,
+                               int distortion_model, int digital_lens,
+                               const float *matrices, const float *mesh_f32, size_t mesh_len, int nthreads)
+{
+    double *mesh = NULL;
+    if (mesh_len) { mesh = (double *)malloc(mesh_len * sizeof(double)); for (size_t i = 0; i < mesh_len; ++i) mesh[i] = (double)mesh_f32[i]; }  /* :539 */
+    plane_job J;
+    const int st = plane_job_init(&J, buffers, p, pixel_type, distortion_model, digital_lens, matrices, mesh, mesh_len);
+    if (st != 1) { free(mesh); return st; }
+    const warp_rows_fn fn = warp_rows_pick(J.I, J.t);
+    int oob_any = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+    #pragma omp parallel for schedule(dynamic, 4) reduction(|:oob_any)
+    for (int64_t y = 0; y < J.rows; ++y) oob_any |= fn(&J, y, y + 1);
     free(mesh);
+    return oob_any ? -1 : 1;
+}
+
+/* The planes of one frame as the CPU BASELINE runs them (bench.py's cpu_baseline leg): the render loop issues the planes one process_pixels call after the
+ * other, each a rayon par_chunks_mut over its rows (work stealing over all cores); here the rows of all planes form ONE parallel region, chunks of
+ * `chunk` rows dealt round-robin (static: no shared counter for hundreds of threads to fight over, and cheap and dear regions of the frame interleave
+ * across the threads).  Same arithmetic, same per-plane results as gfw_oracle_undistort_image — the tests hold both to the reference's fixture. */
+int gfw_oracle_undistort_frame(int nplanes, const gfw_buffers *buffers, const gfw_kernel_params *params, const int *pixel_types,
+                               int distortion_model, int digital_lens, const float *matrices, int nthreads, int chunk)
+{
+    if (nplanes < 1 || nplanes > 8 || !buffers || !params || !pixel_types) return 0;
+    plane_job J[8]; warp_rows_fn fn[8]; int64_t first_chunk[9];
+    if (chunk < 1) chunk = 4;
+    first_chunk[0] = 0;
+    for (int i = 0; i < nplanes; ++i) {
+        const int st = plane_job_init(&J[i], &buffers[i], &params[i], pixel_types[i], distortion_model, digital_lens, matrices, NULL, 0);
+        if (st != 1) return st;
+        fn[i] = warp_rows_pick(J[i].I, J[i].t);
+        first_chunk[i + 1] = first_chunk[i] + (J[i].rows + chunk - 1) / chunk;
+    }
+    int oob_any = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+    #pragma omp parallel for schedule(static, 1) reduction(|:oob_any)
+    for (int64_t k = 0; k < first_chunk[nplanes]; ++k) {
+        int i = 0;
+        while (k >= first_chunk[i + 1]) ++i;
+        const int64_t y0 = (k - first_chunk[i]) * chunk;
+        const int64_t y1 = y0 + chunk < J[i].rows ? y0 + chunk : J[i].rows;
+        oob_any |= fn[i](&J[i], y0, y1);
+    }
     return oob_any ? -1 : 1;
 }
 

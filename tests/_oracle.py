@@ -34,6 +34,8 @@ def lib():
         L.gfw_oracle_stmap_undistort.restype = C.c_int
         L.gfw_oracle_undistort_points.argtypes = [C.POINTER(abi.KernelParams), C.c_int, C.c_int, vp, C.c_size_t, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_size_t, vp]
         L.gfw_oracle_undistort_points.restype = C.c_int
+        L.gfw_oracle_undistort_frame.argtypes = [C.c_int, C.POINTER(abi.Buffers), C.POINTER(abi.KernelParams), C.POINTER(C.c_int), C.c_int, C.c_int, vp, C.c_int, C.c_int]
+        L.gfw_oracle_undistort_frame.restype = C.c_int
         L.gfw_oracle_libm.argtypes = [C.c_int, vp, vp, C.c_size_t]
         L.gfw_oracle_num_threads.restype = C.c_int
         _lib = L
@@ -87,6 +89,36 @@ def run_frame(frame, nthreads=0):
         assert st == 1, "oracle returned %d" % st
         outs.append(dst)
     return outs
+
+
+class FrameRunner:
+    """All planes of a frame through gfw_oracle_undistort_frame (ONE parallel region over the rows of every plane, static chunks): the form bench.py times as
+    the CPU baseline.  Everything is marshalled once; ``run()`` is the timed call, ``outs`` the planes it wrote (uninitialised until the first run, so that
+    the first touch of every output page happens on the thread that will keep writing it)."""
+
+    def __init__(self, frame, nthreads=0, chunk=4):
+        n = len(frame.planes)
+        self.outs = [np.empty_like(pl["dst"]) for pl in frame.planes]
+        self.fill = [pl["dst"] for pl in frame.planes]
+        self.bufs = (abi.Buffers * n)(*[host_buffers(pl["src"], pl["size"], o, pl["out_size"]) for pl, o in zip(frame.planes, self.outs)])
+        self.prm = (abi.KernelParams * n)(*[pl["params"] for pl in frame.planes])
+        self.typ = (C.c_int * n)(*[abi.PIXEL_TYPES[pl["pixel_type"]][0] for pl in frame.planes])
+        self.m = np.ascontiguousarray(frame.matrices, dtype=np.float32)
+        self.args = (n, self.bufs, self.prm, self.typ, frame.model, frame.digital, self.m.ctypes.data, nthreads, chunk)
+        self.fn = lib().gfw_oracle_undistort_frame
+
+    def run(self):
+        st = self.fn(*self.args)
+        assert st == 1, "oracle returned %d" % st
+        return self.outs
+
+
+def run_frame_fast(frame, nthreads=0):
+    """run_frame through the whole-frame entry point (bytes the warp never writes are taken from the frame's ``dst`` like run_frame's copies)."""
+    r = FrameRunner(frame, nthreads)
+    for o, f in zip(r.outs, r.fill):
+        o[...] = f
+    return r.run()
 
 
 def stmap_undistort(params, model, digital, matrices, width, height, nthreads=0):

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_functions():
-    txt = open(os.path.join(ROOT, "include", "gfwarp.h")).read()
+    txt = open(os.path.join(ROOT, "include", "gfwarp.h")).read() + open(os.path.join(ROOT, "include", "gfwarp_testing.h")).read()     # operator surface + test hooks
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(gfw_[a-z0-9_]+)\s*\(", txt)))
 
