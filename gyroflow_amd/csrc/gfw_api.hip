@@ -118,6 +118,7 @@ struct gfw_ctx {
     // run-time specialised kernel (gfw_jit.hip): 0 off; 1 build in the background once the context has seen kJitAfter frames of one
     // clip, warp ahead-of-time meanwhile; 2 build at the first frame and wait for it
     int jit_mode = 1;
+    bool dry = false;                              // gfw_debug_jit_key: argument blocks are built, nothing touches a device
     std::string arch;                              // gcnArchName of the device
     std::string jit_header; int jit_seen = 0;      // bake header of the frames being seen, and how many in a row
     GfwYuvArgs jit_key; int jit_key_misc[8] = {}; bool jit_key_valid = false;      // the clip those frames belong to (argument block, per-frame fields blanked)
@@ -577,9 +578,11 @@ static int p1_prepare_table(gfw_ctx *c, const gfw_kernel_params &p, float rho_ma
     }
     tab[N] = float2{(float)s_prev, 0.0f};
     if (!(etab == etab) || !(smax == smax)) { c->p1_valid = false; return GFW_OK; }
-    HIP_TRY(c->d_p1_table.ensure((N + 1) * sizeof(float2)), GFW_ERR_HIP);
-    HIP_TRY(hipMemcpyAsync(c->d_p1_table.ptr, tab.data(), (N + 1) * sizeof(float2), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
-    HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);      // `tab` is a stack-lifetime source
+    if (!c->dry) {
+        HIP_TRY(c->d_p1_table.ensure((N + 1) * sizeof(float2)), GFW_ERR_HIP);
+        HIP_TRY(hipMemcpyAsync(c->d_p1_table.ptr, tab.data(), (N + 1) * sizeof(float2), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
+        HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);      // `tab` is a stack-lifetime source
+    }
     memcpy(c->p1_k, p.k, sizeof(c->p1_k));
     c->p1_rho_max = rho_max; c->p1_etab = etab; c->p1_smax = smax; c->p1_valid = true;
     return GFW_OK;
@@ -708,10 +711,11 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
         if ((int64_t)b.input.height * p.stride >= (1ll << 31) || (int64_t)b.output.height * b.output.stride >= (1ll << 31)) return false;   // 32-bit offsets
         if (p.stride >= (1 << 23) || b.output.stride >= (1 << 23) || b.input.height >= (1 << 23) || b.output.height >= (1 << 23)) return false;   // 24-bit row-offset multiplies
     }
-    // stretch divisions (cpu_undistort.rs:222-223) other than "skipped" (<= 0.001) or the identity x/1 go the generic way
-    if ((p0.input_horizontal_stretch > 0.001f && p0.input_horizontal_stretch != 1.0f) ||
-        (p0.input_vertical_stretch > 0.001f && p0.input_vertical_stretch != 1.0f)) return false;
+    // stretch divisions (cpu_undistort.rs:222-223): "skipped" (<= 0.001) and the identity x / 1 cost nothing; a real divisor (anamorphic lens profiles) is an
+    // IEEE division at the end of the projection, served since round 4 (not together with the lens-correction blend, whose inverse the kernel does not stretch)
     if (!(p0.input_horizontal_stretch == p0.input_horizontal_stretch) || !(p0.input_vertical_stretch == p0.input_vertical_stretch)) return false;
+    const bool hdiv = p0.input_horizontal_stretch > 0.001f && p0.input_horizontal_stretch != 1.0f, vdiv = p0.input_vertical_stretch > 0.001f && p0.input_vertical_stretch != 1.0f;
+    if ((hdiv || vdiv) && ((extras & 8) || !std::isfinite(p0.input_horizontal_stretch) || !std::isfinite(p0.input_vertical_stretch))) return false;
     for (int i = 0; i < 12; ++i) { const float k = p0.k[i]; if (!(k == k) || fabsf(k) > 1024.0f) return false; }
     if (!std::isfinite(p0.f[0]) || !std::isfinite(p0.f[1]) || !std::isfinite(p0.c[0]) || !std::isfinite(p0.c[1])) return false;
     if (!(p0.translation2d[0] == p0.translation2d[0]) || !(p0.translation2d[1] == p0.translation2d[1])) return false;
@@ -751,6 +755,10 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     const float Wf = (float)p0.width, Hf = (float)p0.height;
     if (!map_const_valid(Wf) || !map_const_valid(Hf)) return false;
 
+    // bicubic / Lanczos4 taps of single-channel integer planes are fetched as aligned dwords at 32-bit offsets from the plane base (taps_inside): the base itself
+    // must be dword aligned (every allocator's is; a caller's odd sub-buffer goes the per-plane way)
+    if (p0.interpolation != 2 && bytes_per_sample != 4)
+        for (int i = 0; i < nplanes; ++i) if ((uintptr_t)launches[i].src & 3u) return false;
     memset(&Y, 0, sizeof(Y));
     for (int i = 0; i < nplanes; ++i) {
         GfwYuvPlane &P = Y.pl[i];
@@ -773,7 +781,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     Y.extras = extras;
     Y.k_all_zero = (p0.k[0] == 0.0f && p0.k[1] == 0.0f && p0.k[2] == 0.0f && p0.k[3] == 0.0f) ? 1 : 0;
     Y.hstretch = p0.input_horizontal_stretch; Y.vstretch = p0.input_vertical_stretch;
-    Y.hstretch_div = 0; Y.vstretch_div = 0;
+    Y.hstretch_div = hdiv ? 1 : 0; Y.vstretch_div = vdiv ? 1 : 0;
     memcpy(Y.f, p0.f, sizeof(Y.f)); memcpy(Y.c, p0.c, sizeof(Y.c)); memcpy(Y.k, p0.k, sizeof(Y.k));
     Y.t2[0] = p0.translation2d[0]; Y.t2[1] = p0.translation2d[1];
     Y.r_limit_sq = p0.r_limit * p0.r_limit;
@@ -873,6 +881,7 @@ static std::string bake_header(const GfwYuvArgs &Y) {
     bake_i(o, "hrs", Y.hrs); bake_i(o, "model", Y.model); bake_i(o, "k_all_zero", Y.k_all_zero);
     bake_i(o, "background_mode", Y.background_mode); bake_i(o, "extras", Y.extras); bake_i(o, "ablate", 0);
     bake_i(o, "digital", (Y.extras & 2) ? Y.common.digital : 0);
+    bake_i(o, "hstretch_div", Y.hstretch_div); bake_i(o, "vstretch_div", Y.vstretch_div); bake_f(o, "hstretch", Y.hstretch); bake_f(o, "vstretch", Y.vstretch);
     o += "#define GFW_BK_audit ((unsigned long long *)nullptr)\n";
     char nm[48];
     for (int i = 0; i < 2; ++i) { snprintf(nm, sizeof(nm), "f_%d", i); bake_f(o, nm, Y.f[i]); snprintf(nm, sizeof(nm), "c_%d", i); bake_f(o, nm, Y.c[i]);
@@ -911,6 +920,31 @@ static int jit_waves(int n0, int matrix_count, int jit_model, int extras) {
     if (jit_model < 0 && (extras & (16 | 32))) return 6;
     return (n0 == 1 && matrix_count > 1) ? 8 : 7;
 }
+// The definition list of a specialised build (with the bake header: everything that names the kernel)
+static std::vector<std::string> jit_defs(const GfwYuvArgs &Y, int bps, int taps, int n0, int dw, int dh, bool interleaved, bool fast1, int jit_model, int waves) {
+    (void)Y;
+    char b[64];
+    std::vector<std::string> defs;
+    snprintf(b, sizeof(b), "GFW_FRAME_KIND=%d", bps); defs.push_back(b);
+    snprintf(b, sizeof(b), "GFW_FRAME_TAPS=%d", taps); defs.push_back(b);
+    snprintf(b, sizeof(b), "GFW_JIT_WAVES=%d", waves); defs.push_back(b);
+    snprintf(b, sizeof(b), "GFW_JIT_MODEL=%d", jit_model); defs.push_back(b);
+    defs.push_back(bps == 1 ? "GFW_JIT_T=uint8_t" : bps == 2 ? "GFW_JIT_T=uint16_t" : "GFW_JIT_T=float");
+    snprintf(b, sizeof(b), "GFW_JIT_N0=%d", n0); defs.push_back(b);
+    snprintf(b, sizeof(b), "GFW_JIT_DW=%d", dw); defs.push_back(b);
+    snprintf(b, sizeof(b), "GFW_JIT_DH=%d", dh); defs.push_back(b);
+    snprintf(b, sizeof(b), "GFW_JIT_IL=%d", interleaved ? 1 : 0); defs.push_back(b);
+    snprintf(b, sizeof(b), "GFW_JIT_RB=%d", gfw_yuv_rows_per_lane(fast1, 0)); defs.push_back(b);
+    snprintf(b, sizeof(b), "GFW_JIT_FAST1=%d", fast1 ? 1 : 0); defs.push_back(b);
+    if (const char *extra = getenv("GFW_JIT_DEFS")) {                                    // experiments: further ';'-separated definitions for the build
+        std::string cur;
+        for (const char *p = extra; ; ++p) { if (*p == ';' || *p == 0) { if (!cur.empty()) defs.push_back(cur); cur.clear(); if (!*p) break; } else cur += *p; }
+    }
+    return defs;
+}
+static int jit_model_of(const GfwYuvArgs &Y) {
+    return (Y.model == GFW_MODEL_OPENCV_FISHEYE && (Y.extras & ~2) == 0) ? GFW_MODEL_OPENCV_FISHEYE : ((Y.extras & (16 | 32)) ? -2 : -1);
+}
 // The specialised kernel for this frame's arguments, or nullptr (not eligible / not wanted / not ready / failed): the caller then
 // launches the ahead-of-time kernel.
 static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps, int n0, int dw, int dh, bool interleaved, bool fast1, int *grid) {
@@ -918,8 +952,7 @@ static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps,
     // projection (MODEL = 1); everything else the generic-model body with the lens model, the digital lens and the feature bits as literals
     // (MODEL = -1, or -2 with background mode 3 / the Sony mesh) — the run-time switch over 14 lens models folds to the one in use
     if (c->jit_mode == 0 || c->kernel_variant != 0 || Y.audit || Y.ablate) return nullptr;
-    const int jit_model = (Y.model == GFW_MODEL_OPENCV_FISHEYE && (Y.extras & ~2) == 0) ? GFW_MODEL_OPENCV_FISHEYE : ((Y.extras & (16 | 32)) ? -2 : -1);
-    if (!gfw_jit_available()) { c->jit_info.state = GFW_JIT_UNAVAILABLE; c->jit_info.log = "libhiprtc.so not found"; return nullptr; }
+    const int jit_model = jit_model_of(Y);
     // the same clip as the previous frame?  Compared on the argument block itself with its per-frame fields blanked (the header text and the
     // cache lookup cost ~15 us of host time, a frame's worth of validation): header, key and function are rebuilt only when it changes
     GfwYuvArgs K = Y;
@@ -940,23 +973,7 @@ static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps,
     }
     if (c->jit_mode == 1 && c->jit_seen < gfw_ctx::kJitAfter) return nullptr;          // one or two frames are not a clip
     const int waves = jit_waves(n0, Y.matrix_count, jit_model, Y.extras);
-    char b[64];
-    std::vector<std::string> defs;
-    snprintf(b, sizeof(b), "GFW_FRAME_KIND=%d", bps); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_FRAME_TAPS=%d", taps); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_JIT_WAVES=%d", waves); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_JIT_MODEL=%d", jit_model); defs.push_back(b);
-    defs.push_back(bps == 1 ? "GFW_JIT_T=uint8_t" : bps == 2 ? "GFW_JIT_T=uint16_t" : "GFW_JIT_T=float");
-    snprintf(b, sizeof(b), "GFW_JIT_N0=%d", n0); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_JIT_DW=%d", dw); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_JIT_DH=%d", dh); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_JIT_IL=%d", interleaved ? 1 : 0); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_JIT_RB=%d", gfw_yuv_rows_per_lane(fast1, 0)); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_JIT_FAST1=%d", fast1 ? 1 : 0); defs.push_back(b);
-    if (const char *extra = getenv("GFW_JIT_DEFS")) {                                    // experiments: further ';'-separated definitions for the build
-        std::string cur;
-        for (const char *p = extra; ; ++p) { if (*p == ';' || *p == 0) { if (!cur.empty()) defs.push_back(cur); cur.clear(); if (!*p) break; } else cur += *p; }
-    }
+    const std::vector<std::string> defs = jit_defs(Y, bps, taps, n0, dw, dh, interleaved, fast1, jit_model, waves);
     hipFunction_t fn = gfw_jit_get(c->device, c->arch, defs, c->jit_header, c->jit_mode == 2, &c->jit_info);
     if (!fn) { c->jit_dead = c->jit_info.state == GFW_JIT_FAILED || c->jit_info.state == GFW_JIT_UNAVAILABLE; return nullptr; }
     int g = c->tune_grid > 0 ? c->tune_grid : c->num_cus * waves;
@@ -1337,6 +1354,38 @@ extern "C" long gfw_debug_jit_compile(const char *arch, const char *defines, con
     if (log && cap) snprintf(log, cap, "%s", lg.c_str());
     if (n > 0 && out_path && *out_path) { if (FILE *f = fopen(out_path, "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); } }
     return n;
+}
+
+// Build-time helper of the shipped kernel cache (tools/build_jit_cache.py; no device involved): what the library WOULD specialise a frame of these planes to —
+// the ';'-separated definition list, the bake header and the cache file name of the kernel (gfw_jit.hip) — exactly as run_planes / jit_for derive them on a
+// device, with `matrices_on_device` as the context option would be set (2: device-resident tables, the first pass's table range from the intrinsics).
+extern "C" int gfw_debug_jit_key(int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params, const int *pixel_types, int distortion_model, int digital_lens,
+                                 const float *h_matrices, int matrix_count, int matrices_on_device, const char *arch,
+                                 char *defs_out, size_t defs_cap, char *header_out, size_t header_cap, char *name_out, size_t name_cap) {
+    if (!planes || !params || !pixel_types || !arch || nplanes < 1 || nplanes > 4) { set_error("bad arguments"); return GFW_ERR_INVALID_ARGUMENT; }
+    for (int i = 0; i < nplanes; ++i) {
+        if (pixel_types[i] < 0 || pixel_types[i] >= GFW_PIX_COUNT) { set_error("plane %d: unknown pixel type", i); return GFW_ERR_INVALID_ARGUMENT; }
+        const int rc = validate_plane(&planes[i], &params[i], pixel_types[i]);
+        if (rc != GFW_OK) return rc;
+    }
+    gfw_ctx c;
+    c.dry = true; c.model = distortion_model; c.digital = digital_lens; c.matrices_on_device = matrices_on_device; c.arch = arch;
+    GfwPlane launches[4];
+    memset(launches, 0, sizeof(launches));
+    for (int i = 0; i < nplanes; ++i) { launches[i].src = (const uint8_t *)planes[i].input.data; launches[i].dst = (uint8_t *)planes[i].output.data; }
+    GfwYuvArgs Y;
+    int bps = 0, n0 = 1, dw = 1, dh = 1; bool interleaved = false, fast1 = false;
+    if (!build_yuv_args(&c, nplanes, planes, params, pixel_types, launches, matrices_on_device ? nullptr : h_matrices, matrix_count, 0, Y, bps, n0, dw, dh, interleaved, fast1)) {
+        set_error("not a frame the fused kernel serves"); return GFW_ERR_UNSUPPORTED_BUFFER; }
+    fill_common(&c, &params[0], nullptr, nullptr, 0, Y.common);
+    const int jit_model = jit_model_of(Y);
+    const std::vector<std::string> defs = jit_defs(Y, bps, params[0].interpolation, n0, dw, dh, interleaved, fast1, jit_model, jit_waves(n0, Y.matrix_count, jit_model, Y.extras));
+    std::string d;
+    for (const std::string &x : defs) { if (!d.empty()) d += ";"; d += x; }
+    const std::string header = bake_header(Y), name = gfw_jit_cache_name(arch, defs, header);
+    if (d.size() + 1 > defs_cap || header.size() + 1 > header_cap || name.size() + 1 > name_cap) { set_error("output buffers too small"); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
+    memcpy(defs_out, d.c_str(), d.size() + 1); memcpy(header_out, header.c_str(), header.size() + 1); memcpy(name_out, name.c_str(), name.size() + 1);
+    return GFW_OK;
 }
 
 extern "C" int gfw_checksum64(gfw_ctx *c, const void *d_buf, size_t bytes, unsigned long long *d_out) {

@@ -84,6 +84,12 @@
 #ifndef GFW_FASTROW
 #define GFW_FASTROW 1            // the branch-free lane-row of phase 3 (rd_lean_nobranch + one `__any` / `__all` per stage); 0: the per-pixel divergent code only (A/B)
 #endif
+#ifndef GFW_TAP_ROW_UNROLL
+#define GFW_TAP_ROW_UNROLL(I) ((I) >= 8 ? 2 : 2)        // tap rows of a bicubic / Lanczos4 sample in flight (registers against loads in flight)
+#endif
+#ifndef GFW_FASTROW_LUT
+#define GFW_FASTROW_LUT 1        // the branch-free lane-row for the bicubic / Lanczos4 instantiations too (projection + one interior vote; the tap loops are the old ones)
+#endif
 #ifndef GFW_FASTROW_JOINT
 #define GFW_FASTROW_JOINT 1      // a lane's two pixels through the projection side by side (one basic block, one small-angle vote) instead of one after the other
 #endif
@@ -131,10 +137,10 @@ __device__ __forceinline__ bool gfw_any(bool p) { return __builtin_amdgcn_ballot
 #if defined(GFW_HOST_INTERPRETER)
 typedef bool GfwVote;
 #define GFW_VOTE_ALL true
-#define gfw_lanes(p) (p)
-#define gfw_all_lanes(v) __all(v)
-#define gfw_vote_select(cur, cond, val) ((cond) ? (val) : (cur))
-#define gfw_vote_lane(v, lane) (v)
+static inline bool gfw_lanes(bool p) { return p; }
+static inline bool gfw_all_lanes(bool v) { return __all(v); }
+static inline bool gfw_vote_select(bool cur, bool cond, bool val) { return cond ? val : cur; }
+static inline bool gfw_vote_lane(bool v, int) { return v; }
 #else
 typedef unsigned long long GfwVote;
 #define GFW_VOTE_ALL (~0ull)
@@ -301,8 +307,10 @@ __device__ __forceinline__ GfwPt rd(float px, float py, const float4 ma, const f
         }
         o.x = u; o.y = v;
     }
-    // input_{horizontal,vertical}_stretch (cpu_undistort.rs:222-223): only <= 0.001 (skipped) or 1.0 (x/1 == x) reach
-    // this kernel; any other value is routed to the per-plane kernel by the host.
+    // input_{horizontal,vertical}_stretch (cpu_undistort.rs:222-223; anamorphic lens profiles): <= 0.001 is skipped and x / 1.0 == x, so the host raises the
+    // flags only for a real divisor — then an IEEE division, as the reference's
+    if (AF(hstretch_div)) o.x = o.x / AF(hstretch);
+    if (AF(vstretch_div)) o.y = o.y / AF(vstretch);
     return o;
 }
 // The specialised fisheye projection WITHOUT a branch (round 4).  rd<>'s lean / generic split, the square root's tiny-operand case and the r == 0
@@ -403,16 +411,20 @@ __device__ __forceinline__ uint32_t gfw_f2u_trunc(float v) { uint32_t r; asm("v_
 // Bins holds the two row pointers.  (Keeping 2*I weights per sample in registers cost the bicubic / Lanczos4 kernels
 // their occupancy: 148 VGPRs for I = 8.)
 template <int I> struct Bins { int sx, sy; const float *tx, *ty; };
+template <int I> __device__ __forceinline__ int raw_bin(float u) {           // round((u - offset) * 32): the sample's column / row and its 1/32 phase (:374, :380-381)
+    constexpr float OFFSET = (I == 2) ? 0.0f : (I == 4 ? 1.0f : 3.0f);
+    return round_i32((u - OFFSET) * 32.0f);
+}
 template <int I>
-__device__ __forceinline__ Bins<I> make_bins(float u, float v, const float *lut) {
-    constexpr float OFFSET = (I == 2) ? 0.0f : (I == 4 ? 1.0f : 3.0f);       // :374
-    const int sx0 = round_i32((u - OFFSET) * 32.0f), sy0 = round_i32((v - OFFSET) * 32.0f);
+__device__ __forceinline__ Bins<I> bins_of(int sx0, int sy0, const float *lut) {
     Bins<I> b;
     b.sx = sx0 >> 5; b.sy = sy0 >> 5;
     constexpr int IND = (I == 2) ? 0 : (I == 4) ? 64 : 192, SHIFT = (I >> 2) + 1;       // :373-375
     b.tx = lut + IND + ((sx0 & 31) << SHIFT); b.ty = lut + IND + ((sy0 & 31) << SHIFT);
     return b;
 }
+template <int I>
+__device__ __forceinline__ Bins<I> make_bins(float u, float v, const float *lut) { return bins_of<I>(raw_bin<I>(u), raw_bin<I>(v), lut); }
 template <typename T> struct is_f32 { static constexpr bool value = false; };
 template <> struct is_f32<float> { static constexpr bool value = true; };
 // Taps that straddle the source rect: out-of-rect taps read `bg`, out-of-rect rows contribute bg*cy
@@ -461,44 +473,54 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
         // single-channel integer planes (Y, U, V): the I taps of a row are I*sizeof(T) contiguous bytes.  They are fetched as
         // ALIGNED dwords and funnel-shifted into place: a row fetch whose address is not 4-byte aligned (every odd u16
         // pixel) costs the texture-address unit 65 cycles instead of 18 (profiles/r01_membench_tap_row_fetch.txt), and that
-        // was what the Lanczos4 kernel waited for.  The extra dword is only read when the row is misaligned; the host-side
-        // `inside` test keeps TAP_MARGIN pixels clear of the row end so that it never leaves the plane.
+        // was what the Lanczos4 kernel waited for.
+        // Round 4 (the row body was 45 issue slots, 7 of them scalar): ND + 1 dwords are fetched UNCONDITIONALLY — the interior test keeps
+        // tap_margin pixels clear of the row end, so the last dword never leaves the row (it used to be read under a per-lane branch when the
+        // sample was misaligned) — addresses are 32-bit lane offsets on the uniform plane base (plane bases are 4-byte aligned: host-checked),
+        // and for integer pixels the reference's leading zero-adds (xs = 0 + p*c, sum = 0 + xs*cy) are dropped: they only decide the sign of a
+        // zero, which no later operation of an integer sample can see (`as u8 / u16` maps both zeros to 0).
         constexpr int ND = (I * (int)sizeof(T)) / 4;
-        float s1 = 0.0f;
-        auto row = [&](const uint32_t *wp, unsigned mis, unsigned sh, float wy) {
+        auto row = [&](const uint32_t *wp, bool extra, unsigned sh) -> float {
             uint32_t w[ND + 1];
             #pragma unroll
             for (int j = 0; j < ND; ++j) w[j] = wp[j];
-            w[ND] = mis ? wp[ND] : 0u;
+            w[ND] = extra ? wp[ND] : 0u;
             float xs = 0.0f;
             #pragma unroll
             for (int j = 0; j < ND; ++j) {
                 const uint32_t d = __builtin_amdgcn_alignbit(w[j + 1], w[j], sh);       // ({w[j+1], w[j]} >> sh)[31:0]
                 if (sizeof(T) == 2) {
-                    xs = xs + (float)(d & 0xffffu) * cx[2 * j];
+                    const float t0 = (float)(d & 0xffffu) * cx[2 * j];
+                    xs = (j == 0) ? t0 : xs + t0;
                     xs = xs + (float)(d >> 16) * cx[2 * j + 1];
                 } else {
-                    xs = xs + (float)(d & 0xffu) * cx[4 * j];
+                    const float t0 = (float)(d & 0xffu) * cx[4 * j];
+                    xs = (j == 0) ? t0 : xs + t0;
                     xs = xs + (float)((d >> 8) & 0xffu) * cx[4 * j + 1];
                     xs = xs + (float)((d >> 16) & 0xffu) * cx[4 * j + 2];
                     xs = xs + (float)(d >> 24) * cx[4 * j + 3];
                 }
             }
-            s1 = s1 + xs * wy;
+            return xs;
         };
+        float s1 = 0.0f;
         if ((stride & 3) == 0) {
             // the usual case (row pitch a multiple of 4 bytes): the misalignment is the same for every tap row of the sample
-            const uint8_t *rp0 = src + (uint32_t)off0;
-            const unsigned mis = (unsigned)(uintptr_t)rp0 & 3u, sh = mis * 8u;
-            const uint8_t *ap = rp0 - mis;
-            #pragma unroll (I >= 8 ? 1 : 2)      // tap rows in flight: one for Lanczos4 (measured: 1 beats 2), two for bicubic (registers against loads in flight)
-            for (int yp = 0; yp < I; ++yp) row(reinterpret_cast<const uint32_t *>(ap + (uint32_t)(yp * stride)), mis, sh, b.ty[yp]);
+            const unsigned mis = (unsigned)off0 & 3u, sh = mis * 8u;
+            uint32_t aoff = (uint32_t)off0 & ~3u;
+            #pragma unroll GFW_TAP_ROW_UNROLL(I)
+            for (int yp = 0; yp < I; ++yp) {
+                const float xs = row(reinterpret_cast<const uint32_t *>(src + aoff), true, sh);
+                s1 = s1 + xs * b.ty[yp];                 // (the first of these adds is the reference's 0 + xs*cy: kept, a select in the rolled loop costs more)
+                aoff += (uint32_t)stride;
+            }
         } else {
             #pragma unroll 1
             for (int yp = 0; yp < I; ++yp) {
-                const uint8_t *rp = src + (uint32_t)(off0 + yp * stride);
-                const unsigned mis = (unsigned)(uintptr_t)rp & 3u;
-                row(reinterpret_cast<const uint32_t *>(rp - mis), mis, mis * 8u, b.ty[yp]);
+                const uint32_t o = (uint32_t)(off0 + yp * stride);
+                const unsigned mis = o & 3u;
+                const float xs = row(reinterpret_cast<const uint32_t *>(src + (o & ~3u)), mis != 0, mis * 8u);
+                s1 = s1 + xs * b.ty[yp];
             }
         }
         out[0] = fminf(s1, limit);
@@ -524,11 +546,12 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
     #pragma unroll
     for (int c = 0; c < N; ++c) out[c] = fminf(sum[c], limit);
 }
-// TAP_MARGIN: pixels kept clear of the row end by the aligned dword fetch of taps_inside (one dword may extend
-// 4/sizeof(T) - 1 pixels past the last tap); samples closer to the edge take the exact edge path.
+// tap_margin: pixels kept clear of the row end by the aligned dword fetch of taps_inside, which reads ND + 1 dwords from the aligned address at or below the
+// first tap: up to 4/sizeof(T) pixels past the last tap when the sample IS aligned.  Samples closer to the edge take the exact edge path.
+template <typename T, int N, int I> __device__ constexpr int tap_margin() { return (N == 1 && !is_f32<T>::value && I > 2) ? 4 / (int)sizeof(T) : 0; }
 template <typename T, int N, int I>
 __device__ __forceinline__ bool bins_inside(const Bins<I> &b, int w, int h) {
-    constexpr int TAP_MARGIN = (N == 1 && !is_f32<T>::value && I > 2) ? (4 / (int)sizeof(T) - 1) : 0;
+    constexpr int TAP_MARGIN = tap_margin<T, N, I>();
     return w >= I + TAP_MARGIN && h >= I && (unsigned)b.sx <= (unsigned)(w - I - TAP_MARGIN) && (unsigned)b.sy <= (unsigned)(h - I);
 }
 // Does the saturating `as u8/u16` cast need its upper clamp?  Every value a sample can take is min(sum, limit) or bg[c]; when both are
@@ -557,18 +580,22 @@ __device__ __forceinline__ void store_px(uint8_t *dst, int off, const float *v, 
 }
 // One plane.  32-bit byte offsets from the uniform plane base (planes are < 2 GiB, checked on the host).
 template <typename T, int N, int I>
-__device__ __forceinline__ void sample_store(float u, float v, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy, const float *lut) {
+__device__ __forceinline__ void sample_store_bins(int bx, int by, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy, const float *lut) {
     float out[N];
     #pragma unroll
     for (int c = 0; c < N; ++c) out[c] = bg[c];
     if (ok) {
-        const Bins<I> b = make_bins<I>(u, v, lut);
+        const Bins<I> b = bins_of<I>(bx, by, lut);
         if (__builtin_expect((bins_inside<T, N, I>(b, P.w, P.h)), 1))
             taps_inside<T, N, I>(P.src, row_off(b.sy, P.src_stride) + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
         else
             taps_edge<T, N, I>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
     }
     store_px<T, N>(P.dst, row_off(oy, P.dst_stride) + ox * (int)(N * sizeof(T)), out, px_needs_sat<T>(bg, N, limit));
+}
+template <typename T, int N, int I>
+__device__ __forceinline__ void sample_store(float u, float v, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy, const float *lut) {
+    sample_store_bins<T, N, I>(raw_bin<I>(u), raw_bin<I>(v), ok, P, bg, limit, ox, oy, lut);       // (garbage bins of a point that is not ok are never used)
 }
 // Planar planes of identical geometry (U and V; or G,B,R,A of a planar float frame): one set of bins / weights /
 // offsets, one gather set per plane.
@@ -872,6 +899,21 @@ __device__ __forceinline__ uint32_t inside_value1(const uint8_t *src, int stride
         if constexpr (is_f32<T>::value) return gfw_f2u(o);
         else return px_needs_sat<T>(bg, 1, limit) ? gfw_f2u_sat(o, 65535.0f) : gfw_f2u_trunc(o);
     }
+}
+// ... and of a bicubic / Lanczos4 sample (the interior taps of taps_inside)
+template <typename T, int I>
+__device__ __forceinline__ uint32_t inside_value1_lut(const uint8_t *src, int stride, int bx, int by, const float *bg, float limit, const float *lut) {
+    const Bins<I> b = bins_of<I>(bx, by, lut);
+    float o;
+    taps_inside<T, 1, I>(src, row_off(b.sy, stride) + b.sx * (int)sizeof(T), stride, b, limit, &o);
+    if constexpr (is_f32<T>::value) return gfw_f2u(o);
+    else return px_needs_sat<T>(bg, 1, limit) ? gfw_f2u_sat(o, sizeof(T) == 1 ? 255.0f : 65535.0f) : gfw_f2u_trunc(o);
+}
+template <typename T, int I>
+__device__ __forceinline__ GfwVote lut_interior(int bx, int by, int w, int h) {          // bins_inside, as a vote over its terms
+    constexpr int TAP_MARGIN = tap_margin<T, 1, I>();
+    if (!(w >= I + TAP_MARGIN && h >= I)) return gfw_lanes(false);
+    return gfw_lanes((unsigned)(bx >> 5) <= (unsigned)(w - I - TAP_MARGIN)) & gfw_lanes((unsigned)(by >> 5) <= (unsigned)(h - I));
 }
 template <typename T>
 __device__ __forceinline__ void store_value1(uint8_t *dst, int off, uint32_t v) {
@@ -1218,8 +1260,9 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                 // The branch-free row (round 4; specialised fisheye, bilinear, single-channel luma): a lane's DW pixels of one line are projected with
                 // rd_lean_nobranch, mapped and binned without a divergent branch; the wave is asked ONCE per stage — `__any(rare)` sends the odd lanes
                 // through rd<> itself, `__all(interior)` picks between the branch-free taps (pair stored as one word) and sample_store2.
-                constexpr bool FASTROW = GFW_FASTROW && MODEL == GFW_MODEL_OPENCV_FISHEYE && I == 2 && N0 == 1 && !AUDIT && !GFW_BAKED_DIGITAL;
-                if (FASTROW && !AF(ablate)) {
+                constexpr bool FASTROW = GFW_FASTROW && MODEL == GFW_MODEL_OPENCV_FISHEYE && N0 == 1 && !AUDIT && !GFW_BAKED_DIGITAL && (I == 2 || GFW_FASTROW_LUT);
+                const bool fastrow = FASTROW && !AF(ablate) && !AF(hstretch_div) && !AF(vstretch_div);       // (a stretched clip: rd<>'s divisions)
+                if (fastrow) {
                     #pragma unroll (NPX <= 2 ? DH : 1)
                     for (int j = 0; j < DH; ++j) {
                         const int ly = cy * DH + j;
@@ -1278,14 +1321,18 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                             }
                             const float lu = map_c<INF_COORDS>(pu[i], MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c<INF_COORDS>(pv[i], MP.mul_ly, MP.den_y, MP.rcp_y);   // :511-514
                             if (j == 0 && i == 0) { u0 = pu[0]; v0 = pv[0]; okm0 = okp[0]; lu0 = lu; lv0 = lv; }
-                            bx[i] = round_i32(lu * 32.0f); by[i] = round_i32(lv * 32.0f);
+                            bx[i] = raw_bin<I>(lu); by[i] = raw_bin<I>(lv);
                             const bool live = WHOLE || (lx < AF(out_w) && ly < AF(out_h));
-                            interior = interior & okp[i] & gfw_lanes(live) & gfw_lanes((unsigned)(bx[i] >> 5) < (unsigned)(PL0.w - 1)) & gfw_lanes((unsigned)(by[i] >> 5) < (unsigned)(PL0.h - 1));
+                            if constexpr (I == 2) interior = interior & okp[i] & gfw_lanes(live) & gfw_lanes((unsigned)(bx[i] >> 5) < (unsigned)(PL0.w - 1)) & gfw_lanes((unsigned)(by[i] >> 5) < (unsigned)(PL0.h - 1));
+                            else interior = interior & okp[i] & gfw_lanes(live) & lut_interior<T, I>(bx[i], by[i], PL0.w, PL0.h);
                         }
                         if (__builtin_expect(gfw_all_lanes(interior), 1)) {
                             uint32_t val[DW];
                             #pragma unroll
-                            for (int i = 0; i < DW; ++i) val[i] = inside_value1<T>(PL0.src, PL0.src_stride, bins2_of(bx[i], by[i]), bg_y, lim_y);
+                            for (int i = 0; i < DW; ++i) {
+                                if constexpr (I == 2) val[i] = inside_value1<T>(PL0.src, PL0.src_stride, bins2_of(bx[i], by[i]), bg_y, lim_y);
+                                else val[i] = inside_value1_lut<T, I>(PL0.src, PL0.src_stride, bx[i], by[i], bg_y, lim_y, s_lut);
+                            }
                             const int doff = row_off(ly, PL0.dst_stride) + (cx * DW) * (int)sizeof(T);
                             if constexpr (DW == 2) store_pair1<T>(PL0.dst, doff, val[0], val[1]);
                             else store_value1<T>(PL0.dst, doff, val[0]);
@@ -1293,7 +1340,10 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                             #pragma unroll
                             for (int i = 0; i < DW; ++i) {
                                 const int lx = cx * DW + i;
-                                if (WHOLE || (lx < AF(out_w) && ly < AF(out_h))) sample_store2_bins<T, N0>(bx[i], by[i], gfw_vote_lane(okp[i], lane), PL0, bg_y, lim_y, lx, ly, nullptr);
+                                if (WHOLE || (lx < AF(out_w) && ly < AF(out_h))) {
+                                    if constexpr (I == 2) sample_store2_bins<T, N0>(bx[i], by[i], gfw_vote_lane(okp[i], lane), PL0, bg_y, lim_y, lx, ly, nullptr);
+                                    else sample_store_bins<T, N0, I>(bx[i], by[i], gfw_vote_lane(okp[i], lane), PL0, bg_y, lim_y, lx, ly, s_lut);
+                                }
                             }
                         }
                     }
@@ -1360,7 +1410,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                         cv = map_c<INF_COORDS>(v0, MP.mul_cy, MP.den_y, MP.rcp_y);
                     }
                     bool chroma_done = false;
-                    if constexpr (FASTROW && !is_f32<T>::value) if (!AF(ablate) && (INTERLEAVED_UV || AF(nplanes) == 3)) {
+                    if constexpr (FASTROW && I == 2 && !is_f32<T>::value) if (fastrow && (INTERLEAVED_UV || AF(nplanes) == 3)) {
                         // the chroma site the same way: one question to the wave, then the branch-free interior taps of both chroma samples
                         const Bins2 bc = make_bins2(cu, cv);
                         if (__builtin_expect(gfw_all_lanes(okm0 & gfw_lanes((unsigned)bc.sx < (unsigned)(PL1.w - 1)) & gfw_lanes((unsigned)bc.sy < (unsigned)(PL1.h - 1))), 1)) {
@@ -1389,7 +1439,18 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                             chroma_done = true;
                         }
                     }
-                    if (FASTROW && !AF(ablate) && !chroma_done) ok0 = gfw_vote_lane(okm0, lane);       // the edge-aware samplers below take the per-lane form
+                    if constexpr (FASTROW && I != 2 && !is_f32<T>::value && !INTERLEAVED_UV) if (fastrow && AF(nplanes) == 3) {
+                        // bicubic / Lanczos4 chroma of planar frames: one vote, then both planes' interior taps with one set of bins
+                        const int cbx = raw_bin<I>(cu), cby = raw_bin<I>(cv);
+                        if (__builtin_expect(gfw_all_lanes(okm0 & lut_interior<T, I>(cbx, cby, PL1.w, PL1.h)), 1)) {
+                            const uint32_t vu = inside_value1_lut<T, I>(PL1.src, PL1.src_stride, cbx, cby, &bg_c[0], lim_u, s_lut);
+                            const uint32_t vv = inside_value1_lut<T, I>(PL2.src, PL1.src_stride, cbx, cby, &bg_v, lim_v, s_lut);
+                            const int doff = row_off(cy, PL1.dst_stride) + cx * (int)sizeof(T);
+                            store_value1<T>(PL1.dst, doff, vu); store_value1<T>(PL2.dst, doff, vv);
+                            chroma_done = true;
+                        }
+                    }
+                    if (fastrow && !chroma_done) ok0 = gfw_vote_lane(okm0, lane);       // the edge-aware samplers below take the per-lane form
                     if (chroma_done) {}
                     else if (I == 2) {
                         if (INTERLEAVED_UV) sample_store2<T, 2>(cu, cv, ok0, PL1, bg_c, lim_u, cx, cy, AUDIT ? AF(audit) : nullptr);

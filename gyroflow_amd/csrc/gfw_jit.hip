@@ -12,6 +12,9 @@
 // device); the module is loaded by the first launch that finds the code object ready.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <unistd.h>
 #include <atomic>
 #include <chrono>
 #include <map>
@@ -39,6 +42,7 @@ struct Rtc {
     int (*destroy)(rtcProgram *) = nullptr;
     bool ok = false;
     Rtc() {
+        if (const char *e = getenv("GFW_NO_HIPRTC")) { if (e[0] == '1') return; }        // tests: behave like a box without libhiprtc.so
         for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6", "/opt/rocm/lib/libhiprtc.so"}) {
             lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (lib) break;
@@ -91,13 +95,66 @@ std::mutex g_mu;
 std::map<std::string, std::shared_ptr<Entry>> g_cache;       // key: device | arch | options | bake header
 constexpr size_t kMaxEntries = 256;
 
+// ---- specialised kernels on disk --------------------------------------------------------------------------------------------------
+// A code object is a pure function of (architecture, compiler options, bake header, embedded source): it can be kept.  Two directories are consulted before
+// hiprtc is: <directory of libgfwarp.so>/jit_cache — shipped with the build, filled by tools/build_jit_cache.py for the BASELINE configurations, so that their
+// specialised kernels need no libhiprtc.so at run time — and $GFW_JIT_CACHE, which also receives every kernel this process compiles (a render farm compiles a
+// clip's kernel once).  File name: 128-bit FNV-1a of the key text, so a changed source, option or constant never finds a stale kernel.
+static std::string key_hash(const std::string &key) {
+    unsigned long long h1 = 1469598103934665603ull, h2 = 0x9ae16a3b2f90404full;
+    for (unsigned char c : key) { h1 = (h1 ^ c) * 1099511628211ull; h2 = (h2 ^ (c + 0x9eu)) * 0x100000001b3ull; h2 ^= h2 >> 29; }
+    char b[40]; snprintf(b, sizeof(b), "%016llx%016llx", h1, h2);
+    return b;
+}
+static std::string lib_dir() {
+    Dl_info di;
+    if (!dladdr((const void *)&key_hash, &di) || !di.dli_fname) return std::string();
+    std::string p = di.dli_fname;
+    const size_t k = p.rfind('/');
+    return k == std::string::npos ? std::string(".") : p.substr(0, k);
+}
+static std::string full_key(const std::string &arch, const std::vector<std::string> &opts, const std::string &header) {
+    std::string key = arch;
+    for (const std::string &o : opts) key += "|" + o;
+    key += "|" + header + "|";
+    key += std::to_string(sizeof(GFW_JIT_SOURCE)) + ":" + key_hash(GFW_JIT_SOURCE);          // the embedded source itself
+    return key;
+}
+static bool cache_load(const std::string &hash, std::vector<char> &code, std::string &from) {
+    std::vector<std::string> dirs;
+    const std::string ld = lib_dir();
+    if (!ld.empty()) dirs.push_back(ld + "/jit_cache");
+    if (const char *e = getenv("GFW_JIT_CACHE")) if (*e) dirs.push_back(e);
+    for (const std::string &d : dirs) {
+        const std::string path = d + "/" + hash + ".co";
+        if (FILE *f = fopen(path.c_str(), "rb")) {
+            fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+            bool ok = n > 0;
+            if (ok) { code.resize((size_t)n); ok = fread(code.data(), 1, (size_t)n, f) == (size_t)n; }
+            fclose(f);
+            if (ok) { from = path; return true; }
+        }
+    }
+    return false;
+}
+static void cache_store(const std::string &hash, const std::vector<char> &code) {
+    const char *e = getenv("GFW_JIT_CACHE");
+    if (!e || !*e || code.empty()) return;
+    const std::string path = std::string(e) + "/" + hash + ".co", tmp = path + ".tmp" + std::to_string((long)getpid());
+    if (FILE *f = fopen(tmp.c_str(), "wb")) {
+        const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+        fclose(f);
+        if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
+    }
+}
+
 void join_all_workers() {
     std::vector<std::shared_ptr<Entry>> all;
     { std::lock_guard<std::mutex> lk(g_mu); for (auto &kv : g_cache) all.push_back(kv.second); }
     for (auto &e : all) e->join();
 }
 
-void compile_entry(Entry *e, std::string source, std::vector<std::string> opts) {
+void compile_entry(Entry *e, std::string source, std::vector<std::string> opts, std::string hash) {
     const auto t0 = std::chrono::steady_clock::now();
     Rtc &R = rtc();
     rtcProgram prog = nullptr;
@@ -114,20 +171,27 @@ void compile_entry(Entry *e, std::string source, std::vector<std::string> opts) 
         (void)R.destroy(&prog);
     }
     e->compile_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rc == 0 && !hash.empty()) cache_store(hash, e->code);
     if (rc != 0 && e->log.empty()) e->log = "hiprtc error " + std::to_string(rc);
     e->state.store(rc == 0 ? ST_COMPILED : ST_FAILED, std::memory_order_release);
 }
 
 }  // namespace
 
-bool gfw_jit_available() { return rtc().ok; }
+bool gfw_jit_available() { return rtc().ok; }      // (kernels cached on disk are served without it: gfw_jit_get)
+// The file name a specialised kernel has in the on-disk caches (tools/build_jit_cache.py fills the shipped one through gfw_debug_jit_key).
+std::string gfw_jit_cache_name(const std::string &arch, const std::vector<std::string> &defines, const std::string &bake_header) {
+    std::vector<std::string> opts = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-ffp-contract=off", GFW_JIT_NO_SLP, "-Wno-pass-failed",
+                                     "-Wno-cuda-compat", "-DGFW_JIT=1", "-DGFW_BAKE=1"};
+    for (const std::string &d : defines) opts.push_back(jit_option(d));
+    return key_hash(full_key(arch, opts, bake_header)) + ".co";
+}
 
 // State of the specialised kernel for (device, options, header): starts the build on first sight.  wait: block until it is decided.
 // Returns the function once loaded on `device` (which must be the calling thread's current device), nullptr otherwise.
 hipFunction_t gfw_jit_get(int device, const std::string &arch, const std::vector<std::string> &defines, const std::string &bake_header,
                           bool wait, GfwJitInfo *info) {
     if (info) { info->state = GFW_JIT_UNAVAILABLE; info->compile_ms = 0.0; info->log.clear(); }
-    if (!rtc().ok) { if (info) info->log = "libhiprtc.so not found"; return nullptr; }
     std::string key = std::to_string(device) + "|" + arch;
     for (const std::string &d : defines) key += "|" + d;
     key += "|" + bake_header;
@@ -139,12 +203,22 @@ hipFunction_t gfw_jit_get(int device, const std::string &arch, const std::vector
             // a process that walks through hundreds of distinct clips keeps its first kMaxEntries specialisations (modules stay loaded: kernels of
             // any of them may be in flight); later clips run ahead of time
             if (g_cache.size() >= kMaxEntries) { if (info) { info->state = GFW_JIT_UNAVAILABLE; info->log = "specialisation cache full"; } return nullptr; }
-            e = std::make_shared<Entry>();
             std::vector<std::string> opts = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-ffp-contract=off", GFW_JIT_NO_SLP, "-Wno-pass-failed",
                                              "-Wno-cuda-compat", "-DGFW_JIT=1", "-DGFW_BAKE=1"};
             for (const std::string &d : defines) opts.push_back(jit_option(d));
-            std::string source = bake_header + "\n" + GFW_JIT_SOURCE;
-            e->worker = std::thread(compile_entry, e.get(), std::move(source), std::move(opts));
+            const std::string hash = key_hash(full_key(arch, opts, bake_header));
+            e = std::make_shared<Entry>();
+            std::string from;
+            if (cache_load(hash, e->code, from)) {                      // shipped with the build, or compiled by an earlier process: no hiprtc needed
+                e->log = "code object from " + from;
+                e->state.store(ST_COMPILED, std::memory_order_release);
+            } else if (!rtc().ok) {
+                if (info) info->log = "libhiprtc.so not found and no cached kernel for this clip (" + hash + ".co)";
+                return nullptr;
+            } else {
+                std::string source = bake_header + "\n" + GFW_JIT_SOURCE;
+                e->worker = std::thread(compile_entry, e.get(), std::move(source), std::move(opts), hash);
+            }
             g_cache.emplace(key, e);
         } else e = it->second;
     }
@@ -177,7 +251,7 @@ long gfw_jit_compile_only(const std::string &arch, const std::vector<std::string
     std::vector<std::string> opts = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-ffp-contract=off", GFW_JIT_NO_SLP, "-Wno-pass-failed", "-Wno-cuda-compat",
                                      "-DGFW_JIT=1", "-DGFW_BAKE=1"};
     for (const std::string &d : defines) opts.push_back(jit_option(d));
-    compile_entry(&e, bake_header + "\n" + GFW_JIT_SOURCE, opts);
+    compile_entry(&e, bake_header + "\n" + GFW_JIT_SOURCE, opts, std::string());
     log = e.log;
     if (e.state.load() != ST_COMPILED) return -1;
     const long n = (long)e.code.size();

@@ -28,6 +28,11 @@ long long gfw_debug_selftest(int test, unsigned long long n, unsigned long long 
  * given), -1 on a compile error (log), -2 when libhiprtc.so is absent. */
 long  gfw_debug_jit_compile(const char *arch, const char *defines, const char *bake_header_text, const char *out_path, char *log, size_t cap);
 
+/* Build-time helper of the shipped kernel cache (tools/build_jit_cache.py): the definition list (';'-separated), bake header and cache file name the library
+ * would specialise a frame of these planes to — derived exactly as on a device, without one.  `matrices_on_device` as GFW_OPT_MATRICES_ON_DEVICE would be. */
+int   gfw_debug_jit_key(int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params, const int *pixel_types, int distortion_model, int digital_lens,
+                        const float *host_matrices, int matrix_count, int matrices_on_device, const char *arch,
+                        char *defs_out, size_t defs_cap, char *header_out, size_t header_cap, char *name_out, size_t name_cap);
 
 #ifdef __cplusplus
 }

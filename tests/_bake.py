@@ -20,11 +20,13 @@ def bake_header(frame, rb=4):
     cw, ch = (ow + dw - 1) // dw, (oh + dh - 1) // dh
     d = {"nplanes": n, "width": w, "height": h, "out_w": ow, "out_h": oh, "cw": cw, "ch": ch, "tiles_x": (cw + 63) // 64,
          "tiles_y": (ch + 4 * rb - 1) // (4 * rb), "matrix_count": p0.matrix_count, "hrs": 1 if p0.flags & 16 else 0, "model": frame.model,
-         "k_all_zero": 1 if all(p0.k[i] == 0.0 for i in range(4)) else 0, "background_mode": p0.background_mode, "extras": 0, "ablate": 0, "digital": 0}
+         "k_all_zero": 1 if all(p0.k[i] == 0.0 for i in range(4)) else 0, "background_mode": p0.background_mode, "extras": 0, "ablate": 0, "digital": 0,
+         "hstretch_div": 1 if (p0.input_horizontal_stretch > 0.001 and p0.input_horizontal_stretch != 1.0) else 0,
+         "vstretch_div": 1 if (p0.input_vertical_stretch > 0.001 and p0.input_vertical_stretch != 1.0) else 0}
     out = ["#define GFW_BK_%s (%d)" % kv for kv in d.items()]
     out.append("#define GFW_BK_audit ((unsigned long long *)nullptr)")
     fl = {"f_0": p0.f[0], "f_1": p0.f[1], "c_0": p0.c[0], "c_1": p0.c[1], "t2_0": p0.translation2d[0], "t2_1": p0.translation2d[1],
-          "k_0": p0.k[0], "k_1": p0.k[1], "k_2": p0.k[2], "k_3": p0.k[3], "r_limit_sq": struct.unpack("<f", struct.pack("<f", p0.r_limit))[0] ** 2}
+          "hstretch": p0.input_horizontal_stretch, "vstretch": p0.input_vertical_stretch, "k_0": p0.k[0], "k_1": p0.k[1], "k_2": p0.k[2], "k_3": p0.k[3], "r_limit_sq": struct.unpack("<f", struct.pack("<f", p0.r_limit))[0] ** 2}
     hrs = d["hrs"]
     fl["p1_f"], fl["p1_c"] = (p0.f[0], p0.c[0]) if hrs else (p0.f[1], p0.c[1])
     import numpy as np

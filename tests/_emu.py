@@ -215,7 +215,7 @@ def fused_eligible(fr):
         if p.input_rotation != 0.0 or (p.flags & (abi.FLAG_FIX_COLOR_RANGE | abi.FLAG_FILL_WITH_BACKGROUND)) or p.interpolation not in (2, 4, 8):
             return False
         for st in (p.input_horizontal_stretch, p.input_vertical_stretch):
-            if st > 0.001 and st != 1.0:
+            if st > 0.001 and st != 1.0 and p.lens_correction_amount < 1.0:
                 return False
         if bps == 2 and ((p.stride | pl["out_size"][2]) & 1):
             return False
@@ -258,7 +258,8 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=F
     # any feature bit sends the frame to the generic-model instantiations (gfw_kernels.hip's dispatch)
     lean = fisheye and ((extras & ~2) == 0 if baked else extras == 0)
     jit_model = 1 if lean else (-2 if extras & (16 | 32) else -1)
-    p1 = p1_table(p0, fr0.matrices, p0.matrix_count) if (fisheye and extras == 0) else None
+    stretched = any(st > 0.001 and st != 1.0 for st in (p0.input_horizontal_stretch, p0.input_vertical_stretch))      # p1_setup: exact first pass
+    p1 = p1_table(p0, fr0.matrices, p0.matrix_count) if (fisheye and extras == 0 and not stretched) else None
     fast1 = p1 is not None
     rb = 4 if fast1 else 1
     defs = {"GFW_FRAME_KIND": bps, "GFW_FRAME_TAPS": p0.interpolation, "GFW_JIT_WAVES": 8, "GFW_JIT_MODEL": jit_model,

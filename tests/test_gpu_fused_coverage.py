@@ -86,3 +86,18 @@ def test_sony_mesh_and_focal_plane_distortion_fused(fmt, with_mesh, with_fpd, in
     assert warp.last_backend() == "plane_generic"
     for i, (a, b) in enumerate(zip(ref, base)):
         assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "per-plane mesh, plane %d" % i)
+
+
+@pytest.mark.parametrize("fmt", ["YUV422P16LE", "NV12", "RGBA"])
+@pytest.mark.parametrize("jit", [0, 2])
+@pytest.mark.parametrize("interp", [2, 8])
+def test_stretched_clips_take_the_fused_kernel(fmt, jit, interp):
+    """input_horizontal / vertical_stretch (anamorphic lens profiles, cpu_undistort.rs:222-223): an IEEE division at the end of the projection — served by the
+    fused kernel since round 4 (ahead of time and specialised), no longer by three per-plane launches"""
+    ov = {"input_horizontal_stretch": 1.33, "input_vertical_stretch": 0.9}
+    fr = S.SyntheticFrame(fmt, 384, 208, seed=77, fov=1.2, base_overrides=ov, interpolation=interp)
+    ref = O.run_frame(fr)
+    got = warp.run_frame(fr, jit=jit)
+    assert warp.last_backend().startswith("yuv_fused") and warp.last_backend().endswith("_jit") == (jit == 2), warp.last_backend()
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "stretched clip, plane %d" % i)
