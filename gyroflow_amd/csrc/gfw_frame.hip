@@ -510,7 +510,10 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
             uint32_t aoff = (uint32_t)off0 & ~3u;
             #pragma unroll GFW_TAP_ROW_UNROLL(I)
             for (int yp = 0; yp < I; ++yp) {
-                const float xs = row(reinterpret_cast<const uint32_t *>(src + aoff), true, sh);
+                // 16-bit Lanczos4 is bound by the fetches themselves (dwordx4 + dword per row: the second one only for the misaligned half of the samples —
+                // unconditional it measured 170 against 157 us per C2 frame); everywhere else the branch costs more than the fetch it saves
+                // (bicubic 81 -> 67 us, 8-bit Lanczos4 141 -> 106)
+                const float xs = row(reinterpret_cast<const uint32_t *>(src + aoff), (sizeof(T) == 2 && I == 8) ? mis != 0u : true, sh);
                 s1 = s1 + xs * b.ty[yp];                 // (the first of these adds is the reference's 0 + xs*cy: kept, a select in the rolled loop costs more)
                 aoff += (uint32_t)stride;
             }
@@ -885,6 +888,8 @@ __device__ __forceinline__ void sample_store_uv2(float u, float v, bool ok, cons
 // sample_store_uv2.  Waves that touch the frame border, background or an invalid point take those functions as before.
 __device__ __forceinline__ bool bins2_inside(const Bins2 &b, int w, int h) { return (unsigned)b.sx < (unsigned)(w - 1) && (unsigned)b.sy < (unsigned)(h - 1); }
 // the value of one interior sample of a single-channel plane, converted like `as u8 / u16` (integer types) or as its f32 bit pattern
+// (16-bit taps through v_dot2_u32_u16, the form the 8-bit planes use with v_dot4: 15 fewer vector instructions per pixel pair and 46.8 instead of 45.8 us per C2
+// frame — measured in round 4 as in round 2, not kept: profiles/r04_ab_fastrow.txt)
 template <typename T>
 __device__ __forceinline__ uint32_t inside_value1(const uint8_t *src, int stride, const Bins2 &b, const float *bg, float limit) {
     const int off0 = row_off(b.sy, stride) + b.sx * (int)sizeof(T);

@@ -43,7 +43,10 @@ CONFIGS = [
 ]
 
 
-def key_of(lib, fr, arch=b"gfx950"):
+ARCH = b"gfx950:sramecc+:xnack-"       # hipDeviceProp_t::gcnArchName of an MI355X: the string the library compiles for at run time (part of the key)
+
+
+def key_of(lib, fr, arch=ARCH):
     n = len(fr.planes)
     bufs = []
     for p, pl in enumerate(fr.planes):                 # any non-null device pointers: the key holds no pointer
@@ -75,7 +78,7 @@ def main():
         if os.path.exists(path):
             continue
         log = C.create_string_buffer(1 << 16)
-        n = lib.gfw_debug_jit_compile(b"gfx950", defs, header, path.encode(), log, len(log))
+        n = lib.gfw_debug_jit_compile(ARCH, defs, header, path.encode(), log, len(log))
         if n == -2:
             sys.stderr.write("[build] libhiprtc.so not available: the shipped kernel cache stays empty (kernels are compiled at run time)\n")
             return 0
