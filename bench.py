@@ -51,7 +51,7 @@ N_RESIDENT = 64                  # distinct source frames + per-row matrix table
 CLIP_FRAMES = 16                 # most frames gfw_undistort_clip puts into one launch (GFW_CLIP_FRAMES_MAX)
 N_DST = 8                        # destination frame sets written round-robin (the frames of one clip launch are in flight together: one set each)
 N_CHECK = 3                      # frames of the timed region compared with the oracle afterwards
-TRAFFIC_FILE = os.path.join("profiles", "r03_c2_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_c2_traffic.json")
 
 
 # coefficient sets of the other physical lens models (the ones tests/test_gpu_lens_models.py runs), for --lens-model

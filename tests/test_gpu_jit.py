@@ -275,3 +275,46 @@ def test_full_size_c2_clip():
         ref = O.run_frame(_View(fr, srcs[j]))
         for p, (a, b) in enumerate(zip(ref, outs[j])):
             assert_plane_equal(a, b, fr.planes[p]["pixel_type"], "frame %d plane %d" % (j, p))
+
+
+def test_clip_call_under_the_default_synchronous_option_returns_finished_frames():
+    """GFW_OPT_SYNCHRONOUS defaults to 1: "the outputs are complete when the call returns".  A frame that joins a clip launch leaves run_planes before its
+    own synchronisation point, so gfw_undistort_clip has to synchronise after its last launch (round-3 advisor finding): the outputs are read here through a
+    NON-blocking side stream right after the call, with no synchronize of ours in between."""
+    import torch
+    dev = torch.device("cuda", 0)
+    assert abi.load_library().gfw_set_device(0) == 0
+    frames = [S.SyntheticFrame("YUV422P16LE", 1920, 1080, seed=0xC11 + j, timestamp_ms=1000.0 + 33.3 * j) for j in range(8)]
+    d_src = [fr.device_planes(dev) for fr in frames]
+    d_dst = [fr.device_outputs(dev) for fr in frames]
+    d_mat = [torch.from_numpy(warp.pack_matrices(fr.matrices)).to(dev) for fr in frames]
+    torch.cuda.synchronize(dev)
+    types = [pl["pixel_type"] for pl in frames[0].planes]
+    params = [pl["params"] for pl in frames[0].planes]
+    bufs = [[warp.device_buffers(d_src[j][p].data_ptr(), d_src[j][p].numel(), pl["size"], d_dst[j][p].data_ptr(), d_dst[j][p].numel(), pl["out_size"])
+             for p, pl in enumerate(fr.planes)] for j, fr in enumerate(frames)]
+    be = warp.Backend(params[0], types[0], frames[0].model, frames[0].digital, bufs[0][0])
+    side = torch.cuda.Stream(dev)
+    try:
+        be.set_option(abi.OPT_MATRICES_ON_DEVICE, 2)                 # (GFW_OPT_SYNCHRONOUS stays at its default)
+        be.set_option(abi.OPT_JIT, 2)
+        call = warp.ClipCall(be, bufs, params, types, [m.data_ptr() for m in d_mat], frames[0].matrices.shape[0])
+        call()                                                       # first call: compiles, frames may run one by one
+        for t in d_dst:
+            for x in t:
+                x.fill_(0x5A)
+        torch.cuda.synchronize(dev)
+        call()                                                       # now the eight frames share one launch of the specialised kernel
+        assert warp.last_backend().endswith("_jit")
+        with torch.cuda.stream(side):                                # the library's own stream is unknown to torch: nothing here waits for it
+            host = [[torch.empty_like(x, device="cpu").pin_memory() for x in t] for t in d_dst]
+            for hj, tj in zip(host, d_dst):
+                for h, x in zip(hj, tj):
+                    h.copy_(x, non_blocking=True)
+        side.synchronize()
+    finally:
+        be.close()
+    for j, fr in enumerate(frames):
+        ref = O.run_frame(_View(fr, [t.cpu().numpy() for t in d_src[j]]))
+        for p, (a, b) in enumerate(zip(ref, host[j])):
+            assert np.array_equal(a, b.numpy()), "frame %d plane %d was read before the clip call had finished it" % (j, p)
