@@ -84,6 +84,9 @@
 #ifndef GFW_FASTROW
 #define GFW_FASTROW 1            // the branch-free lane-row of phase 3 (rd_lean_nobranch + one `__any` / `__all` per stage); 0: the per-pixel divergent code only (A/B)
 #endif
+#ifndef GFW_ROW_UNROLL
+#define GFW_ROW_UNROLL 1         // lane-rows of phase 3 per loop iteration (A/B)
+#endif
 #ifndef GFW_TAP_ROW_UNROLL
 #define GFW_TAP_ROW_UNROLL(I) ((I) >= 8 ? 2 : 2)        // tap rows of a bicubic / Lanczos4 sample in flight (registers against loads in flight)
 #endif
@@ -1253,7 +1256,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
 #endif
         // ---- phase 3: exact projection with the row's own matrix, then taps ---------------------------
         if (lane_ok) {
-            #pragma unroll 1
+            #pragma unroll GFW_ROW_UNROLL
             for (int r = 0; r < RB; ++r) {
 #if GFW_PRIO_MODE == 1 && GFW_PRIO_ROWS
                 set_prio((tiles_left * RB) - r);

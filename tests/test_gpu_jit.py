@@ -305,7 +305,7 @@ def test_clip_call_under_the_default_synchronous_option_returns_finished_frames(
                 x.fill_(0x5A)
         torch.cuda.synchronize(dev)
         call()                                                       # now the eight frames share one launch of the specialised kernel
-        assert warp.last_backend().endswith("_jit")
+        assert warp.Backend.last_backend_of(be).endswith("_jit"), warp.Backend.last_backend_of(be)
         with torch.cuda.stream(side):                                # the library's own stream is unknown to torch: nothing here waits for it
             host = [[torch.empty_like(x, device="cpu").pin_memory() for x in t] for t in d_dst]
             for hj, tj in zip(host, d_dst):
