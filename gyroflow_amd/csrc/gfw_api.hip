@@ -678,7 +678,7 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     for (int i = 0; i < nplanes; ++i) {
         const gfw_kernel_params &p = params[i];
         if ((p.interpolation != 2 && p.interpolation != 4 && p.interpolation != 8) || p.interpolation != p0.interpolation) return false;
-        if (p.background_mode < 0 || p.background_mode > 3 || p.background_mode != p0.background_mode || p.input_rotation != 0.0f) return false;
+        if (p.background_mode < 0 || p.background_mode > 3 || p.background_mode != p0.background_mode || p.input_rotation != p0.input_rotation || !(p.input_rotation == p.input_rotation)) return false;
         if (p.background_mode == 3) {
             if (p.background_margin != p0.background_margin || p.background_margin_feather != p0.background_margin_feather) return false;
             extras |= 16;                                                        // two samples + blend (:576-613), generic-model instantiation
@@ -690,7 +690,8 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
         if ((p.flags ^ p0.flags) & GFW_FLAG_HAS_DIGITAL_LENS) return false;
         if (mesh_len != 0 && ((p.flags ^ p0.flags) & 128)) return false;          // the mesh terms read flag 128 (vertically flipped frame buffer)
         if (memcmp(p.digital_lens_params, p0.digital_lens_params, sizeof(p.digital_lens_params))) return false;
-        if (p.flags & (GFW_FLAG_FIX_COLOR_RANGE | GFW_FLAG_FILL_WITH_BACKGROUND)) return false;
+        if (p.flags & GFW_FLAG_FIX_COLOR_RANGE) return false;                       // (a macOS VideoToolbox workaround: per plane)
+        if ((p.flags ^ p0.flags) & GFW_FLAG_FILL_WITH_BACKGROUND) return false;
         if (p.translation3d[0] != 0.0f || p.translation3d[1] != 0.0f || p.translation3d[2] != 0.0f) return false;
         if (p.width != p0.width || p.height != p0.height || p.output_width != p0.output_width || p.output_height != p0.output_height) return false;
         if (p.matrix_count != p0.matrix_count || ((p.flags ^ p0.flags) & GFW_FLAG_HORIZONTAL_RS)) return false;
@@ -752,7 +753,14 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
         extras |= 1;
     }
     // source_rect map constants: u * pw / W  (cpu_undistort.rs:511-514 with frame_size = (width, height))
-    const float Wf = (float)p0.width, Hf = (float)p0.height;
+    // (frame_size: the source frame, turned by input_rotation — cpu_undistort.rs:484-490; fill_common evaluates the same expression for the kernels' uniforms)
+    float Wf = (float)p0.width, Hf = (float)p0.height;
+    if (p0.input_rotation != 0.0f) {
+        if (extras & (8 | 16 | 32)) return false;                       // with the lens-correction blend, margin feather or the Sony mesh: per plane
+        GfwCommon rc; fill_common(c, &p0, nullptr, nullptr, 0, rc);
+        Wf = rc.frame_w; Hf = rc.frame_h;
+        if (!(Wf >= 1.0f) || !(Hf >= 1.0f)) return false;
+    }
     if (!map_const_valid(Wf) || !map_const_valid(Hf)) return false;
 
     // bicubic / Lanczos4 taps of single-channel integer planes are fetched as aligned dwords at 32-bit offsets from the plane base (taps_inside): the base itself
@@ -782,6 +790,8 @@ static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, c
     Y.k_all_zero = (p0.k[0] == 0.0f && p0.k[1] == 0.0f && p0.k[2] == 0.0f && p0.k[3] == 0.0f) ? 1 : 0;
     Y.hstretch = p0.input_horizontal_stretch; Y.vstretch = p0.input_vertical_stretch;
     Y.hstretch_div = hdiv ? 1 : 0; Y.vstretch_div = vdiv ? 1 : 0;
+    Y.fill_bg = (p0.flags & GFW_FLAG_FILL_WITH_BACKGROUND) ? 1 : 0;
+    Y.rot_on = p0.input_rotation != 0.0f ? 1 : 0;
     memcpy(Y.f, p0.f, sizeof(Y.f)); memcpy(Y.c, p0.c, sizeof(Y.c)); memcpy(Y.k, p0.k, sizeof(Y.k));
     Y.t2[0] = p0.translation2d[0]; Y.t2[1] = p0.translation2d[1];
     Y.r_limit_sq = p0.r_limit * p0.r_limit;
@@ -881,6 +891,7 @@ static std::string bake_header(const GfwYuvArgs &Y) {
     bake_i(o, "hrs", Y.hrs); bake_i(o, "model", Y.model); bake_i(o, "k_all_zero", Y.k_all_zero);
     bake_i(o, "background_mode", Y.background_mode); bake_i(o, "extras", Y.extras); bake_i(o, "ablate", 0);
     bake_i(o, "digital", (Y.extras & 2) ? Y.common.digital : 0);
+    bake_i(o, "fill_bg", Y.fill_bg); bake_i(o, "rot_on", Y.rot_on);
     bake_i(o, "hstretch_div", Y.hstretch_div); bake_i(o, "vstretch_div", Y.vstretch_div); bake_f(o, "hstretch", Y.hstretch); bake_f(o, "vstretch", Y.vstretch);
     o += "#define GFW_BK_audit ((unsigned long long *)nullptr)\n";
     char nm[48];

@@ -34,6 +34,8 @@ struct GfwYuvArgs {
     int32_t model;
     int32_t k_all_zero;               // k[0..3] all zero (opencv_fisheye.rs:75)
     int32_t hstretch_div, vstretch_div;
+    int32_t fill_bg;                  // FILL_WITH_BACKGROUND (flags & 4, cpu_undistort.rs:558-561): every pixel of the output rect is the background
+    int32_t rot_on;                   // input_rotation != 0 (:485-491): the projected point is rotated about the frame centre (cos / sin / rotated frame size in `common`)
     int32_t background_mode;          // 0 solid, 1 edge repeat, 2 edge mirror, 3 margin + feather (with extras & 16)
     int32_t grid_limit;               // persistent workgroups to launch (0 = default)
     int32_t extras;                   // features served by the generic-model instantiation only: 1 IBIS/OIS terms in the

@@ -30,10 +30,9 @@
 //     (GFW_JIT / GFW_BAKE, gfw_jit.hip) — 74 against 51 us per 4K frame.
 //
 // Eligibility (decided on the host, gfw_api.hip build_yuv_args): bilinear / bicubic / Lanczos4 taps (this file is
-// compiled once per tap count and sample type), background_mode 0-3, no input rotation,
-// no colour-range fix / fill flag, translation3d == 0 (other lens models, refraction, digital lens, IBIS/OIS terms, the lens-correction
-// blend, background mode 3 and the Sony mesh are served by the generic-model instantiations with the exact first pass), stretches in
-// {<=0.001, 1}, full-plane rects; Luma8/Luma16 (+UV8/UV16) planes with chroma planes of identical geometry, one
+// compiled once per tap count and sample type), background_mode 0-3, input rotation and the fill flag (round 4; not the colour-range fix), translation3d == 0 (other lens models, refraction, digital lens, IBIS/OIS terms, the lens-correction
+// blend, background mode 3 and the Sony mesh are served by the generic-model instantiations with the exact first pass), any stretch (round 4),
+// full-plane rects; Luma8/Luma16 (+UV8/UV16) planes with chroma planes of identical geometry, one
 // packed RGB(A)8/16 / BGRA8 / AYUV16 / RGBAf plane, or planar R32f planes.
 #ifndef GFW_JIT
 #define GFW_JIT 0                // 1: this file is being compiled at run time by hiprtc (gfw_jit.hip) into ONE baked instantiation: device code only
@@ -68,13 +67,9 @@
 #define GFW_PRIO_MODE 1          // wave issue priority by remaining work (s_setprio).  The SIMD arbiter serves the oldest wave first, so the
                                  // waves of a SIMD progress at 0.115 ... 0.196 lane-rows/us and finish up to 17 us apart
                                  // (profiles/r02_wave_timeline.txt).  1: the priority steps 3 -> 0 as the wave's remaining lane-rows fall below
-                                 // 3, 2 and 1 x (its total / GFW_PRIO_SPAN), re-evaluated every row: waves with more work left are served first
+                                 // 3, 2 and 1 x (its total / GFW_PRIO_SPAN), re-evaluated every tile (every row until round 4: ~20 scalar instructions per row, 46.4 -> 46.15 us): waves with more work left are served first
                                  // and progress stays level.  0: off.  What it is worth depends on how long a wave lives: nothing on a lone 4K
                                  // frame at 6 waves (79.3 = 79.3 us), 4 us of 59 once a launch carries 8 frames at 8 waves per SIMD.
-#endif
-#ifndef GFW_PRIO_ROWS
-#define GFW_PRIO_ROWS 0          // 1: the priority is re-evaluated before every lane-row (round 3); 0: once per tile (4 rows) — the ~20 scalar instructions per row
-                                 // take issue slots like vector ones (tools/microbench_mix.hip)
 #endif
 #ifndef GFW_PRIO_SPAN
 #define GFW_PRIO_SPAN 6          // round 3, C2, 8 waves, 63 lane-rows per wave: fixed divisors 3 / 4 / 5 / 6 / 8 / 12 / 16 / 24 / 32 / 64 gave
@@ -83,18 +78,6 @@
 #endif
 #ifndef GFW_FASTROW
 #define GFW_FASTROW 1            // the branch-free lane-row of phase 3 (rd_lean_nobranch + one `__any` / `__all` per stage); 0: the per-pixel divergent code only (A/B)
-#endif
-#ifndef GFW_ROW_UNROLL
-#define GFW_ROW_UNROLL 1         // lane-rows of phase 3 per loop iteration (A/B)
-#endif
-#ifndef GFW_TAP_ROW_UNROLL
-#define GFW_TAP_ROW_UNROLL(I) ((I) >= 8 ? 2 : 2)        // tap rows of a bicubic / Lanczos4 sample in flight (registers against loads in flight)
-#endif
-#ifndef GFW_FASTROW_LUT
-#define GFW_FASTROW_LUT 1        // the branch-free lane-row for the bicubic / Lanczos4 instantiations too (projection + one interior vote; the tap loops are the old ones)
-#endif
-#ifndef GFW_FASTROW_JOINT
-#define GFW_FASTROW_JOINT 1      // a lane's two pixels through the projection side by side (one basic block, one small-angle vote) instead of one after the other
 #endif
 #ifndef GFW_BAKE
 #define GFW_BAKE 0               // 1: the clip-invariant arguments are the literals GFW_BK_<field> of the bake header in front of this file (read through AF())
@@ -511,7 +494,7 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
             // the usual case (row pitch a multiple of 4 bytes): the misalignment is the same for every tap row of the sample
             const unsigned mis = (unsigned)off0 & 3u, sh = mis * 8u;
             uint32_t aoff = (uint32_t)off0 & ~3u;
-            #pragma unroll GFW_TAP_ROW_UNROLL(I)
+            #pragma unroll 2                       // tap rows in flight: 1 / 2 / 4 measured — bicubic 79.9 / 67.5 / 76.9 us, Lanczos4 the same within 1 %
             for (int yp = 0; yp < I; ++yp) {
                 // 16-bit Lanczos4 is bound by the fetches themselves (dwordx4 + dword per row: the second one only for the misaligned half of the samples —
                 // unconditional it measured 170 against 157 us per C2 frame); everywhere else the branch costs more than the fetch it saves
@@ -1094,7 +1077,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         for (int i = tid; i < 448; i += 256) s_lut[i] = GFW_COEFFS[i];
         __syncthreads();
     }
-    const bool two_pass = AF(matrix_count) > 1 && !(AF(ablate) & 1);
+    const bool two_pass = AF(matrix_count) > 1 && !(AF(ablate) & 1) && !AF(fill_bg);
     const bool hrs = AF(hrs) != 0;
 
     // uniform floats of the pixel loops
@@ -1256,20 +1239,36 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
 #endif
         // ---- phase 3: exact projection with the row's own matrix, then taps ---------------------------
         if (lane_ok) {
-            #pragma unroll GFW_ROW_UNROLL
+            #pragma unroll 1                       // (2 or 4 lane-rows per iteration: 45.9 = 45.8 us)
             for (int r = 0; r < RB; ++r) {
-#if GFW_PRIO_MODE == 1 && GFW_PRIO_ROWS
-                set_prio((tiles_left * RB) - r);
-#endif
                 const int cy = cy0 + r;
                 if (!WHOLE && cy >= AF(ch)) break;
+                if (AF(fill_bg)) {
+                    // FILL_WITH_BACKGROUND (cpu_undistort.rs:558-561; the render loop sets it for frames outside the trim ranges): `*pix_out = bg_t` for every
+                    // pixel of the plane — no projection, no taps
+                    #pragma unroll
+                    for (int k = 0; k < NPX; ++k) {
+                        const int lx = cx * DW + k % DW, ly = cy * DH + k / DW;
+                        if (WHOLE || (lx < AF(out_w) && ly < AF(out_h))) store_px<T, N0>(PL0.dst, row_off(ly, PL0.dst_stride) + lx * (int)(N0 * sizeof(T)), bg_y);
+                    }
+                    if (AF(nplanes) > 1) {
+                        if (INTERLEAVED_UV) store_px<T, 2>(PL1.dst, row_off(cy, PL1.dst_stride) + cx * (int)(2 * sizeof(T)), bg_c);
+                        else {
+                            const int doff = row_off(cy, PL1.dst_stride) + cx * (int)sizeof(T);
+                            store_px<T, 1>(PL1.dst, doff, PL1.bg);
+                            if (AF(nplanes) > 2) store_px<T, 1>(PL2.dst, doff, PL2.bg);
+                            if (AF(nplanes) > 3) store_px<T, 1>(PL3.dst, doff, PL3.bg);
+                        }
+                    }
+                    continue;
+                }
                 float u0 = 0.0f, v0 = 0.0f, lu0 = 0.0f, lv0 = 0.0f; bool ok0 = false;
                 GfwVote okm0 = GFW_VOTE_ALL;              // the branch-free row's form of ok0
                 // The branch-free row (round 4; specialised fisheye, bilinear, single-channel luma): a lane's DW pixels of one line are projected with
                 // rd_lean_nobranch, mapped and binned without a divergent branch; the wave is asked ONCE per stage — `__any(rare)` sends the odd lanes
                 // through rd<> itself, `__all(interior)` picks between the branch-free taps (pair stored as one word) and sample_store2.
-                constexpr bool FASTROW = GFW_FASTROW && MODEL == GFW_MODEL_OPENCV_FISHEYE && N0 == 1 && !AUDIT && !GFW_BAKED_DIGITAL && (I == 2 || GFW_FASTROW_LUT);
-                const bool fastrow = FASTROW && !AF(ablate) && !AF(hstretch_div) && !AF(vstretch_div);       // (a stretched clip: rd<>'s divisions)
+                constexpr bool FASTROW = GFW_FASTROW && MODEL == GFW_MODEL_OPENCV_FISHEYE && N0 == 1 && !AUDIT && !GFW_BAKED_DIGITAL;
+                const bool fastrow = FASTROW && !AF(ablate) && !AF(hstretch_div) && !AF(vstretch_div) && !AF(rot_on);       // (a stretched or rotated clip: the per-pixel path)
                 if (fastrow) {
                     #pragma unroll (NPX <= 2 ? DH : 1)
                     for (int j = 0; j < DH; ++j) {
@@ -1287,12 +1286,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                                 const float *m = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(matrices) + (uint32_t)row * (uint32_t)(GFW_MAT_STRIDE * sizeof(float)));
                                 ma[i] = *reinterpret_cast<const float4 *>(m); mb[i] = *reinterpret_cast<const float4 *>(m + 4); m8[i] = m[8];
                             }
-#if GFW_FASTROW_JOINT
-                            rd_lean_nobranch<DW>(ox, oy, ma, mb, m8, L, A, pu, pv, odd);
-#else
-                            #pragma unroll
-                            for (int i = 0; i < DW; ++i) rd_lean_nobranch<1>(ox + i, oy + i, ma + i, mb + i, m8 + i, L, A, pu + i, pv + i, odd + i);
-#endif
+                            rd_lean_nobranch<DW>(ox, oy, ma, mb, m8, L, A, pu, pv, odd);         // (the pair side by side or one after the other: 46.2 = 46.4 us)
                             #pragma unroll
                             for (int i = 0; i < DW; ++i) { okp[i] = GFW_VOTE_ALL; any_odd = any_odd | odd[i]; }
                         }
@@ -1370,6 +1364,13 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                         const int row = min(sy, AF(matrix_count) - 1);
                         if (AUDIT && (unsigned)row >= (unsigned)AF(matrix_count)) atomicAdd(&AF(audit)[5], 1ull);
                         p = rd_row<MODEL>(ox, oy, row, matrices, L, A);
+                    }
+                    if (AF(rot_on) && p.ok) {                                                          // input_rotation (cpu_undistort.rs:485-491): rotate_point(uv, rot, size/2, frame_size/2),
+                        const float ox_ = (float)AF(width) / 2.0f, oy_ = (float)AF(height) / 2.0f;      // cos / sin from the host libm as the reference's f32::cos / sin
+                        const float o2x = A.common.frame_w / 2.0f, o2y = A.common.frame_h / 2.0f;
+                        const float rx = A.common.rot_cos * (p.x - ox_) - A.common.rot_sin * (p.y - oy_) + o2x;
+                        const float ry = A.common.rot_sin * (p.x - ox_) + A.common.rot_cos * (p.y - oy_) + o2y;
+                        p.x = rx; p.y = ry;
                     }
                     if ((AF(background_mode) == 1 || AF(background_mode) == 2) && p.ok) {                      // cpu_undistort.rs:495-509 (edge repeat / edge mirror)
                         const float width_f = (float)AF(width), height_f = (float)AF(height);

@@ -7,6 +7,24 @@ def _f(v):
     return "__builtin_bit_cast(float, 0x%08xu)" % struct.unpack("<I", struct.pack("<f", float(v)))[0]
 
 
+def rotated_frame_size(p0):
+    """cpu_undistort.rs:484-490 in f32 with the host libm (as gfw_api.hip fill_common evaluates it): the source frame turned by input_rotation"""
+    import ctypes as C
+    import numpy as np
+    if p0.input_rotation == 0.0:
+        return float(p0.width), float(p0.height)
+    libm = C.CDLL("libm.so.6")
+    for fn in ("cosf", "sinf", "roundf"):
+        getattr(libm, fn).restype, getattr(libm, fn).argtypes = C.c_float, [C.c_float]
+    f = np.float32
+    rotation = f(p0.input_rotation) * (f(3.14159265358979323846) / f(180.0))
+    rc, rs = f(libm.cosf(rotation)), f(libm.sinf(rotation))
+    s0, s1 = f(p0.width), f(p0.height)
+    fx = rc * (s0 - f(0.0)) - rs * (s1 - f(0.0)) + f(0.0)
+    fy = rs * (s0 - f(0.0)) + rc * (s1 - f(0.0)) + f(0.0)
+    return libm.roundf(abs(float(fx))), libm.roundf(abs(float(fy)))
+
+
 def bake_header(frame, rb=4):
     pls = frame.planes
     p0 = pls[0]["params"]
@@ -21,6 +39,7 @@ def bake_header(frame, rb=4):
     d = {"nplanes": n, "width": w, "height": h, "out_w": ow, "out_h": oh, "cw": cw, "ch": ch, "tiles_x": (cw + 63) // 64,
          "tiles_y": (ch + 4 * rb - 1) // (4 * rb), "matrix_count": p0.matrix_count, "hrs": 1 if p0.flags & 16 else 0, "model": frame.model,
          "k_all_zero": 1 if all(p0.k[i] == 0.0 for i in range(4)) else 0, "background_mode": p0.background_mode, "extras": 0, "ablate": 0, "digital": 0,
+         "fill_bg": 1 if p0.flags & 4 else 0, "rot_on": 1 if p0.input_rotation != 0.0 else 0,
          "hstretch_div": 1 if (p0.input_horizontal_stretch > 0.001 and p0.input_horizontal_stretch != 1.0) else 0,
          "vstretch_div": 1 if (p0.input_vertical_stretch > 0.001 and p0.input_vertical_stretch != 1.0) else 0}
     out = ["#define GFW_BK_%s (%d)" % kv for kv in d.items()]
@@ -32,7 +51,8 @@ def bake_header(frame, rb=4):
     import numpy as np
     one = np.float32(1.0)
     cpl = pls[1] if n >= 2 else pls[0]
-    for name, mul, den in (("map_lx", pls[0]["size"][0], w), ("map_ly", pls[0]["size"][1], h), ("map_cx", cpl["size"][0], w), ("map_cy", cpl["size"][1], h)):
+    fw, fh = rotated_frame_size(p0)
+    for name, mul, den in (("map_lx", pls[0]["size"][0], fw), ("map_ly", pls[0]["size"][1], fh), ("map_cx", cpl["size"][0], fw), ("map_cy", cpl["size"][1], fh)):
         fl[name + "_mul"], fl[name + "_den"], fl[name + "_rcp"] = float(mul), float(den), float(one / np.float32(den))
     for i in range(4):
         if i < n:

@@ -212,7 +212,11 @@ def fused_eligible(fr):
             return False
     for pl in pls:
         p = pl["params"]
-        if p.input_rotation != 0.0 or (p.flags & (abi.FLAG_FIX_COLOR_RANGE | abi.FLAG_FILL_WITH_BACKGROUND)) or p.interpolation not in (2, 4, 8):
+        if (p.flags & abi.FLAG_FIX_COLOR_RANGE) or p.interpolation not in (2, 4, 8) or p.input_rotation != p0.input_rotation:
+            return False
+        if (p.flags ^ p0.flags) & abi.FLAG_FILL_WITH_BACKGROUND:
+            return False
+        if p.input_rotation != 0.0 and (p.lens_correction_amount < 1.0 or p.background_mode == 3):
             return False
         for st in (p.input_horizontal_stretch, p.input_vertical_stretch):
             if st > 0.001 and st != 1.0 and p.lens_correction_amount < 1.0:
@@ -304,7 +308,7 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=F
         tab = guarded(tab, GUARD == "end")
     libm = C.CDLL("libm.so.6")
     libm.tanf.restype, libm.tanf.argtypes = C.c_float, [C.c_float]
-    com = Common(model=fr0.model, digital=fr0.digital, rot_cos=1.0, rot_sin=0.0, frame_w=float(p0.width), frame_h=float(p0.height), gopro_tt=libm.tanf(1.5533))
+    com = common_for(fr0, p0)
     if mesh is not None and len(mesh):
         mesh = np.ascontiguousarray(mesh, dtype=np.float32)
         com.mesh, com.mesh_len = mesh.ctypes.data, mesh.size

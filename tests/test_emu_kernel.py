@@ -136,13 +136,13 @@ def test_clip_launch_of_the_feature_bodies(fmt, kw):
 
 # ---- the complete per-plane operator (gfw_plane_kernel.h), which serves whatever the fused kernel does not ------------------------------
 
-PER_PLANE = sorted(n for n in G.CASES if n not in FUSED) + ["yuv422p16_stretch", "c2_yuv422p16_480x270_rs", "c1_nv12_1920x1080_constquat", "p010_lanczos4_640x360", "yuv420p_bilinear_642x362",
+PER_PLANE = sorted(n for n in G.CASES if n not in FUSED) + ["yuv422p16_stretch", "yuv422p16_fill_background", "input_rotation_90_nv12", "input_rotation_180_640x360", "c2_yuv422p16_480x270_rs", "c1_nv12_1920x1080_constquat", "p010_lanczos4_640x360", "yuv420p_bilinear_642x362",
                                                             "rgba64_bicubic_640x360", "gbrapf32_bicubic_640x360", "yuv422p16_mirror", "gopro_640x360", "hyperview_lca06_640x360",
                                                             "ibis_terms_640x360"]
 
 
 def test_per_plane_cases_cover_what_the_fused_kernel_leaves():
-    assert "yuv422p16_stretch" in FUSED                    # stretched clips are the fused kernel's since round 4 (and still the per-plane kernel's when asked)
+    assert {"yuv422p16_stretch", "yuv422p16_fill_background", "input_rotation_90_nv12", "input_rotation_180_640x360"} <= set(FUSED)     # the fused kernel's since round 4 (and still the per-plane kernel's when asked)
     assert {"yuv422p16_stretch", "yuv422p16_fill_background", "input_rotation_90_nv12", "input_rotation_180_640x360", "rgbaf16_bilinear_640x360"} <= set(PER_PLANE)
 
 

@@ -4,7 +4,7 @@ plane + alpha blend; f64 mesh spline) and through the per-plane kernel, and both
 MI355X in round 3 as a staging build — 31 / 31 — and promoted: gpurun_out/r03b/staged.log.)"""
 import pytest
 
-from gyroflow_amd import synthetic as S, warp
+from gyroflow_amd import abi, synthetic as S, warp
 import _oracle as O
 from test_gpu_parity import assert_plane_equal
 
@@ -101,3 +101,29 @@ def test_stretched_clips_take_the_fused_kernel(fmt, jit, interp):
     assert warp.last_backend().startswith("yuv_fused") and warp.last_backend().endswith("_jit") == (jit == 2), warp.last_backend()
     for i, (a, b) in enumerate(zip(ref, got)):
         assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "stretched clip, plane %d" % i)
+
+
+@pytest.mark.parametrize("fmt", ["YUV422P16LE", "NV12", "RGBA"])
+@pytest.mark.parametrize("jit", [0, 2])
+@pytest.mark.parametrize("rot", [90.0, 180.0, 270.0, 33.5])
+def test_rotated_input_takes_the_fused_kernel(fmt, jit, rot):
+    """input_rotation (cpu_undistort.rs:484-491: the projected point turned about the frame centre, frame_size turned with it) — fused since round 4"""
+    w, h = (256, 384) if rot in (90.0, 270.0) else (384, 256)
+    fr = S.SyntheticFrame(fmt, w, h, seed=91, fov=1.3, base_overrides={"input_rotation": rot})
+    ref = O.run_frame(fr)
+    got = warp.run_frame(fr, jit=jit)
+    assert warp.last_backend().startswith("yuv_fused"), warp.last_backend()
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "input rotation %g, plane %d" % (rot, i))
+
+
+@pytest.mark.parametrize("fmt", ["YUV422P16LE", "NV12", "YUV420P", "RGBA", "GBRAPF32LE"])
+@pytest.mark.parametrize("jit", [0, 2])
+def test_fill_with_background_takes_the_fused_kernel(fmt, jit):
+    """FILL_WITH_BACKGROUND (cpu_undistort.rs:558-561; the render loop raises it for frames outside the trim ranges): one launch writes every plane's background"""
+    fr = S.SyntheticFrame(fmt, 322, 186, seed=93, flags=abi.FLAG_FILL_WITH_BACKGROUND, background_rgba=(0.2, 0.4, 0.6, 1.0))
+    ref = O.run_frame(fr)
+    got = warp.run_frame(fr, jit=jit)
+    assert warp.last_backend().startswith("yuv_fused"), warp.last_backend()
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "fill, plane %d" % i)
