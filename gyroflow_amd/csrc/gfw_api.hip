@@ -93,6 +93,7 @@ struct gfw_ctx {
     DevBuf d_p1_table, d_audit;
     float p1_eps_last = 0.0f;                      // certificate half-width of the last frame set up (reported in gfw_get_audit's word 6)
     float p1_k[4] = {0, 0, 0, 0}; float p1_rho_max = 0.0f; double p1_etab = 0.0; double p1_smax = 1.0; bool p1_valid = false;
+    double p1_slope = 0.0, p1_kappa = 0.0;         // max |ds/drho| over the table's range; roundoff amplification of the exact path's theta_d/r (section 2c)
     DevBuf d_pts_in, d_pts_out, d_pts_rot, d_pts_shift, d_pts_mesh;   // gfw_undistort_points staging
     DevBuf d_tracks;                              // quaternion tracks
     // context-owned per-row tables built on the device (gfw_build_matrices): a small ring, built on copy_stream so that
@@ -363,7 +364,7 @@ int gfw_get_audit(gfw_ctx *c, unsigned long long *counters8, int reset) {
     if (fresh) HIP_TRY(hipMemsetAsync(c->d_audit.ptr, 0, 8 * sizeof(unsigned long long), c->stream), GFW_ERR_HIP);
     HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
     HIP_TRY(hipMemcpy(counters8, c->d_audit.ptr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost), GFW_ERR_HIP);
-    { uint32_t bits; memcpy(&bits, &c->p1_eps_last, 4); counters8[6] = bits; }      // E of the last frame, f32 bits
+    if (counters8[6] == 0) { uint32_t bits; memcpy(&bits, &c->p1_eps_last, 4); counters8[6] = bits; }      // E (f32 bits): the largest an audited launch used, else the host's estimate for the last frame
     if (reset) HIP_TRY(hipMemset(c->d_audit.ptr, 0, 8 * sizeof(unsigned long long)), GFW_ERR_HIP);
     return GFW_OK;
 }
@@ -562,29 +563,50 @@ static int p1_prepare_table(gfw_ctx *c, const gfw_kernel_params &p, float rho_ma
     const int N = GFW_P1_TABLE_N;
     std::vector<float2> tab(N + 1);
     const double h = (double)rho_max / N;
-    double etab = 0.0, smax = 0.0;
+    double etab = 0.0, smax = 0.0, slope = 0.0;
     double s_prev = p1_s_of_rho(0.0, p.k);
     for (int i = 0; i < N; ++i) {
         const double s_next = p1_s_of_rho((i + 1) * h, p.k);
         tab[i] = float2{(float)s_prev, (float)(s_next - s_prev)};
-        // interpolation error at the eighth points of the interval, against the float entries actually stored
-        for (int q = 1; q < 8; ++q) {
+        // interpolation error at the eighth points of the interval, against the float entries actually stored; |ds/drho| from the chords between them
+        double s_at = s_prev;
+        for (int q = 1; q <= 8; ++q) {
             const double fr = q / 8.0;
-            const double lerp = (double)tab[i].x + fr * (double)tab[i].y;
-            etab = fmax(etab, fabs(lerp - p1_s_of_rho((i + fr) * h, p.k)));
+            const double s_q = q == 8 ? s_next : p1_s_of_rho((i + fr) * h, p.k);
+            if (q < 8) etab = fmax(etab, fabs((double)tab[i].x + fr * (double)tab[i].y - s_q));
+            slope = fmax(slope, fabs(s_q - s_at) * 8.0 / h);
+            s_at = s_q;
         }
         smax = fmax(smax, fmax(fabs(s_prev), fabs(s_next)));
         s_prev = s_next;
     }
     tab[N] = float2{(float)s_prev, 0.0f};
-    if (!(etab == etab) || !(smax == smax)) { c->p1_valid = false; return GFW_OK; }
+    // the exact path's theta_d / r as a function of its (already rounded) rho: sqrt (1 rounding), glibc atanf (< 1 ulp = 2 roundings), the polynomial
+    // 1 + k0 t^2 + k1 t^4 + k2 t^6 + k3 t^8 (powers by repeated products: 2, 4, 6, 8 roundings on the terms, 4 on the partial sums), t * poly, / r:
+    // relative error <= u * kappa, kappa = 3.5 (1 + R) + (R + 4 K) + 3 with R = max sum (2i |k_i| t^2i) / |P| (both t P'/P's bound and the terms' own
+    // roundings) and K = max sum |terms| / |P| (the partial sums)  
+    double kappa = 3.0;                                             // all four k zero: the exact path is (X/W) * f + c, nothing of the above
+    if (!(p.k[0] == 0.0f && p.k[1] == 0.0f && p.k[2] == 0.0f && p.k[3] == 0.0f)) {
+        const double tmax = atan(sqrt((double)rho_max));
+        double rp = 0.0, kp = 1.0;
+        for (int i = 0; i <= 4096; ++i) {
+            const double t2 = (tmax * i / 4096.0) * (tmax * i / 4096.0), t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+            const double P = 1.0 + p.k[0] * t2 + p.k[1] * t4 + p.k[2] * t6 + p.k[3] * t8;
+            const double Pabs = 1.0 + fabs(p.k[0]) * t2 + fabs(p.k[1]) * t4 + fabs(p.k[2]) * t6 + fabs(p.k[3]) * t8;
+            const double dPabs = 2.0 * fabs(p.k[0]) * t2 + 4.0 * fabs(p.k[1]) * t4 + 6.0 * fabs(p.k[2]) * t6 + 8.0 * fabs(p.k[3]) * t8;
+            if (!(fabs(P) > 1e-3)) { rp = kp = 1e30; break; }     // theta_d's polynomial (nearly) vanishes inside the range: no certificate
+            rp = fmax(rp, dPabs / fabs(P)); kp = fmax(kp, Pabs / fabs(P));
+        }
+        kappa = 4.5 * rp + 4.0 * kp + 6.5;
+    }
+    if (!(etab == etab) || !(smax == smax) || !(slope == slope) || !(kappa == kappa)) { c->p1_valid = false; return GFW_OK; }
     if (!c->dry) {
         HIP_TRY(c->d_p1_table.ensure((N + 1) * sizeof(float2)), GFW_ERR_HIP);
         HIP_TRY(hipMemcpyAsync(c->d_p1_table.ptr, tab.data(), (N + 1) * sizeof(float2), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
         HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);      // `tab` is a stack-lifetime source
     }
     memcpy(c->p1_k, p.k, sizeof(c->p1_k));
-    c->p1_rho_max = rho_max; c->p1_etab = etab; c->p1_smax = smax; c->p1_valid = true;
+    c->p1_rho_max = rho_max; c->p1_etab = etab; c->p1_smax = smax; c->p1_slope = slope; c->p1_kappa = kappa; c->p1_valid = true;
     return GFW_OK;
 }
 // Fill the first-pass fields of the fused kernel's arguments; returns true when the certified pass may be used.
@@ -621,13 +643,30 @@ static bool p1_setup(gfw_ctx *c, const gfw_kernel_params &p0, const float *h_mat
     const double f = fabs((double)(hrs ? p0.f[0] : p0.f[1])), cc = fabs((double)(hrs ? p0.c[0] : p0.c[1]));
     const double rmax = sqrt((double)c->p1_rho_max);
     const double vmag = f * rmax * c->p1_smax + cc;
-    // bound on |approx - exact|: ~12 roundings of relative size 2^-24 on each path (1.2e-6
-    // of the term magnitude), taken 1.5x, plus the table's interpolation error carried through f*b, taken 2x, plus an
-    // absolute floor.  The audit (tests/test_gpu_pass1.py) measures the real gap at <= 1/8 of this on every frame.
-    const double eps = 1.5 * 1.2e-6 * vmag + 2.0 * f * rmax * c->p1_etab + 1.0 / 4096.0;
+    // E >= |approx - exact| (derived operation by operation): with u = 2^-24,
+    //   E = 1.05 u { G * (mu + rmax omega + 10 rmax) + 6 |f| rmax rho_max S' + |f| rmax smax (kappa + 4) + 2 vmag } + 2 |f| rmax e_table + 2^-14,
+    //   G = |f| smax + 2 sqrt2 |f| rmax^2 S',   S' = max |ds/drho|,
+    // mu and omega measure the rounding error of the mid-row matrix's linear forms relative to W (gfw_frame.hip: p1_bound): the kernel
+    // evaluates them from the matrix it actually uses (device-resident tables included) and forms E = p1_eps + p1_ew * omega + p1_em * mu per frame.
+    const double u24 = 1.05 / 16777216.0;
+    const double G = f * c->p1_smax + 2.0 * M_SQRT2 * f * rmax * rmax * c->p1_slope;
+    const double e0 = u24 * (G * 10.0 * rmax + 6.0 * f * rmax * (double)c->p1_rho_max * c->p1_slope + f * rmax * c->p1_smax * (c->p1_kappa + 4.0) + 2.0 * vmag)
+                    + 2.0 * f * rmax * c->p1_etab + 1.0 / 16384.0;
+    const double ew = u24 * G * rmax, em = u24 * G;
+    // the host's own view of omega, mu (only to decide whether the certified pass is worth launching and to report E; the kernel's value decides)
+    double omega = 1.0, mu = 6.0 * (rmax + 1.0);
+    if (h_matrices) {
+        const float *m = h_matrices + (size_t)(matrix_count >> 1) * 14;
+        const double x0 = p0.translation2d[0], x1 = x0 + p0.output_width, y0 = p0.translation2d[1], y1 = y0 + p0.output_height;
+        const double ax = fmax(fabs(x0), fabs(x1)), ay = fmax(fabs(y0), fabs(y1));
+        const double px = ax * fabs(m[0]) + ay * fabs(m[1]), py = ax * fabs(m[3]) + ay * fabs(m[4]), pw = ax * fabs(m[6]) + ay * fabs(m[7]);
+        const double wden = fmax((double)m[8] - pw, fmax(1.0 / 1024.0, (pw + fabs(m[8])) / 8.0));
+        omega = 3.0 * pw / wden; mu = 3.0 * fmax(px, py) / wden;
+    }
+    const double eps = e0 + ew * omega + em * mu;
     Y.p1_table = (const float2 *)c->d_p1_table.ptr;
     Y.p1_rho_max = c->p1_rho_max; Y.p1_rho_scale = (float)(GFW_P1_TABLE_N / (double)c->p1_rho_max);
-    Y.p1_eps = (float)eps;
+    Y.p1_eps = (float)e0; Y.p1_ew = (float)ew; Y.p1_em = (float)em;
     c->p1_eps_last = (float)eps;
     Y.p1_f = hrs ? p0.f[0] : p0.f[1]; Y.p1_c = hrs ? p0.c[0] : p0.c[1];
     table_ok = true;
@@ -968,7 +1007,7 @@ static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps,
     // cache lookup cost ~15 us of host time, a frame's worth of validation): header, key and function are rebuilt only when it changes
     GfwYuvArgs K = Y;
     for (int i = 0; i < 4; ++i) { K.pl[i].src = nullptr; K.pl[i].dst = nullptr; K.pl[i].src_len = 0; K.pl[i].dst_len = 0; }
-    K.matrices = nullptr; K.p1_table = nullptr; K.p1_rho_max = 0.0f; K.p1_rho_scale = 0.0f; K.p1_eps = 0.0f; K.audit = nullptr; K.grid_limit = 0;
+    K.matrices = nullptr; K.p1_table = nullptr; K.p1_rho_max = 0.0f; K.p1_rho_scale = 0.0f; K.p1_eps = 0.0f; K.p1_ew = 0.0f; K.p1_em = 0.0f; K.audit = nullptr; K.grid_limit = 0;
     memset(&K.kp, 0, sizeof(K.kp));
     { const int dig = K.common.digital; memset(&K.common, 0, sizeof(K.common)); K.common.digital = dig; }
     const int key_misc[8] = {bps, taps, n0, dw, dh, interleaved ? 1 : 0, fast1 ? 1 : 0, c->tune_grid};
@@ -1058,7 +1097,7 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
         if (jf && batch && all_device && c->bslot_cur < 0 && c->mslot_cur < 0) {      // (a table of the cross-stream ring is ordered by events: frame by frame)
             // the frame joins the clip launch being assembled; a frame that does not share the pending ones' kernel or first-pass table goes out behind them
             if (batch->n > 0 && (batch->fn != jf || batch->CA.Y.p1_table != Y.p1_table || batch->CA.Y.p1_rho_max != Y.p1_rho_max ||
-                                 batch->CA.Y.p1_rho_scale != Y.p1_rho_scale || batch->CA.Y.p1_eps != Y.p1_eps || clip_overlaps(batch, planes, nplanes))) {
+                                 batch->CA.Y.p1_rho_scale != Y.p1_rho_scale || batch->CA.Y.p1_eps != Y.p1_eps || batch->CA.Y.p1_ew != Y.p1_ew || clip_overlaps(batch, planes, nplanes))) {
                 const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc;
             }
             if (batch->n == 0) { batch->CA.Y = Y; batch->fn = jf; batch->grid = jgrid; batch->first = planes; batch->backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit"; }
@@ -1074,6 +1113,8 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
         if (jf) {
             GfwClipArgs CA;
             CA.Y = Y; CA.n_frames = 1; CA.pad_ = 0;
+            for (int i = 0; i < 4; ++i) { CA.fr[0].src[i] = Y.pl[i].src; CA.fr[0].dst[i] = Y.pl[i].dst; }
+            CA.fr[0].matrices = Y.matrices;
             HIP_TRY(gfw_jit_launch(jf, CA, jgrid, c->stream), GFW_ERR_HIP);
             c->last_backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit";
         } else {

@@ -52,7 +52,8 @@ struct GfwYuvArgs {
     // certified first pass (gfw_frame.hip): table of (s_i, s_{i+1}-s_i) over rho in [0, rho_max], certificate half-width
     const float2 *p1_table;
     float p1_rho_max, p1_rho_scale;   // scale = N / rho_max
-    float p1_eps;                     // E: bound on |approx - exact| of the projected row/column coordinate, pixels
+    float p1_eps, p1_ew, p1_em;       // E = p1_eps + p1_ew * omega + p1_em * mu: bound on |approx - exact| of the projected row/column coordinate, pixels;
+                                      // omega, mu = the cancellation measures of the frame's mid-row matrix, evaluated by the kernel
     float p1_f, p1_c;                 // f[1], c[1] (f[0], c[0] for horizontal rolling shutter)
     unsigned long long *audit;        // nullptr, or 8 words: certified, certified-but-wrong, queued, queue-overflow, max |approx-exact| (f32 bits),
                                       // [5] global addresses outside their buffer (audit mode range-checks every tap, store, matrix row and table entry)

@@ -76,6 +76,9 @@
                                  // 57.3 / 56.4 / 56.0 / 55.5 / 55.0 / 55.1 / 55.6 / 56.4 / 56.9 / 58.4 us; 1080p (18 rows per wave) wants 3, 8K
                                  // (253 rows) 16 or more: the step is a sixth of the wave's work (profiles/r03_ab_waves_priority.txt)
 #endif
+#ifndef GFW_P1_E_SCALE
+#define GFW_P1_E_SCALE 1.0f      // A/B only: scales the derived certificate half-width (what its width costs: profiles/r04_ab_certificate.txt)
+#endif
 #ifndef GFW_FASTROW
 #define GFW_FASTROW 1            // the branch-free lane-row of phase 3 (rd_lean_nobranch + one `__any` / `__all` per stage); 0: the per-pixel divergent code only (A/B)
 #endif
@@ -114,7 +117,10 @@ namespace {
 #if defined(GFW_HOST_INTERPRETER)
 #define gfw_all(p) __all(p)
 #define gfw_any(p) __any(p)
+static inline float gfw_uniform(float v) { return v; }
 #else
+// a wave-uniform value the compiler computed with vector instructions: into a scalar register (else it occupies a VGPR of every lane for the whole kernel)
+__device__ __forceinline__ float gfw_uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 __device__ __forceinline__ bool gfw_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
 __device__ __forceinline__ bool gfw_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 #endif
@@ -979,7 +985,7 @@ __device__ __forceinline__ void feather_store(float ux, float uy, const Feather 
 // else — a percent or two of the pixels — goes through the exact projection: queued in LDS per wave and resolved
 // densely (one exact pass per few rows of the wave instead of one per pixel row).
 struct Mid { float m0, m1, m2, m3, m4, m5, m6, m7, m8; };
-struct P1 { float rho_max, rho_scale, eps, f, c, lim; };
+struct P1 { float rho_max, rho_scale, eps, f, c, lim, wmin; };
 
 template <int MODEL>
 __device__ __forceinline__ int default_row(float ox, float oy, const GfwYuvArgs &A) {
@@ -1005,7 +1011,7 @@ __device__ __forceinline__ bool pass1_fast(float ax, float ay, float aw, float o
     const float a = X * rw, b = Y * rw;
     const float rho = __builtin_fmaf(a, a, b * b);
     // W safely positive (the exact path decides validity otherwise) and rho inside the table (NaN fails both)
-    bool good = (W > 0.0009765625f) & (rho < Q.rho_max);
+    bool good = (W > Q.wmin) & (rho < Q.rho_max);
     if (rl2 > 0.0f) {                                              // :139 — decide only when clear of the boundary
         const float lhs = __builtin_fmaf(X, X, Y * Y), rhs = rl2 * W;
         good = good & (lhs < rhs * 0.9999f);
@@ -1071,6 +1077,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     __shared__ unsigned short q_dst[FAST1 ? 4 : 1][FAST1 ? QCAP : 1];           // (owner lane << 6) | slot in s_rows
     __shared__ unsigned short s_rows[RB * NPX][256];                             // phase-1 rows (< 65536: the host keeps larger frames off this path), one column per lane
     __shared__ float s_lut[I == 2 ? 1 : 448];                                    // bicubic / Lanczos4 tap table
+    __shared__ float2 s_p1[FAST1 ? GFW_CLIP_MAX : 1];                            // per frame of the launch: certificate half-width E, W threshold
     const int wave = threadIdx.y, lane = threadIdx.x, tid = wave * 64 + lane;
     if (MODEL == GFW_MODEL_OPENCV_FISHEYE) { gfw_atan_lds_init(tid); gfw_atan_key_lds_init(tid); }
     if (I != 2) {
@@ -1095,17 +1102,61 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     float bg_c[2] = {PL1.bg[0], PL1.bg[1]};
     const float lim_u = PL1.limit, bg_v = PL2.bg[0], lim_v = PL2.limit;
     Mid M{0, 0, 0, 0, 0, 0, 0, 0, 0};
-    P1 Q{0, 0, 0, 0, 0, 0};
+    P1 Q{0, 0, 0, 0, 0, 0, 0};
     auto load_mid = [&]() {                          // first-pass matrix of the current frame: wave-uniform -> scalar loads
         const float *mid = matrices + (size_t)(AF(matrix_count) >> 1) * GFW_MAT_STRIDE;
         M.m0 = mid[0]; M.m1 = mid[1]; M.m2 = mid[2]; M.m3 = mid[3]; M.m4 = mid[4];
         M.m5 = mid[5]; M.m6 = mid[6]; M.m7 = mid[7]; M.m8 = mid[8];
     };
+    // The certificate's half-width per frame of the launch: E = e0 + ew * omega + em * mu with the host's lens-dependent
+    // coefficients and two matrix-dependent measures of the rounding error of the linear forms X, Y, W of the frame's mid-row matrix.  With
+    // P_X = |ox m0| + |oy m1|, the exact path's X = fl(fl(fl(ox m0) + fl(oy m1)) + m2) is within u (2 P_X + |X|) of the real value and the first
+    // pass's fma(oy, m1, fma(ox, m0, m2)) within u (P_X + 2 |X|): mu = 3 max(P_X, P_Y) / W and omega = 3 P_W / W carry the two paths' sum through
+    // the division (the |X| terms are in e0).  The P's are maximal at the frame's extreme |ox|, |oy| (literals in a baked build); W >= m8 - P_W
+    // everywhere; pixels with W below wmin = max(2^-10, (P_W + |m8|) / 8) are left to the exact path, which keeps omega <= 24 whatever the
+    // matrix.  E >= 0.2 px, a NaN anywhere, or an r-limit test that the margin in pass1_fast cannot decide: no pixel of the frame is certified.
+    // Thread j of the workgroup evaluates frame j of the launch ONCE, into LDS; a frame change reads two words.  (Evaluated by every wave at
+    // every frame change — 35 wave-uniform vector instructions behind the matrix loads — it cost 1.05 us of C2's 46: profiles/r04_ab_certificate.txt.)
+    if (FAST1 && two_pass) {
+        if (tid < n_frames) {
+#if GFW_BAKE
+            const float *mid = (tid > 0 ? clip->fr[tid].matrices : matrices) + (size_t)(AF(matrix_count) >> 1) * GFW_MAT_STRIDE;   // (frame 0: the argument block's own table)
+#else
+            const float *mid = matrices + (size_t)(AF(matrix_count) >> 1) * GFW_MAT_STRIDE;
+#endif
+            const float m0 = mid[0], m1 = mid[1], m3 = mid[3], m4 = mid[4], m6 = mid[6], m7 = mid[7], m8 = mid[8];
+            const float ax = fmaxf(fabsf(L.t2x), fabsf((float)AF(out_w) + L.t2x)), ay = fmaxf(fabsf(L.t2y), fabsf((float)AF(out_h) + L.t2y));
+            const float px = ax * fabsf(m0) + ay * fabsf(m1), py = ax * fabsf(m3) + ay * fabsf(m4), pw = ax * fabsf(m6) + ay * fabsf(m7);
+            const float wmin = fmaxf(0.0009765625f, 0.125f * (pw + fabsf(m8)));
+            const float rden = gfw_hw_rcp(fmaxf(m8 - pw, wmin)) * 3.003f;            // (3x; 1 ulp reciprocal and the roundings of the sums above: inside the 0.1 %)
+            const float omega = pw * rden, mu = fmaxf(px, py) * rden;
+#if defined(GFW_P1_BOUND_OFF)                                                            // A/B only (what deriving E in the kernel costs): a constant, unsound E
+            const float E = 1.4f * A.p1_eps;
+#else
+            const float E = GFW_P1_E_SCALE * __builtin_fmaf(A.p1_em, mu, __builtin_fmaf(A.p1_ew, omega, A.p1_eps));
+#endif
+            bool usable = (E < 0.2f) & (pw + m8 < 3.0e38f);                           // (a NaN or an infinity among the operands fails a comparison)
+            if (L.rl2 > 0.0f) {
+                // :139 in pass1_fast: lhs < 0.9999 rhs must imply the exact path's lhs <= rhs.  The two paths' X^2 + Y^2 differ by at most
+                // 1.05 u W^2 (2 sqrt2 rmax mu + 12.5 rho_max), their r_limit^2 W by r_limit^2 W u (omega + 8); W <= m8 + P_W; 1e-4 / u = 1677.7
+                const float rmax = __builtin_sqrtf(A.p1_rho_max);
+                usable = usable & (1.05f * (m8 + pw) * (2.83f * rmax * mu + 12.5f * A.p1_rho_max) + L.rl2 * (omega + 8.0f) <= 1677.0f * L.rl2);
+            }
+            s_p1[tid] = float2{E, usable ? wmin : __builtin_inff()};                 // W > inf never holds: every pixel of the frame goes to the exact path
+            if (AUDIT && usable) atomicMax(&AF(audit)[6], (unsigned long long)gfw_f2u(E));
+        }
+        __syncthreads();
+    }
+    auto p1_bound = [&](int fi) {
+        const float2 q = s_p1[fi];
+        Q.eps = gfw_uniform(q.x); Q.wmin = gfw_uniform(q.y);
+    };
     if (two_pass) {
         load_mid();
         if (FAST1) {
-            Q.rho_max = A.p1_rho_max; Q.rho_scale = A.p1_rho_scale; Q.eps = A.p1_eps;
+            Q.rho_max = A.p1_rho_max; Q.rho_scale = A.p1_rho_scale;
             Q.f = AF(p1_f); Q.c = AF(p1_c); Q.lim = (float)(AF(hrs) ? AF(width) : AF(height));
+            p1_bound(0);
         }
     }
 
@@ -1153,7 +1204,10 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
             PL0.src = clip->fr[fi].src[0]; PL0.dst = clip->fr[fi].dst[0]; PL1.src = clip->fr[fi].src[1]; PL1.dst = clip->fr[fi].dst[1];
             PL2.src = clip->fr[fi].src[2]; PL2.dst = clip->fr[fi].dst[2]; PL3.src = clip->fr[fi].src[3]; PL3.dst = clip->fr[fi].dst[3];
             matrices = clip->fr[fi].matrices;
-            if (two_pass) load_mid();
+            if (two_pass) {
+                load_mid();
+                if (FAST1) p1_bound(fi);
+            }
         }
 #endif
 #if GFW_PRIO_MODE == 1

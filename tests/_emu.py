@@ -97,7 +97,7 @@ def build(defs, header, top="gfw_frame.hip", n_asm=7, driver="emu_driver.inc", e
 
 def p1_table(p0, matrices, matrix_count):
     """gfw_api.hip p1_setup / p1_prepare_table restated: the s(rho) table of the certified first pass (f64 -> float2 entries), its range and
-    the certificate half-width E.  -> (table [N+1][2] f32, rho_max, rho_scale, eps) or None when the certified pass is not used."""
+    the certificate's coefficients.  -> (table [N+1][2] f32, rho_max, rho_scale, (e0, ew, em, host's E)) or None when the certified pass is not used."""
     k = [float(p0.k[i]) for i in range(4)]
     hrs = bool(p0.flags & abi.FLAG_HORIZONTAL_RS)
     m = np.asarray(matrices, dtype=np.float64)[matrix_count >> 1]
@@ -123,20 +123,52 @@ def p1_table(p0, matrices, matrix_count):
     h = rho_max / n
     s = [s_of(i * h) for i in range(n + 1)]
     tab = np.zeros((n + 1, 2), dtype=np.float32)
-    etab = smax = 0.0
+    etab = smax = slope = 0.0
     for i in range(n):
         tab[i] = (s[i], s[i + 1] - s[i])
-        for q in range(1, 8):
-            etab = max(etab, abs(float(tab[i, 0]) + q / 8.0 * float(tab[i, 1]) - s_of((i + q / 8.0) * h)))
+        s_at = s[i]
+        for q in range(1, 9):
+            s_q = s[i + 1] if q == 8 else s_of((i + q / 8.0) * h)
+            if q < 8:
+                etab = max(etab, abs(float(tab[i, 0]) + q / 8.0 * float(tab[i, 1]) - s_q))
+            slope = max(slope, abs(s_q - s_at) * 8.0 / h)
+            s_at = s_q
         smax = max(smax, abs(s[i]), abs(s[i + 1]))
     tab[n] = (s[n], 0.0)
+    kappa = 3.0
+    if any(v != 0.0 for v in k):
+        tmax = math.atan(math.sqrt(rho_max))
+        rp, kp = 0.0, 1.0
+        for i in range(4097):
+            t2 = (tmax * i / 4096.0) ** 2
+            t4 = t2 * t2
+            t6, t8 = t4 * t2, t4 * t4
+            P = 1.0 + k[0] * t2 + k[1] * t4 + k[2] * t6 + k[3] * t8
+            Pabs = 1.0 + abs(k[0]) * t2 + abs(k[1]) * t4 + abs(k[2]) * t6 + abs(k[3]) * t8
+            dPabs = 2.0 * abs(k[0]) * t2 + 4.0 * abs(k[1]) * t4 + 6.0 * abs(k[2]) * t6 + 8.0 * abs(k[3]) * t8
+            if not abs(P) > 1e-3:
+                rp = kp = 1e30
+                break
+            rp, kp = max(rp, dPabs / abs(P)), max(kp, Pabs / abs(P))
+        kappa = 4.5 * rp + 4.0 * kp + 6.5
     f = abs(float(p0.f[0] if hrs else p0.f[1]))
     c = abs(float(p0.c[0] if hrs else p0.c[1]))
     rmax = math.sqrt(rho_max)
-    eps = 1.5 * 1.2e-6 * (f * rmax * smax + c) + 2.0 * f * rmax * etab + 1.0 / 4096.0
+    vmag = f * rmax * smax + c
+    u24 = 1.05 / 16777216.0
+    G = f * smax + 2.0 * math.sqrt(2.0) * f * rmax * rmax * slope
+    e0 = u24 * (G * 10.0 * rmax + 6.0 * f * rmax * rho_max * slope + f * rmax * smax * (kappa + 4.0) + 2.0 * vmag) + 2.0 * f * rmax * etab + 1.0 / 16384.0
+    ew, em = u24 * G * rmax, u24 * G
+    # the host's view of omega, mu (the kernel's own evaluation decides; this one only whether the certified instantiation is launched)
+    x0, y0 = float(p0.translation2d[0]), float(p0.translation2d[1])
+    x1, y1 = x0 + p0.output_width, y0 + p0.output_height
+    ax, ay = max(abs(x0), abs(x1)), max(abs(y0), abs(y1))
+    px, py, pw = ax * abs(m[0]) + ay * abs(m[1]), ax * abs(m[3]) + ay * abs(m[4]), ax * abs(m[6]) + ay * abs(m[7])
+    wden = max(m[8] - pw, 1.0 / 1024.0, (pw + abs(m[8])) / 8.0)
+    eps = e0 + ew * 3.0 * pw / wden + em * 3.0 * max(px, py) / wden
     if matrix_count <= 1 or not eps < 0.2:
         return None
-    return tab, rho_max, float(np.float32(n / rho_max)), float(np.float32(eps))
+    return tab, rho_max, float(np.float32(n / rho_max)), (float(np.float32(e0)), float(np.float32(ew)), float(np.float32(em)), float(eps))
 
 
 SAMPLE_KIND = {"Luma8": (1, 1), "Luma16": (2, 1), "RGB8": (1, 3), "RGBA8": (1, 4), "BGRA8": (1, 4), "RGB16": (2, 3), "RGBA16": (2, 4), "AYUV16": (2, 4),
@@ -276,7 +308,7 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=F
     small = len(frames) * p0.output_width * p0.output_height < 400000              # small launches: an unoptimised build compiles faster than it runs slower
     lib = C.CDLL(build(defs, header, opt="-O0" if small else "-O1", extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=%d" % (1 if baked else 0), "-DEMU_VOTES=%d" % votes, "-DEMU_HW_ULP=%d" % hw_ulp, "-DEMU_AUDIT=%d" % (1 if audit else 0))))
     lib.gfw_emu_launch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
-                                   C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     n = len(frames)
     pints, pfloats = np.zeros(24, np.int32), np.zeros(20, np.float32)        # the plane descriptors of the argument block (build_yuv_args); [16..23]: declared lengths
     for i, pl in enumerate(fr0.planes):
@@ -313,7 +345,7 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=F
         mesh = np.ascontiguousarray(mesh, dtype=np.float32)
         com.mesh, com.mesh_len = mesh.ctypes.data, mesh.size
     kp = fr0.planes[0]["params"]
-    rc = lib.gfw_emu_launch(n, srcs, dsts, mats, tab.ctypes.data, p1[1] if fast1 else 0.0, p1[2] if fast1 else 0.0, p1[3] if fast1 else 0.0,
+    rc = lib.gfw_emu_launch(n, srcs, dsts, mats, tab.ctypes.data, p1[1] if fast1 else 0.0, p1[2] if fast1 else 0.0, *(p1[3][:3] if fast1 else (0.0, 0.0, 0.0)),
                             C.cast(C.byref(kp), C.c_void_p), C.cast(C.byref(com), C.c_void_p), grid, pints.ctypes.data, pfloats.ctypes.data)
     assert rc == 0, "gfw_emu_launch -> %d" % rc
     if audit:
@@ -321,7 +353,8 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=F
         lib.gfw_emu_audit(words, 1)
         gap = float(np.array([int(words[4]) & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0])
         return outs, {"certified": int(words[0]), "wrong": int(words[1]), "queued": int(words[2]), "queue_overflow": int(words[3]), "gap_px": gap,
-                      "out_of_range": int(words[5]), "eps_px": p1[3] if fast1 else None}
+                      "out_of_range": int(words[5]), "eps_px": float(np.array([int(words[6]) & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0]) if fast1 else None,
+                      "eps_host_px": p1[3][3] if fast1 else None}
     return outs
 
 

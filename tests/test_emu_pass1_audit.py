@@ -33,3 +33,33 @@ def test_every_certificate_of_a_random_clip(seed):
     assert a["wrong"] == 0 and a["queue_overflow"] == 0 and a["out_of_range"] == 0, a
     assert a["certified"] > 0 and a["gap_px"] < 0.5 * a["eps_px"], a
     assert all(np.array_equal(x, y) for x, y in zip(O.run_frame(fr), outs[0]))
+
+
+def shifted_frame(shift, fmt="YUV422P16LE", w=640, h=360, seed=3):
+    """The same geometry through coordinates far from the origin: translation2d = (shift, shift) and the matrices' constant terms moved the other
+    way, so X = ox m0 + oy m1 + m2 is a small difference of large terms — rounding errors of size u * shift * |m0| that a certificate derived
+    from the lens alone (rounds 2-3: 1.8e-6 * (|f| rmax smax + |c|) + ...) does not know about."""
+    fr = S.SyntheticFrame(fmt, w, h, seed=seed, base_overrides={"translation2d": (shift, shift)})
+    m, t = fr.matrices, np.float32(shift)
+    for col in (0, 3, 6):
+        m[:, col + 2] -= t * m[:, col] + t * m[:, col + 1]
+    return fr
+
+
+def test_cancellation_in_the_matrix_widens_the_certificate():
+    fr = shifted_frame(3e4)
+    p0 = fr.planes[0]["params"]
+    assert _emu.p1_table(p0, fr.matrices, p0.matrix_count) is not None
+    outs, a = _emu.run_frames([fr], audit=True)
+    assert a["wrong"] == 0 and a["certified"] > 0 and a["gap_px"] < a["eps_px"], a
+    # the measured gap is beyond what the lens-only bound of rounds 2-3 allowed: that certificate was unsound for such matrices
+    lens_only = 1.5 * 1.2e-6 * (abs(p0.f[1]) * 1.6 + abs(p0.c[1])) + 1.0 / 4096.0
+    assert a["gap_px"] > lens_only, (a, lens_only)
+    assert all(np.array_equal(x, y) for x, y in zip(O.run_frame(fr), outs[0]))
+
+
+def test_hopeless_cancellation_certifies_nothing_and_stays_exact():
+    fr = shifted_frame(3e5)
+    outs, a = _emu.run_frames([fr], audit=True)
+    assert a["wrong"] == 0 and a["certified"] == 0, a             # W's own terms dwarf it: every pixel is left to the exact projection
+    assert all(np.array_equal(x, y) for x, y in zip(O.run_frame(fr), outs[0]))
