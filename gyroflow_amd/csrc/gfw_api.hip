@@ -891,22 +891,24 @@ static bool clip_overlaps(const ClipBatch *b, const gfw_buffers *planes, int npl
     }
     return false;
 }
+// diagnosis (GFW_JIT_DEFS=GFW_TIMELINE=1 builds): the per-wave clocks of the 40th launch of a specialised kernel go to $GFW_TIMELINE_FILE (tools/analyze_timeline.py)
+static void timeline_dump(gfw_ctx *c, hipFunction_t fn) {
+    static const char *tl_file = getenv("GFW_TIMELINE_FILE");
+    static int n_launch = 0;
+    if (tl_file && ++n_launch == 40) {
+        std::vector<unsigned long long> host(8192 * 8);
+        (void)hipStreamSynchronize(c->stream);
+        if (gfw_jit_read_symbol(fn, "gfw_tl", host.data(), host.size() * 8))
+            if (FILE *f = fopen(tl_file, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+    }
+}
 static int clip_flush(gfw_ctx *c, ClipBatch *b) {
     if (!b || b->n == 0) return GFW_OK;
     b->CA.n_frames = b->n; b->CA.pad_ = 0;
     prof_begin(c);
     const hipError_t e = gfw_jit_launch(b->fn, b->CA, b->grid, c->stream);
     prof_end(c, b->n);
-    {   // diagnosis (GFW_JIT_DEFS=GFW_TIMELINE=1 builds): the 40th clip launch's per-wave clocks go to $GFW_TIMELINE_FILE (tools/analyze_timeline.py)
-        static const char *tl_file = getenv("GFW_TIMELINE_FILE");
-        static int n_launch = 0;
-        if (tl_file && ++n_launch == 40) {
-            std::vector<unsigned long long> host(8192 * 8);
-            (void)hipStreamSynchronize(c->stream);
-            if (gfw_jit_read_symbol(b->fn, "gfw_tl", host.data(), host.size() * 8))
-                if (FILE *f = fopen(tl_file, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
-        }
-    }
+    timeline_dump(c, b->fn);
     b->n = 0;
     if (e != hipSuccess) { set_error("clip launch failed: %s", hipGetErrorString(e)); return GFW_ERR_HIP; }
     return GFW_OK;
@@ -1116,6 +1118,7 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
             for (int i = 0; i < 4; ++i) { CA.fr[0].src[i] = Y.pl[i].src; CA.fr[0].dst[i] = Y.pl[i].dst; }
             CA.fr[0].matrices = Y.matrices;
             HIP_TRY(gfw_jit_launch(jf, CA, jgrid, c->stream), GFW_ERR_HIP);
+            timeline_dump(c, jf);
             c->last_backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit";
         } else {
             HIP_TRY(gfw_launch_yuv(Y, bps, params[0].interpolation, n0, dw, dh, interleaved, fast1, c->stream), GFW_ERR_HIP);

@@ -1047,6 +1047,9 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     // loads, the uniform branches and the scalar registers they pin disappear — the reference bakes its per-clip constants into the
     // OpenCL source it compiles per clip the same way (opencl.rs:181-214).  Pointers and the per-frame fields stay arguments.
     const GfwYuvArgs &A = A_in;
+#if GFW_TIMELINE
+    const unsigned long long tl_start = wall_clock64();           // the wave's first instruction
+#endif
 #if GFW_BAKE
     const int n_frames = clip ? clip->n_frames : 1;
 #else
@@ -1177,7 +1180,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     const int wg_per_xcd = (int)gridDim.x >> 3;
     const int n_slots = per_xcd * n_frames;
 #if GFW_TIMELINE
-    const unsigned long long tl_start = wall_clock64();
+    const unsigned long long tl_ready = wall_clock64();           // set-up done (LDS tables, the frames' certificates, uniforms): the tile walk starts
     unsigned long long tl_p1 = 0, tl_p3 = 0, tl_units = 0;
 #endif
 #if GFW_PRIO_MODE
@@ -1540,7 +1543,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     if (lane == 0) {       // per wave: start, end (100 MHz device clock), phase clocks, lane-rows, HW_ID, XCC_ID, workgroup
         unsigned long long *o = gfw_tl + ((size_t)blockIdx.x * 4 + wave) * 8;
         o[0] = tl_start; o[1] = wall_clock64(); o[2] = tl_p1; o[3] = tl_p3; o[4] = tl_units;
-        o[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); o[6] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); o[7] = blockIdx.x;
+        o[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); o[6] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); o[7] = blockIdx.x | ((tl_ready - tl_start) << 32);
     }
 #endif
 }

@@ -11,6 +11,8 @@ t0 = start.min()
 s_us, e_us = (start - t0) / 100.0, (end - t0) / 100.0
 life = e_us - s_us
 print("waves %d   kernel span %.1f us   start: min %.1f max %.1f mean %.1f   end: min %.1f max %.1f mean %.1f" % (n, e_us.max(), s_us.min(), s_us.max(), s_us.mean(), e_us.min(), e_us.max(), e_us.mean()))
+setup = (a[:, 7].astype(np.int64) >> 32) / 100.0
+print("set-up before the tile walk, us: mean %.2f  p50 %.2f  p95 %.2f  max %.2f" % (setup.mean(), *np.percentile(setup, [50, 95]), setup.max()))
 print("wave lifetime us: mean %.1f  p5 %.1f  p50 %.1f  p95 %.1f max %.1f" % (life.mean(), *np.percentile(life, [5, 50, 95]), life.max()))
 units = a[:, 4].astype(np.int64)
 print("units(rows)/wave: min %d max %d mean %.2f;  us per row: mean %.2f" % (units.min(), units.max(), units.mean(), (life / np.maximum(units, 1)).mean()))
@@ -18,7 +20,7 @@ p1, p3 = a[:, 2].astype(np.float64), a[:, 3].astype(np.float64)
 print("phase clocks (s_memtime ticks): phase1+flush %.3g  phase3 %.3g  ratio p1/(p1+p3) %.3f" % (p1.sum(), p3.sum(), p1.sum() / (p1.sum() + p3.sum())))
 hw = a[:, 5].astype(np.int64); xcc = a[:, 6].astype(np.int64) & 0xf
 cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 3
-print("XCC ids seen:", sorted(set(xcc.tolist())), " blockIdx&7 == xcc for %.1f %% of waves" % (100.0 * np.mean((a[:, 7].astype(np.int64) & 7) == xcc)))
+print("XCC ids seen:", sorted(set(xcc.tolist())), " blockIdx&7 == xcc for %.1f %% of waves" % (100.0 * np.mean(((a[:, 7].astype(np.int64) & 0xffffffff) & 7) == xcc)))
 for x in sorted(set(xcc.tolist())):
     m = xcc == x
     print("  xcc %d: waves %4d  start mean %.1f  end mean %.1f max %.1f  life mean %.1f  rows %d" % (x, m.sum(), s_us[m].mean(), e_us[m].mean(), e_us[m].max(), life[m].mean(), units[m].sum()))
