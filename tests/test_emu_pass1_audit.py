@@ -63,3 +63,35 @@ def test_hopeless_cancellation_certifies_nothing_and_stays_exact():
     outs, a = _emu.run_frames([fr], audit=True)
     assert a["wrong"] == 0 and a["certified"] == 0, a             # W's own terms dwarf it: every pixel is left to the exact projection
     assert all(np.array_equal(x, y) for x, y in zip(O.run_frame(fr), outs[0]))
+
+
+def limited_shifted_clip(seed):
+    """random clip with an r_limit (cpu_undistort.rs:139: the first pass must agree with the exact path on which pixels have a point at all) and, every other seed,
+    coordinates moved away from the origin (the matrix-dependent part of the certificate)"""
+    rng = np.random.default_rng(70000 + seed)
+    w, h = int(rng.integers(60, 260)) * 2, int(rng.integers(40, 150)) * 2
+    lens = S.gopro_style_lens(w, h)
+    lens["f"] = (float(rng.uniform(0.35, 1.0)) * w,) * 2
+    lens["k"] = [float(rng.uniform(-0.05, 0.1)), float(rng.uniform(-0.04, 0.04)), float(rng.uniform(-0.02, 0.02)), float(rng.uniform(-0.01, 0.01))] + [0.0] * 8
+    lens["r_limit"] = float(rng.uniform(0.4, 2.5))
+    shift = float(rng.choice([0.0, 300.0, 3000.0, 20000.0])) if seed % 2 else 0.0
+    fr = S.SyntheticFrame(["YUV422P16LE", "NV12"][seed % 2], w, h, seed=int(rng.integers(1, 1 << 20)), lens=lens, fov=float(rng.uniform(0.8, 2.5)),
+                          readout_ms=float(rng.uniform(-25.0, 25.0)), base_overrides={"translation2d": (shift, -shift)})
+    m, t = fr.matrices, np.float32(shift)
+    for col in (0, 3, 6):
+        m[:, col + 2] -= t * m[:, col] - t * m[:, col + 1]
+    return fr
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_every_certificate_with_an_r_limit_and_shifted_coordinates(seed):
+    fr = limited_shifted_clip(seed)
+    p0 = fr.planes[0]["params"]
+    assert p0.r_limit > 0.0
+    if _emu.p1_table(p0, fr.matrices, p0.matrix_count) is None:
+        pytest.skip("no certified first pass for this clip")
+    outs, a = _emu.run_frames([fr], audit=True)
+    assert a["wrong"] == 0 and a["queue_overflow"] == 0 and a["out_of_range"] == 0, a
+    if a["certified"]:
+        assert a["gap_px"] < a["eps_px"], a
+    assert all(np.array_equal(x, y) for x, y in zip(O.run_frame(fr), outs[0]))
