@@ -76,9 +76,6 @@
                                  // 57.3 / 56.4 / 56.0 / 55.5 / 55.0 / 55.1 / 55.6 / 56.4 / 56.9 / 58.4 us; 1080p (18 rows per wave) wants 3, 8K
                                  // (253 rows) 16 or more: the step is a sixth of the wave's work (profiles/r03_ab_waves_priority.txt)
 #endif
-#ifndef GFW_P1_E_SCALE
-#define GFW_P1_E_SCALE 1.0f      // A/B only: scales the derived certificate half-width (what its width costs: profiles/r04_ab_certificate.txt)
-#endif
 #ifndef GFW_FASTROW
 #define GFW_FASTROW 1            // the branch-free lane-row of phase 3 (rd_lean_nobranch + one `__any` / `__all` per stage); 0: the per-pixel divergent code only (A/B)
 #endif
@@ -1133,11 +1130,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
             const float wmin = fmaxf(0.0009765625f, 0.125f * (pw + fabsf(m8)));
             const float rden = gfw_hw_rcp(fmaxf(m8 - pw, wmin)) * 3.003f;            // (3x; 1 ulp reciprocal and the roundings of the sums above: inside the 0.1 %)
             const float omega = pw * rden, mu = fmaxf(px, py) * rden;
-#if defined(GFW_P1_BOUND_OFF)                                                            // A/B only (what deriving E in the kernel costs): a constant, unsound E
-            const float E = 1.4f * A.p1_eps;
-#else
-            const float E = GFW_P1_E_SCALE * __builtin_fmaf(A.p1_em, mu, __builtin_fmaf(A.p1_ew, omega, A.p1_eps));
-#endif
+            const float E = __builtin_fmaf(A.p1_em, mu, __builtin_fmaf(A.p1_ew, omega, A.p1_eps));
             bool usable = (E < 0.2f) & (pw + m8 < 3.0e38f);                           // (a NaN or an infinity among the operands fails a comparison)
             if (L.rl2 > 0.0f) {
                 // :139 in pass1_fast: lhs < 0.9999 rhs must imply the exact path's lhs <= rhs.  The two paths' X^2 + Y^2 differ by at most
