@@ -86,12 +86,15 @@ def build(defs, header, top="gfw_frame.hip", n_asm=7, driver="emu_driver.inc", e
     key = hashlib.sha256((text + " ".join(flags) + "".join(open(os.path.join(EMU, f)).read() for f in sorted(os.listdir(EMU)))).encode()).hexdigest()[:20]
     so = os.path.join(OUT, "emu_%s.so" % key)
     if not os.path.exists(so):
-        cpp = os.path.join(OUT, "emu_%s.cpp" % key)
+        # names of this process's own: two pytest-xdist workers may build the same key at once, and a source file rewritten under a running compiler ends it with SIGBUS
+        cpp = os.path.join(OUT, "emu_%s.%d.cpp" % (key, os.getpid()))
+        tmp = "%s.%d.tmp" % (so, os.getpid())
         open(cpp, "w").write(text)
-        r = subprocess.run([CXX] + flags + [cpp, "-o", so + ".tmp", "-lm"], capture_output=True, text=True)
+        r = subprocess.run([CXX] + flags + [cpp, "-o", tmp, "-lm"], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("emulator build failed:\n" + r.stderr[-4000:])
-        os.replace(so + ".tmp", so)
+        os.replace(cpp, os.path.join(OUT, "emu_%s.cpp" % key))
+        os.replace(tmp, so)
     return so
 
 
