@@ -966,10 +966,16 @@ static std::string bake_header(const GfwYuvArgs &Y) {
 // The generic-model body keeps the rule — the lens-correction blend too, although it spills a few dwords at eight waves (GoPro lens, blend 0.5:
 // 141.5 us at 6 waves, 139.2 at 7, 134.4 at 8; fisheye + blend 140.5 / 137.4 / 135.9) — except with background mode 3 or the Sony mesh (two
 // samples per pixel, f64 splines: up to 80 registers), which get six.
-static int jit_waves(int n0, int matrix_count, int jit_model, int extras) {
+static int jit_waves(int n0, int matrix_count, int jit_model, int extras, int taps, int bps, int dh) {
     static const int forced = getenv("GFW_JIT_WAVES") ? atoi(getenv("GFW_JIT_WAVES")) : 0;      // experiments
     if (forced >= 1 && forced <= 8) return forced;
     if (jit_model < 0 && (extras & (16 | 32))) return 6;
+    // bicubic / Lanczos4 on single-channel integer planes: registers for the tap rows in flight are worth more than the seventh and eighth wave
+    // (gfw_frame.hip GFW_TAP_ROW_UNROLL; profiles/r04_ab_lut_rows.txt).  Not for bicubic on 16-bit planes with full-height chroma (C2's 4:2:2): there the six-wave
+    // build is 64 us from the ROCm 7.0 hiprtc that torch brings into the benchmark process and 78 us from the system's ROCm 7.2 (the build step's kernel cache, any host
+    // without torch) — against a steady 67.6 at eight waves from both.
+    if (n0 == 1 && bps <= 2 && taps == 4 && (bps == 1 || dh == 2)) return 6;
+    if (n0 == 1 && bps <= 2 && taps == 8) return bps == 1 ? 5 : 6;
     return (n0 == 1 && matrix_count > 1) ? 8 : 7;
 }
 // The definition list of a specialised build (with the bake header: everything that names the kernel)
@@ -1024,7 +1030,7 @@ static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps,
         c->jit_info = GfwJitInfo{GFW_JIT_UNAVAILABLE, 0.0, std::string()};
     }
     if (c->jit_mode == 1 && c->jit_seen < gfw_ctx::kJitAfter) return nullptr;          // one or two frames are not a clip
-    const int waves = jit_waves(n0, Y.matrix_count, jit_model, Y.extras);
+    const int waves = jit_waves(n0, Y.matrix_count, jit_model, Y.extras, taps, bps, dh);
     const std::vector<std::string> defs = jit_defs(Y, bps, taps, n0, dw, dh, interleaved, fast1, jit_model, waves);
     hipFunction_t fn = gfw_jit_get(c->device, c->arch, defs, c->jit_header, c->jit_mode == 2, &c->jit_info);
     if (!fn) { c->jit_dead = c->jit_info.state == GFW_JIT_FAILED || c->jit_info.state == GFW_JIT_UNAVAILABLE; return nullptr; }
@@ -1434,7 +1440,7 @@ extern "C" int gfw_debug_jit_key(int nplanes, const gfw_buffers *planes, const g
         set_error("not a frame the fused kernel serves"); return GFW_ERR_UNSUPPORTED_BUFFER; }
     fill_common(&c, &params[0], nullptr, nullptr, 0, Y.common);
     const int jit_model = jit_model_of(Y);
-    const std::vector<std::string> defs = jit_defs(Y, bps, params[0].interpolation, n0, dw, dh, interleaved, fast1, jit_model, jit_waves(n0, Y.matrix_count, jit_model, Y.extras));
+    const std::vector<std::string> defs = jit_defs(Y, bps, params[0].interpolation, n0, dw, dh, interleaved, fast1, jit_model, jit_waves(n0, Y.matrix_count, jit_model, Y.extras, params[0].interpolation, bps, dh));
     std::string d;
     for (const std::string &x : defs) { if (!d.empty()) d += ";"; d += x; }
     const std::string header = bake_header(Y), name = gfw_jit_cache_name(arch, defs, header);

@@ -76,6 +76,17 @@
                                  // 57.3 / 56.4 / 56.0 / 55.5 / 55.0 / 55.1 / 55.6 / 56.4 / 56.9 / 58.4 us; 1080p (18 rows per wave) wants 3, 8K
                                  // (253 rows) 16 or more: the step is a sixth of the wave's work (profiles/r03_ab_waves_priority.txt)
 #endif
+// Tap rows of a bicubic / Lanczos4 sample in flight (single-channel integer planes, taps_inside): more rows = more fetches outstanding, and more registers.  Round 4's last
+// scans (profiles/r04_ab_lut_rows.txt): at 8 waves per SIMD (64 VGPRs) two rows fit and four spill; at 6 waves four fit, at 5 all eight of an 8-bit Lanczos4 sample —
+// bicubic 65.5 -> 50.4 us (NV12), 68.5 -> 52.7 (P010); Lanczos4 107.1 -> 91.9 (NV12), 122.4 -> 112.5 (P010), C2 unchanged (142).  The host picks the waves
+// (gfw_api.hip jit_waves), the rows follow from them; ahead of time (6 waves, more live scalars) four rows, two for 16-bit Lanczos4 (four spill there).
+#ifdef GFW_TAP_ROWS_FORCE
+#define GFW_TAP_ROW_UNROLL(I, T) (GFW_TAP_ROWS_FORCE)
+#elif GFW_BAKE
+#define GFW_TAP_ROW_UNROLL(I, T) (GFW_JIT_WAVES >= 7 ? 2 : ((I) == 4 ? 4 : (GFW_JIT_WAVES <= 5 ? 8 : 4)))
+#else
+#define GFW_TAP_ROW_UNROLL(I, T) ((I) == 4 ? 4 : (sizeof(T) == 1 ? 4 : 2))
+#endif
 #ifndef GFW_FASTROW
 #define GFW_FASTROW 1            // the branch-free lane-row of phase 3 (rd_lean_nobranch + one `__any` / `__all` per stage); 0: the per-pixel divergent code only (A/B)
 #endif
@@ -497,7 +508,7 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
             // the usual case (row pitch a multiple of 4 bytes): the misalignment is the same for every tap row of the sample
             const unsigned mis = (unsigned)off0 & 3u, sh = mis * 8u;
             uint32_t aoff = (uint32_t)off0 & ~3u;
-            #pragma unroll 2                       // tap rows in flight: 1 / 2 / 4 measured — bicubic 79.9 / 67.5 / 76.9 us, Lanczos4 the same within 1 %
+            #pragma unroll (GFW_TAP_ROW_UNROLL(I, T))      // tap rows in flight
             for (int yp = 0; yp < I; ++yp) {
                 // 16-bit Lanczos4 is bound by the fetches themselves (dwordx4 + dword per row: the second one only for the misaligned half of the samples —
                 // unconditional it measured 170 against 157 us per C2 frame); everywhere else the branch costs more than the fetch it saves

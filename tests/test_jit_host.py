@@ -39,8 +39,8 @@ def test_embedded_source_compiles_into_the_c2_instantiation(tmp_path):
 
 @pytest.mark.parametrize("taps", [4, 8])
 def test_embedded_source_compiles_for_the_lut_samplers(tmp_path, taps):
-    k = compile_c2(tmp_path, taps, 7)
-    assert k[".vgpr_count"] <= 73 and k[".private_segment_fixed_size"] == 0, (k[".vgpr_count"], k[".private_segment_fixed_size"])
+    k = compile_c2(tmp_path, taps, 6)                 # gfw_api.hip jit_waves: six waves per SIMD for the LUT samplers of integer planes, four tap rows in flight
+    assert k[".vgpr_count"] <= 80 and k[".private_segment_fixed_size"] == 0, (k[".vgpr_count"], k[".private_segment_fixed_size"])
 
 
 def test_a_broken_bake_header_is_reported_not_fatal(tmp_path):

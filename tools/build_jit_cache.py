@@ -40,6 +40,9 @@ CONFIGS = [
     ("4K NV12", dict(fmt="NV12")),
     ("4K P010LE", dict(fmt="P010LE")),
     ("4K YUV420P", dict(fmt="YUV420P")),
+    ("4K NV12 bicubic", dict(fmt="NV12", interp=4)),
+    ("4K NV12 Lanczos4", dict(fmt="NV12", interp=8)),
+    ("4K P010LE bicubic", dict(fmt="P010LE", interp=4)),
 ]
 
 
