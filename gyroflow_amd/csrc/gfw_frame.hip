@@ -480,11 +480,8 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
         // and for integer pixels the reference's leading zero-adds (xs = 0 + p*c, sum = 0 + xs*cy) are dropped: they only decide the sign of a
         // zero, which no later operation of an integer sample can see (`as u8 / u16` maps both zeros to 0).
         constexpr int ND = (I * (int)sizeof(T)) / 4;
-        auto row = [&](const uint32_t *wp, bool extra, unsigned sh) -> float {
-            uint32_t w[ND + 1];
-            #pragma unroll
-            for (int j = 0; j < ND; ++j) w[j] = wp[j];
-            w[ND] = extra ? wp[ND] : 0u;
+        // one tap row from its ND + 1 fetched dwords: funnel-shifted into place, converted, multiplied, added in the reference's order
+        auto row_sum = [&](const uint32_t *w, unsigned sh) -> float {
             float xs = 0.0f;
             #pragma unroll
             for (int j = 0; j < ND; ++j) {
@@ -503,27 +500,41 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
             }
             return xs;
         };
+        auto fetch = [&](const uint32_t *wp, bool extra, uint32_t *w) {
+            #pragma unroll
+            for (int j = 0; j < ND; ++j) w[j] = wp[j];
+            w[ND] = extra ? wp[ND] : 0u;
+        };
         float s1 = 0.0f;
         if ((stride & 3) == 0) {
-            // the usual case (row pitch a multiple of 4 bytes): the misalignment is the same for every tap row of the sample
+            // the usual case (row pitch a multiple of 4 bytes): the misalignment is the same for every tap row of the sample.  The rows go in groups of R: all
+            // fetches of a group first, then its arithmetic — said in so many words because the ROCm 7.2 compiler, left to unroll a fetch-and-convert loop, issued
+            // `load, wait, load, wait` for one of the two luma samples where the 7.0 one clustered the loads (profiles/r04_ab_lut_rows.txt)
+            constexpr int R = GFW_TAP_ROW_UNROLL(I, T) < I ? GFW_TAP_ROW_UNROLL(I, T) : I;
+            static_assert(I % R == 0, "tap rows per group");
             const unsigned mis = (unsigned)off0 & 3u, sh = mis * 8u;
+            // 16-bit Lanczos4 is bound by the fetches themselves (dwordx4 + dword per row: the second one only for the misaligned half of the samples —
+            // unconditional it measured 170 against 157 us per C2 frame); everywhere else the branch costs more than the fetch it saves
+            // (bicubic 81 -> 67 us, 8-bit Lanczos4 141 -> 106)
+            const bool extra = (sizeof(T) == 2 && I == 8) ? mis != 0u : true;
             uint32_t aoff = (uint32_t)off0 & ~3u;
-            #pragma unroll (GFW_TAP_ROW_UNROLL(I, T))      // tap rows in flight
-            for (int yp = 0; yp < I; ++yp) {
-                // 16-bit Lanczos4 is bound by the fetches themselves (dwordx4 + dword per row: the second one only for the misaligned half of the samples —
-                // unconditional it measured 170 against 157 us per C2 frame); everywhere else the branch costs more than the fetch it saves
-                // (bicubic 81 -> 67 us, 8-bit Lanczos4 141 -> 106)
-                const float xs = row(reinterpret_cast<const uint32_t *>(src + aoff), (sizeof(T) == 2 && I == 8) ? mis != 0u : true, sh);
-                s1 = s1 + xs * b.ty[yp];                 // (the first of these adds is the reference's 0 + xs*cy: kept, a select in the rolled loop costs more)
-                aoff += (uint32_t)stride;
+            #pragma unroll 1
+            for (int y0 = 0; y0 < I; y0 += R) {
+                uint32_t w[R][ND + 1];
+                #pragma unroll
+                for (int r = 0; r < R; ++r) fetch(reinterpret_cast<const uint32_t *>(src + aoff + (uint32_t)(r * stride)), extra, w[r]);
+                #pragma unroll
+                for (int r = 0; r < R; ++r) s1 = s1 + row_sum(w[r], sh) * b.ty[y0 + r];      // (the first of these adds is the reference's 0 + xs*cy: kept)
+                aoff += (uint32_t)(R * stride);
             }
         } else {
             #pragma unroll 1
             for (int yp = 0; yp < I; ++yp) {
                 const uint32_t o = (uint32_t)(off0 + yp * stride);
                 const unsigned mis = o & 3u;
-                const float xs = row(reinterpret_cast<const uint32_t *>(src + (o & ~3u)), mis != 0, mis * 8u);
-                s1 = s1 + xs * b.ty[yp];
+                uint32_t w[ND + 1];
+                fetch(reinterpret_cast<const uint32_t *>(src + (o & ~3u)), mis != 0, w);
+                s1 = s1 + row_sum(w, mis * 8u) * b.ty[yp];
             }
         }
         out[0] = fminf(s1, limit);
