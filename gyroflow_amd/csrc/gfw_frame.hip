@@ -522,7 +522,16 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
             for (int y0 = 0; y0 < I; y0 += R) {
                 uint32_t w[R][ND + 1];
                 #pragma unroll
-                for (int r = 0; r < R; ++r) fetch(reinterpret_cast<const uint32_t *>(src + aoff + (uint32_t)(r * stride)), extra, w[r]);
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t *wp = reinterpret_cast<const uint32_t *>(src + aoff + (uint32_t)(r * stride));
+                    #pragma unroll
+                    for (int j = 0; j < ND; ++j) w[r][j] = wp[j];
+                    w[r][ND] = 0u;
+                }
+                if (extra) {                             // ONE per-lane region for the group's last dwords (it was one per row: three more sets of exec bookkeeping)
+                    #pragma unroll
+                    for (int r = 0; r < R; ++r) w[r][ND] = reinterpret_cast<const uint32_t *>(src + aoff + (uint32_t)(r * stride))[ND];
+                }
                 #pragma unroll
                 for (int r = 0; r < R; ++r) s1 = s1 + row_sum(w[r], sh) * b.ty[y0 + r];      // (the first of these adds is the reference's 0 + xs*cy: kept)
                 aoff += (uint32_t)(R * stride);
