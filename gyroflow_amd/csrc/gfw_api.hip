@@ -1174,7 +1174,20 @@ struct PlaneGroup {
 static std::mutex g_group_mu;
 static std::vector<PlaneGroup *> g_groups;       // at most one per thread that ever coalesced
 static std::vector<gfw_ctx *> g_live;            // every context alive (frame_owner links are cleared when their target goes)
-static thread_local PlaneGroup *t_group = nullptr;
+// The calling thread's group.  A thread that ends with an empty group takes it along; one that ends in the middle of a frame leaves the planes where the contexts'
+// own flushes (gfw_synchronize, gfw_flush, gfw_destroy, the next call) find them.
+struct GroupSlot {
+    PlaneGroup *g = nullptr;
+    ~GroupSlot() {
+        if (!g) return;
+        std::lock_guard<std::mutex> lk(g_group_mu);
+        if (g->n != 0) return;
+        for (size_t i = 0; i < g_groups.size(); ++i) if (g_groups[i] == g) { g_groups[i] = g_groups.back(); g_groups.pop_back(); break; }
+        delete g;
+    }
+};
+static thread_local GroupSlot t_slot;
+#define t_group (t_slot.g)
 
 // Orders the streams of the owner's member contexts behind everything enqueued on the owner's stream so far.
 static int order_members_behind(gfw_ctx *owner) {
