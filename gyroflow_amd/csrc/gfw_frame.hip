@@ -523,14 +523,14 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
                 uint32_t w[R][ND + 1];
                 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const uint32_t *wp = reinterpret_cast<const uint32_t *>(src + aoff + (uint32_t)(r * stride));
+                    const uint32_t *wp = reinterpret_cast<const uint32_t *>(src + (uint32_t)(aoff + (uint32_t)(r * stride)));     // base + ONE zero-extended 32-bit lane offset (saddr form)
                     #pragma unroll
                     for (int j = 0; j < ND; ++j) w[r][j] = wp[j];
                     w[r][ND] = 0u;
                 }
                 if (extra) {                             // ONE per-lane region for the group's last dwords (it was one per row: three more sets of exec bookkeeping)
                     #pragma unroll
-                    for (int r = 0; r < R; ++r) w[r][ND] = reinterpret_cast<const uint32_t *>(src + aoff + (uint32_t)(r * stride))[ND];
+                    for (int r = 0; r < R; ++r) w[r][ND] = reinterpret_cast<const uint32_t *>(src + (uint32_t)(aoff + (uint32_t)(r * stride) + 4u * ND))[0];
                 }
                 #pragma unroll
                 for (int r = 0; r < R; ++r) s1 = s1 + row_sum(w[r], sh) * b.ty[y0 + r];      // (the first of these adds is the reference's 0 + xs*cy: kept)
