@@ -516,7 +516,7 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
             // 16-bit Lanczos4 is bound by the fetches themselves (dwordx4 + dword per row: the second one only for the misaligned half of the samples —
             // unconditional it measured 170 against 157 us per C2 frame); everywhere else the branch costs more than the fetch it saves
             // (bicubic 81 -> 67 us, 8-bit Lanczos4 141 -> 106)
-            const bool extra = (sizeof(T) == 2 && I == 8) ? mis != 0u : true;
+            constexpr bool COND = sizeof(T) == 2 && I == 8;      // the last dword only for the misaligned half of the samples
             uint32_t aoff = (uint32_t)off0 & ~3u;
             #pragma unroll 1
             for (int y0 = 0; y0 < I; y0 += R) {
@@ -525,10 +525,10 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
                 for (int r = 0; r < R; ++r) {
                     const uint32_t *wp = reinterpret_cast<const uint32_t *>(src + (uint32_t)(aoff + (uint32_t)(r * stride)));     // base + ONE zero-extended 32-bit lane offset (saddr form)
                     #pragma unroll
-                    for (int j = 0; j < ND; ++j) w[r][j] = wp[j];
-                    w[r][ND] = 0u;
+                    for (int j = 0; j < ND + (COND ? 0 : 1); ++j) w[r][j] = wp[j];       // (ND + 1 adjacent dwords: one wider fetch)
+                    if (COND) w[r][ND] = 0u;
                 }
-                if (extra) {                             // ONE per-lane region for the group's last dwords (it was one per row: three more sets of exec bookkeeping)
+                if (COND && mis != 0u) {                 // ONE per-lane region for the group's last dwords (it was one per row: three more sets of exec bookkeeping)
                     #pragma unroll
                     for (int r = 0; r < R; ++r) w[r][ND] = reinterpret_cast<const uint32_t *>(src + (uint32_t)(aoff + (uint32_t)(r * stride) + 4u * ND))[0];
                 }
