@@ -851,17 +851,23 @@ __device__ __forceinline__ void sample_store_shared2_refs(float u, float v, bool
         off0 = row_off(b.sy, Pa.src_stride) + b.sx * (int)sizeof(T);
     }
     const int doff = row_off(oy, Pa.dst_stride) + ox * (int)sizeof(T);
-    auto one = [&](const GfwYuvPlane &P) {
-        float o = P.bg[0];
-        if (ok) {
-            if (__builtin_expect(inside, 1)) taps_inside2<T, 1>(P.src, off0, Pa.src_stride, b, P.limit, &o);
-            else taps_edge2<T, 1>(P.src, Pa.src_stride, b, Pa.w, Pa.h, P.bg, P.limit, &o);
+    // every plane's taps first, then the stores: a store between two planes' fetches (the destination may alias a source as far as the compiler knows) had them
+    // issued plane by plane — fetch, wait, blend, store, four times over for planar float frames (the disassembly of the shipped C4 kernel, round 4)
+    float oa = Pa.bg[0], ob = n > 1 ? Pb.bg[0] : 0.0f, oc = n > 2 ? Pc.bg[0] : 0.0f;
+    if (ok) {
+        if (__builtin_expect(inside, 1)) {
+            taps_inside2<T, 1>(Pa.src, off0, Pa.src_stride, b, Pa.limit, &oa);
+            if (n > 1) taps_inside2<T, 1>(Pb.src, off0, Pa.src_stride, b, Pb.limit, &ob);
+            if (n > 2) taps_inside2<T, 1>(Pc.src, off0, Pa.src_stride, b, Pc.limit, &oc);
+        } else {
+            taps_edge2<T, 1>(Pa.src, Pa.src_stride, b, Pa.w, Pa.h, Pa.bg, Pa.limit, &oa);
+            if (n > 1) taps_edge2<T, 1>(Pb.src, Pa.src_stride, b, Pa.w, Pa.h, Pb.bg, Pb.limit, &ob);
+            if (n > 2) taps_edge2<T, 1>(Pc.src, Pa.src_stride, b, Pa.w, Pa.h, Pc.bg, Pc.limit, &oc);
         }
-        store_px<T, 1>(P.dst, doff, &o, px_needs_sat<T>(P.bg, 1, P.limit));
-    };
-    one(Pa);
-    if (n > 1) one(Pb);
-    if (n > 2) one(Pc);
+    }
+    store_px<T, 1>(Pa.dst, doff, &oa, px_needs_sat<T>(Pa.bg, 1, Pa.limit));
+    if (n > 1) store_px<T, 1>(Pb.dst, doff, &ob, px_needs_sat<T>(Pb.bg, 1, Pb.limit));
+    if (n > 2) store_px<T, 1>(Pc.dst, doff, &oc, px_needs_sat<T>(Pc.bg, 1, Pc.limit));
 }
 
 // Two planar chroma planes of identical geometry (U, V) — the C2 hot path: one set of bins / weights / offsets,
