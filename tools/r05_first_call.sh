@@ -17,3 +17,6 @@ run A=1 --fmt P010LE --interp 8
 run A=1 --fmt YUV420P --interp 8
 run A=1 --interp 4 --jit 0 --clip 1
 run A=1 --interp 8 --jit 0 --clip 1
+run A=1 --fmt GBRAPF32LE --crop --resident 16
+run A=1 --fmt RGBAF32 --crop --resident 16
+run A=1 --fmt YUV444P16LE
