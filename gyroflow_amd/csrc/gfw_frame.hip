@@ -87,6 +87,10 @@
 #else
 #define GFW_TAP_ROW_UNROLL(I, T) ((I) == 4 ? 4 : (sizeof(T) == 1 ? 4 : 2))
 #endif
+#ifndef GFW_ROW_CLUSTER
+#define GFW_ROW_CLUSTER 0       // experiment queued for round 5 (tools/r05_first_call.sh; bit-exact on the host interpreter): the luma pair's and the chroma site's taps of a
+                                 // 4:2:2 / 4:4:4 planar lane-row fetched in ONE cluster, stores last (the luma store between them is an aliasing barrier: the row waits twice)
+#endif
 #ifndef GFW_FASTROW
 #define GFW_FASTROW 1            // the branch-free lane-row of phase 3 (rd_lean_nobranch + one `__any` / `__all` per stage); 0: the per-pixel divergent code only (A/B)
 #endif
@@ -1351,6 +1355,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                 }
                 float u0 = 0.0f, v0 = 0.0f, lu0 = 0.0f, lv0 = 0.0f; bool ok0 = false;
                 GfwVote okm0 = GFW_VOTE_ALL;              // the branch-free row's form of ok0
+                bool row_done = false;                    // GFW_ROW_CLUSTER: luma and chroma of this lane-row already written
                 // The branch-free row (round 4; specialised fisheye, bilinear, single-channel luma): a lane's DW pixels of one line are projected with
                 // rd_lean_nobranch, mapped and binned without a divergent branch; the wave is asked ONCE per stage — `__any(rare)` sends the odd lanes
                 // through rd<> itself, `__all(interior)` picks between the branch-free taps (pair stored as one word) and sample_store2.
@@ -1415,7 +1420,30 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                             if constexpr (I == 2) interior = interior & okp[i] & gfw_lanes(live) & gfw_lanes((unsigned)(bx[i] >> 5) < (unsigned)(PL0.w - 1)) & gfw_lanes((unsigned)(by[i] >> 5) < (unsigned)(PL0.h - 1));
                             else interior = interior & okp[i] & gfw_lanes(live) & lut_interior<T, I>(bx[i], by[i], PL0.w, PL0.h);
                         }
-                        if (__builtin_expect(gfw_all_lanes(interior), 1)) {
+                        if constexpr (GFW_ROW_CLUSTER && GFW_BAKE && MODEL == GFW_MODEL_OPENCV_FISHEYE && I == 2 && DH == 1 && !INTERLEAVED_UV && !is_f32<T>::value) {
+                            // the chroma site's bins and its interior vote BEFORE any tap: with both votes in hand the row's eight fetches leave together
+                            if (AF(nplanes) == 3 && !(AF(ablate) & 4)) {
+                                const float ccu = chroma_from_luma<INF_COORDS>(lu0, u0, MP.mul_cx, MP.mul_lx, MP.den_x, MP.rcp_x);
+                                const float ccv = chroma_from_luma<INF_COORDS>(lv0, v0, MP.mul_cy, MP.mul_ly, MP.den_y, MP.rcp_y);
+                                const Bins2 bc = make_bins2(ccu, ccv);
+                                const GfwVote both = interior & okm0 & gfw_lanes((unsigned)bc.sx < (unsigned)(PL1.w - 1)) & gfw_lanes((unsigned)bc.sy < (unsigned)(PL1.h - 1));
+                                if (__builtin_expect(gfw_all_lanes(both), 1)) {
+                                    uint32_t val[DW];
+                                    #pragma unroll
+                                    for (int i = 0; i < DW; ++i) val[i] = inside_value1<T>(PL0.src, PL0.src_stride, bins2_of(bx[i], by[i]), bg_y, lim_y);
+                                    const uint32_t vu = inside_value1<T>(PL1.src, PL1.src_stride, bc, &bg_c[0], lim_u);
+                                    const uint32_t vv = inside_value1<T>(PL2.src, PL1.src_stride, bc, &bg_v, lim_v);
+                                    const int doff = row_off(ly, PL0.dst_stride) + (cx * DW) * (int)sizeof(T);
+                                    if constexpr (DW == 2) store_pair1<T>(PL0.dst, doff, val[0], val[1]);
+                                    else store_value1<T>(PL0.dst, doff, val[0]);
+                                    const int cdoff = row_off(cy, PL1.dst_stride) + cx * (int)sizeof(T);
+                                    store_value1<T>(PL1.dst, cdoff, vu); store_value1<T>(PL2.dst, cdoff, vv);
+                                    row_done = true;
+                                }
+                            }
+                        }
+                        if (row_done) {}
+                        else if (__builtin_expect(gfw_all_lanes(interior), 1)) {
                             uint32_t val[DW];
                             #pragma unroll
                             for (int i = 0; i < DW; ++i) {
@@ -1495,7 +1523,8 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                         if (AF(nplanes) > 3) feather_store<T, 1, I, true>(u0, v0, f, PL3, PL3.bg, PL3.limit, MP.mul_cx, MP.mul_cy, MP, cx, cy, s_lut);
                     }
                 } else
-                if (AF(nplanes) > 1 && !(AF(ablate) & 4)) {
+                if (row_done) {}
+                else if (AF(nplanes) > 1 && !(AF(ablate) & 4)) {
                     float cu, cv;
                     if (GFW_BAKE && MODEL == GFW_MODEL_OPENCV_FISHEYE) {
                         // the chroma site's coordinate from the luma pixel's that shares it (chroma_from_luma): nothing for 4:2:2's rows, one multiply for a halved axis
