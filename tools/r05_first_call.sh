@@ -6,10 +6,12 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05a; mkdir -p $O
 run() { env $1 timeout 120 python3 bench.py --gpus 1 --steps 64 --warmup 16 --no-cpu-baseline $2 $3 $4 $5 > $O/bench.json 2> $O/bench.err
   python3 -c "import json; d=json.load(open('$O/bench.json')); print('[$1] [$2 $3 $4 $5]',d['value'], d['ms_per_step'], d['roofline']['kernel_ms_per_frame'], d['config']['jit']['compile_ms'], d['config']['parity_vs_oracle'])" 2>&1 | tail -1 | tee -a $O/summary.txt; }
-run A=1 ""
-run GFW_JIT_DEFS=GFW_ROW_CLUSTER=1 ""
-run A=1 --steps 200
+# C2 row with its fetches in one cluster (GFW_ROW_CLUSTER): both sides compiled in the process (the same compiler: torch's hiprtc), then the shipped default for reference
+run GFW_JIT_DEFS=GFW_UNUSED_TAG=1 --steps 200
 run GFW_JIT_DEFS=GFW_ROW_CLUSTER=1 --steps 200
+run GFW_JIT_DEFS=GFW_UNUSED_TAG=1 --steps 200
+run GFW_JIT_DEFS=GFW_ROW_CLUSTER=1 --steps 200
+run A=1 --steps 200
 run A=1 --interp 4
 run GFW_JIT_WAVES=6 --interp 4
 run "GFW_JIT_WAVES=6 GFW_JIT_DEFS=GFW_UNUSED_TAG=1" --interp 4
