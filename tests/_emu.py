@@ -277,6 +277,17 @@ def fused_eligible(fr):
     return _int_products_exact(p0.output_width, p0.output_width) and _int_products_exact(p0.output_height, p0.output_height) and p0.width <= 65535 and p0.height <= 65535
 
 
+def jit_waves(n0, matrix_count, jit_model, extras, taps, bps, dh):
+    """gfw_api.hip jit_waves: the waves per SIMD a specialised build is compiled for (the kernel derives its tap rows in flight from them)"""
+    if jit_model < 0 and (extras & (16 | 32)):
+        return 6
+    if n0 == 1 and bps <= 2 and taps == 4 and (bps == 1 or dh == 2):
+        return 6
+    if n0 == 1 and bps <= 2 and taps == 8:
+        return 5 if bps == 1 else 6
+    return 8 if (n0 == 1 and matrix_count > 1) else 7
+
+
 def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=False):
     """One clip launch of the host-interpreted kernel over `frames` (same shape and constants, <= 16) -> [[plane outputs] per frame].
     `votes`: 0 = a wave vote answers with the lane's own predicate, 1 = as if another lane of the wave failed it (every lane takes the general route).
@@ -301,7 +312,7 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=F
     p1 = p1_table(p0, fr0.matrices, p0.matrix_count) if (fisheye and extras == 0 and not stretched) else None
     fast1 = p1 is not None
     rb = 4 if fast1 else 1
-    defs = {"GFW_FRAME_KIND": bps, "GFW_FRAME_TAPS": p0.interpolation, "GFW_JIT_WAVES": 8, "GFW_JIT_MODEL": jit_model,
+    defs = {"GFW_FRAME_KIND": bps, "GFW_FRAME_TAPS": p0.interpolation, "GFW_JIT_WAVES": jit_waves(n0, p0.matrix_count, jit_model, extras, p0.interpolation, bps, dh), "GFW_JIT_MODEL": jit_model,
             "GFW_JIT_T": {1: "uint8_t", 2: "uint16_t", 4: "float"}[bps], "GFW_JIT_N0": n0, "GFW_JIT_DW": dw, "GFW_JIT_DH": dh,
             "GFW_JIT_IL": 1 if il else 0, "GFW_JIT_RB": rb, "GFW_JIT_FAST1": 1 if fast1 else 0}
     header = _bake.bake_header(fr0, rb=rb)
