@@ -23,6 +23,7 @@
 #include "gfw_jit.h"
 #include <stdlib.h>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <thread>
 
@@ -94,6 +95,7 @@ struct gfw_ctx {
     float p1_eps_last = 0.0f;                      // certificate half-width of the last frame set up (reported in gfw_get_audit's word 6)
     float p1_k[4] = {0, 0, 0, 0}; float p1_rho_max = 0.0f; double p1_etab = 0.0; double p1_smax = 1.0; bool p1_valid = false;
     double p1_slope = 0.0, p1_kappa = 0.0;         // max |ds/drho| over the table's range; roundoff amplification of the exact path's theta_d/r (section 2c)
+    double p1_u1 = 0.0, p1_u2 = 0.0, p1_t32 = 0.0; // max sqrt(rho) |s'|, rho |s'|, rho^1.5 |s''| over the table's range: the curvature of the first pass's value across a lattice cell (gfw_frame.hip)
     DevBuf d_pts_in, d_pts_out, d_pts_rot, d_pts_shift, d_pts_mesh;   // gfw_undistort_points staging
     DevBuf d_tracks;                              // quaternion tracks
     // context-owned per-row tables built on the device (gfw_build_matrices): a small ring, built on copy_stream so that
@@ -132,6 +134,11 @@ struct gfw_ctx {
     int coalesce_planes = 1;                       // GFW_OPT_COALESCE_PLANES
     int coalesce_frames = 1;                       // GFW_OPT_COALESCE_FRAMES: assembled frames held for one clip launch (1 = each frame leaves when complete)
     hipEvent_t group_done = nullptr;               // orders a member context's stream behind the owner's launch
+    hipEvent_t inputs_ready = nullptr;             // a member context's side of the same frame: what was enqueued on ITS stream before its plane's call (an upload, a decode,
+                                                   // a consumer still reading the destination) — the owner's stream waits for it before the fused launch
+    std::atomic<int> pending_planes{0};            // planes of this context held in some thread's group (flush_if_pending looks here: the holder may be another thread)
+    bool multi_plane = false;                      // this context has been seen as one plane of a multi-plane frame (its calls may be held: GFW_OPT_COALESCE_PLANES = 1)
+    int frame_sync = 0;                            // GFW_OPT_FRAME_SYNC
     struct ClipBatch *held = nullptr;              // frames assembled from per-plane calls, waiting for their launch (owner context only)
     gfw_ctx *frame_owner = nullptr; bool needs_order = false;   // a member context: whose stream its planes were launched on, and whether its own stream has been ordered behind that yet
     std::vector<gfw_buffers> held_planes;          // ... and the descriptions those frames were validated with
@@ -292,6 +299,7 @@ void gfw_destroy(gfw_ctx *c) {
     gfw_forget_context(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->group_done) (void)hipEventDestroy(c->group_done);
+    if (c->inputs_ready) (void)hipEventDestroy(c->inputs_ready);
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &b : c->stage_src) b.release();
     for (auto &b : c->stage_dst) b.release();
@@ -323,13 +331,20 @@ int gfw_set_option(gfw_ctx *c, int option, int64_t value) {
     case GFW_OPT_JIT: if (value < 0 || value > 2) { set_error("GFW_OPT_JIT %lld", (long long)value); return GFW_ERR_INVALID_ARGUMENT; }
                       c->jit_mode = (int)value; c->jit_fn = nullptr; c->jit_key_valid = false; c->jit_dead = false;
                       c->jit_info = GfwJitInfo{GFW_JIT_UNAVAILABLE, 0.0, std::string()}; return GFW_OK;
-    case GFW_OPT_COALESCE_PLANES: { const int frc = gfw_flush(c); if (frc != GFW_OK) return frc; c->coalesce_planes = value != 0; return GFW_OK; }
+    case GFW_OPT_COALESCE_PLANES: if (value < 0 || value > 2) { set_error("GFW_OPT_COALESCE_PLANES %lld (0..2)", (long long)value); return GFW_ERR_INVALID_ARGUMENT; }
+                                  { const int frc = gfw_flush(c); if (frc != GFW_OK) return frc; c->coalesce_planes = (int)value; return GFW_OK; }
+    case GFW_OPT_FRAME_SYNC: { const int frc = gfw_flush(c); if (frc != GFW_OK) return frc; c->frame_sync = value != 0; return GFW_OK; }
     case GFW_OPT_COALESCE_FRAMES: if (value < 1 || value > GFW_CLIP_FRAMES_MAX) { set_error("GFW_OPT_COALESCE_FRAMES %lld (1..%d)", (long long)value, GFW_CLIP_FRAMES_MAX); return GFW_ERR_INVALID_ARGUMENT; }
                                   { const int frc = gfw_flush(c); if (frc != GFW_OK) return frc; } c->coalesce_frames = (int)value; return GFW_OK;
     default: set_error("unknown option %d", option); return GFW_ERR_INVALID_ARGUMENT;
     }
 }
-void *gfw_get_stream(gfw_ctx *c) { return c ? (void *)c->stream : nullptr; }
+void *gfw_get_stream(gfw_ctx *c) {
+    // whoever asks for the stream is about to order something behind this context's work on it (an event, a synchronise, a consumer's kernel): what is being
+    // held for a frame or a launch leaves first, so that "everything enqueued so far" means what it meant before planes could be held
+    if (c) (void)flush_if_pending(c);
+    return c ? (void *)c->stream : nullptr;
+}
 int gfw_set_stream(gfw_ctx *c, void *s) {
     if (!c) return GFW_ERR_INVALID_ARGUMENT;
     // the previous stream is drained first: frames still in flight on it use this context's staging buffers and matrix slots,
@@ -558,48 +573,105 @@ static double p1_s_of_rho(double rho, const float *k) {
     const double t = atan(r), t2 = t * t;
     return t * (1.0 + t2 * ((double)k[0] + t2 * ((double)k[1] + t2 * ((double)k[2] + t2 * (double)k[3])))) / r;
 }
+// ---- derivative bounds of s(rho), derived (round 5) -------------------------------------------------------------------------
+// s = A(rho) P(w):  A(rho) = atan(sqrt rho) / sqrt rho = int_0^1 dt / (1 + rho t^2),  w(rho) = atan^2(sqrt rho) = rho A^2 (= theta^2),
+// P(w) = 1 + k0 w + k1 w^2 + k2 w^3 + k3 w^4.  From the integral: |d^n A / d rho^n| <= n! / (2n + 1) for every rho >= 0 (A, -A', A'', ... are positive and
+// decreasing);  w' = A / (1 + rho) in (0, 1],  w'' = A' / (1 + rho) - A / (1 + rho)^2,  w(3) = A'' / (1 + rho) - 2 A' / (1 + rho)^2 + 2 A / (1 + rho)^3:
+// |w''| <= 4/3, |w(3)| <= 46/15.  The values of s', s'' at a point come from the closed forms below (a series under rho = 1/64, where the closed forms
+// cancel); between two points of a grid of spacing g the next derivative's GLOBAL bound (products of the bounds above) carries the value:
+// |s''(rho)| <= |s''(rho_i)| + g L3 on [rho_i, rho_i + g].  Nothing here is sampled-and-doubled: every number the certificate uses is a bound.
+static void p1_A_derivs(double rho, double &A, double &A1, double &A2) {
+    if (rho < 1.0 / 64.0) {                     // alternating series, terms falling by >= 64 each: 14 terms leave < 2^-84
+        A = A1 = A2 = 0.0;
+        double pw = 1.0;                         // (-rho)^n
+        for (int n = 0; n < 14; ++n) { A += pw / (2 * n + 1); pw *= -rho; }
+        double p1 = 1.0;                         // (-rho)^(n-1)
+        for (int n = 1; n < 14; ++n) { A1 += -(double)n / (2 * n + 1) * p1; p1 *= -rho; }
+        double p2 = 1.0;                         // (-rho)^(n-2)
+        for (int n = 2; n < 14; ++n) { A2 += (double)n * (n - 1) / (2 * n + 1) * p2; p2 *= -rho; }
+        return;
+    }
+    const double r = sqrt(rho);
+    A = atan(r) / r;
+    A1 = (1.0 / (1.0 + rho) - A) / (2.0 * rho);                               // from (rho A^2)' = A / (1 + rho)
+    A2 = (-1.0 / ((1.0 + rho) * (1.0 + rho)) - 3.0 * A1) / (2.0 * rho);       // the same identity differentiated once more
+}
+struct P1Derivs { double s, s1, s2; };
+static P1Derivs p1_s_derivs(double rho, const float *k) {
+    double A, A1, A2;
+    p1_A_derivs(rho, A, A1, A2);
+    const double w = rho * A * A, w1 = A / (1.0 + rho), w2 = A1 / (1.0 + rho) - A / ((1.0 + rho) * (1.0 + rho));
+    const double k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3];
+    const double P = 1.0 + w * (k0 + w * (k1 + w * (k2 + w * k3)));
+    const double P1 = k0 + w * (2.0 * k1 + w * (3.0 * k2 + w * 4.0 * k3));
+    const double P2 = 2.0 * k1 + w * (6.0 * k2 + w * 12.0 * k3);
+    P1Derivs d;
+    d.s = A * P;
+    d.s1 = A1 * P + A * P1 * w1;
+    d.s2 = A2 * P + 2.0 * A1 * P1 * w1 + A * (P2 * w1 * w1 + P1 * w2);
+    return d;
+}
 static int p1_prepare_table(gfw_ctx *c, const gfw_kernel_params &p, float rho_max) {
     if (c->p1_valid && memcmp(c->p1_k, p.k, sizeof(c->p1_k)) == 0 && rho_max <= c->p1_rho_max && rho_max >= 0.5f * c->p1_rho_max) return GFW_OK;
     const int N = GFW_P1_TABLE_N;
     std::vector<float2> tab(N + 1);
     const double h = (double)rho_max / N;
-    double etab = 0.0, smax = 0.0, slope = 0.0;
     double s_prev = p1_s_of_rho(0.0, p.k);
     for (int i = 0; i < N; ++i) {
         const double s_next = p1_s_of_rho((i + 1) * h, p.k);
         tab[i] = float2{(float)s_prev, (float)(s_next - s_prev)};
-        // interpolation error at the eighth points of the interval, against the float entries actually stored; |ds/drho| from the chords between them
-        double s_at = s_prev;
-        for (int q = 1; q <= 8; ++q) {
-            const double fr = q / 8.0;
-            const double s_q = q == 8 ? s_next : p1_s_of_rho((i + fr) * h, p.k);
-            if (q < 8) etab = fmax(etab, fabs((double)tab[i].x + fr * (double)tab[i].y - s_q));
-            slope = fmax(slope, fabs(s_q - s_at) * 8.0 / h);
-            s_at = s_q;
-        }
-        smax = fmax(smax, fmax(fabs(s_prev), fabs(s_next)));
         s_prev = s_next;
     }
     tab[N] = float2{(float)s_prev, 0.0f};
-    // the exact path's theta_d / r as a function of its (already rounded) rho: sqrt (1 rounding), glibc atanf (< 1 ulp = 2 roundings), the polynomial
-    // 1 + k0 t^2 + k1 t^4 + k2 t^6 + k3 t^8 (powers by repeated products: 2, 4, 6, 8 roundings on the terms, 4 on the partial sums), t * poly, / r:
-    // relative error <= u * kappa, kappa = 3.5 (1 + R) + (R + 4 K) + 3 with R = max sum (2i |k_i| t^2i) / |P| (both t P'/P's bound and the terms' own
-    // roundings) and K = max sum |terms| / |P| (the partial sums)  
-    double kappa = 3.0;                                             // all four k zero: the exact path is (X/W) * f + c, nothing of the above
-    if (!(p.k[0] == 0.0f && p.k[1] == 0.0f && p.k[2] == 0.0f && p.k[3] == 0.0f)) {
-        const double tmax = atan(sqrt((double)rho_max));
+    const bool k_zero = p.k[0] == 0.0f && p.k[1] == 0.0f && p.k[2] == 0.0f && p.k[3] == 0.0f;
+    // global bounds over [0, rho_max]: P and its derivatives over w in [0, w_max] by the triangle inequality, then the products (header comment)
+    double smax = 1.0, slope = 0.0, s2max = 0.0, u1 = 0.0, u2 = 0.0, t32 = 0.0;
+    double kappa = 3.0;                                             // all four k zero: the exact path is (X/W) * f + c, s == 1, every derivative 0
+    if (!k_zero) {
+        const double tmax = atan(sqrt((double)rho_max)), wm = tmax * tmax;
+        const double a0 = fabs((double)p.k[0]), a1 = fabs((double)p.k[1]), a2 = fabs((double)p.k[2]), a3 = fabs((double)p.k[3]);
+        const double P0 = 1.0 + wm * (a0 + wm * (a1 + wm * (a2 + wm * a3)));
+        const double Pd1 = a0 + wm * (2.0 * a1 + wm * (3.0 * a2 + wm * 4.0 * a3));
+        const double Pd2 = 2.0 * a1 + wm * (6.0 * a2 + wm * 12.0 * a3);
+        const double Pd3 = 6.0 * a2 + wm * 24.0 * a3;
+        const double L1 = P0 / 3.0 + Pd1;                                                   // |s'|   <= |A'| P + A |P'| w'
+        const double L2 = 0.4 * P0 + 2.0 * Pd1 + Pd2;                                       // |s''|  <= |A''| P + 2 |A'| |P'| w' + A (|P''| w'^2 + |P'| |w''|)
+        const double L3 = (6.0 / 7.0) * P0 + 1.2 * Pd1 + (Pd2 + Pd1 * 4.0 / 3.0)            // |s(3)| <= |A(3)| P + 3 |A''| |(P)'| + 3 |A'| |(P)''| + A |(P)(3)|
+                        + (Pd3 + 4.0 * Pd2 + Pd1 * 46.0 / 15.0);
+        const int NG = 4096;
+        const double g = (double)rho_max / NG;
+        smax = 0.0;
+        for (int i = 0; i < NG; ++i) {
+            const P1Derivs d = p1_s_derivs(i * g, p.k);
+            const double hi = (i + 1) * g;
+            const double b0 = fabs(d.s) + g * L1, b1 = fabs(d.s1) + g * L2, b2 = fabs(d.s2) + g * L3;     // bounds over [i g, (i + 1) g]
+            smax = fmax(smax, b0); slope = fmax(slope, b1); s2max = fmax(s2max, b2);
+            u1 = fmax(u1, sqrt(hi) * b1); u2 = fmax(u2, hi * b1); t32 = fmax(t32, hi * sqrt(hi) * b2);
+        }
+        const double slack = 1.0 + 1e-9;                            // the f64 evaluation itself
+        smax *= slack; slope *= slack; s2max *= slack; u1 *= slack; u2 *= slack; t32 *= slack;
+        // the exact path's theta_d / r as a function of its (already rounded) rho: sqrt (1 rounding), glibc atanf (< 1 ulp = 2 roundings), the polynomial
+        // 1 + k0 t^2 + k1 t^4 + k2 t^6 + k3 t^8 (powers by repeated products: 2, 4, 6, 8 roundings on the terms, 4 on the partial sums), t * poly, / r:
+        // relative error <= u * kappa, kappa = 3.5 (1 + R) + (R + 4 K) + 3 with R = max sum (2i |k_i| t^2i) / |P| (both t P'/P's bound and the terms' own
+        // roundings) and K = max sum |terms| / |P| (the partial sums)  (DESIGN.md section 2c).  |P| from below: its value on a grid of w = t^2 less the
+        // grid step times the bound on |dP/dw|; the sums of absolute terms at the interval's upper end.
         double rp = 0.0, kp = 1.0;
+        const double gw = wm / 4096.0;
         for (int i = 0; i <= 4096; ++i) {
-            const double t2 = (tmax * i / 4096.0) * (tmax * i / 4096.0), t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
-            const double P = 1.0 + p.k[0] * t2 + p.k[1] * t4 + p.k[2] * t6 + p.k[3] * t8;
-            const double Pabs = 1.0 + fabs(p.k[0]) * t2 + fabs(p.k[1]) * t4 + fabs(p.k[2]) * t6 + fabs(p.k[3]) * t8;
-            const double dPabs = 2.0 * fabs(p.k[0]) * t2 + 4.0 * fabs(p.k[1]) * t4 + 6.0 * fabs(p.k[2]) * t6 + 8.0 * fabs(p.k[3]) * t8;
-            if (!(fabs(P) > 1e-3)) { rp = kp = 1e30; break; }     // theta_d's polynomial (nearly) vanishes inside the range: no certificate
-            rp = fmax(rp, dPabs / fabs(P)); kp = fmax(kp, Pabs / fabs(P));
+            const double t2 = gw * i, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+            const double P = fabs(1.0 + p.k[0] * t2 + p.k[1] * t4 + p.k[2] * t6 + p.k[3] * t8) - gw * Pd1;
+            const double t2h = t2 + gw, t4h = t2h * t2h, t6h = t4h * t2h, t8h = t4h * t4h;
+            const double Pabs = 1.0 + a0 * t2h + a1 * t4h + a2 * t6h + a3 * t8h;
+            const double dPabs = 2.0 * a0 * t2h + 4.0 * a1 * t4h + 6.0 * a2 * t6h + 8.0 * a3 * t8h;
+            if (!(P > 1e-3)) { rp = kp = 1e30; break; }           // theta_d's polynomial (nearly) vanishes inside the range: no certificate
+            rp = fmax(rp, dPabs / P); kp = fmax(kp, Pabs / P);
         }
         kappa = 4.5 * rp + 4.0 * kp + 6.5;
     }
-    if (!(etab == etab) || !(smax == smax) || !(slope == slope) || !(kappa == kappa)) { c->p1_valid = false; return GFW_OK; }
+    // the table's own error against s: the chord of a function with |s''| <= s2max over an interval h, the float rounding of the entry s_i (u |s|) and of
+    // the entry s_{i+1} - s_i (u h |s'|, times a fraction <= 1); the fma that combines them is counted with the first pass's roundings (section 2c, item 4)
+    const double etab = h * h / 8.0 * s2max + (smax + h * slope) / 16777216.0;
+    if (!(etab == etab) || !(smax == smax) || !(slope == slope) || !(kappa == kappa) || !(t32 == t32)) { c->p1_valid = false; return GFW_OK; }
     if (!c->dry) {
         HIP_TRY(c->d_p1_table.ensure((N + 1) * sizeof(float2)), GFW_ERR_HIP);
         HIP_TRY(hipMemcpyAsync(c->d_p1_table.ptr, tab.data(), (N + 1) * sizeof(float2), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
@@ -607,6 +679,7 @@ static int p1_prepare_table(gfw_ctx *c, const gfw_kernel_params &p, float rho_ma
     }
     memcpy(c->p1_k, p.k, sizeof(c->p1_k));
     c->p1_rho_max = rho_max; c->p1_etab = etab; c->p1_smax = smax; c->p1_slope = slope; c->p1_kappa = kappa; c->p1_valid = true;
+    c->p1_u1 = u1; c->p1_u2 = u2; c->p1_t32 = t32;
     return GFW_OK;
 }
 // Fill the first-pass fields of the fused kernel's arguments; returns true when the certified pass may be used.
@@ -667,10 +740,18 @@ static bool p1_setup(gfw_ctx *c, const gfw_kernel_params &p0, const float *h_mat
     Y.p1_table = (const float2 *)c->d_p1_table.ptr;
     Y.p1_rho_max = c->p1_rho_max; Y.p1_rho_scale = (float)(GFW_P1_TABLE_N / (double)c->p1_rho_max);
     Y.p1_eps = (float)e0; Y.p1_ew = (float)ew; Y.p1_em = (float)em;
+    // the lattice form of the first pass (gfw_frame.hip, phase 1): bounds on s and its derivatives for the curvature of v across a cell, and the roundings of the
+    // interpolation itself (node differences, three fmas, the row fraction: < 4 u vmag; 2^-17 px on top)
+    Y.p1_lat[0] = (float)(c->p1_smax * (1.0 + 1e-6)); Y.p1_lat[1] = (float)(c->p1_u1 * (1.0 + 1e-6)); Y.p1_lat[2] = (float)(c->p1_u2 * (1.0 + 1e-6));
+    Y.p1_lat[3] = (float)(c->p1_t32 * (1.0 + 1e-6)); Y.p1_lat[4] = (float)(4.0 * u24 * vmag + 1.0 / 131072.0); Y.p1_lat[5] = 0.0f;
     c->p1_eps_last = (float)eps;
     Y.p1_f = hrs ? p0.f[0] : p0.f[1]; Y.p1_c = hrs ? p0.c[0] : p0.c[1];
     table_ok = true;
-    if (c->kernel_variant == 3) {                               // audit mode: count certificates and check each one
+    {   // the per-pixel form of the first pass on request: GFW_OPT_KERNEL_VARIANT = 4 (audit of that form) or GFW_P1_LATTICE=0 in the environment (A/B runs)
+        static const bool env_off = [] { const char *e = getenv("GFW_P1_LATTICE"); return e && e[0] == '0' && e[1] == 0; }();
+        if (c->kernel_variant == 4 || env_off) Y.p1_lat[5] = 1.0f;
+    }
+    if (c->kernel_variant == 3 || c->kernel_variant == 4) {     // audit mode: count certificates and check each one
         const bool fresh = c->d_audit.cap == 0;
         if (c->d_audit.ensure(8 * sizeof(unsigned long long)) != hipSuccess) { table_ok = false; return false; }
         if (fresh) (void)hipMemsetAsync(c->d_audit.ptr, 0, 8 * sizeof(unsigned long long), c->stream);
@@ -876,6 +957,19 @@ static bool clip_ring_table(gfw_ctx *c, const float *m) {          // a table of
 }
 // The frames of one launch are in flight together, the calls they stand for are ordered: a frame whose planes overlap a pending frame's
 // destination (it would read or overwrite that frame's output) or whose destination overlaps a pending frame's source must go out behind them.
+// A launch shares ONE argument block among its frames: everything but the per-frame pointers.  The specialised kernel reads a handful of fields from that
+// block at run time — plane-0's KernelParams (fov, lens_correction_amount, the refraction coefficient, background margin / feather, the digital lens's
+// parameters) and the host-evaluated uniforms (cos / sin of input_rotation, the rotated frame size) — and the jit key blanks them (they may move from
+// frame to frame: dynamic zoom, keyframed lens correction).  Frames that arrive through per-plane calls bring their OWN parameters: a frame may join a pending
+// launch only when these blocks are byte-identical to the launch's, else the pending frames go out first (gfw_undistort_clip shares one array by contract).
+static bool clip_same_params(const GfwYuvArgs &a, const GfwYuvArgs &b) {
+    if (memcmp(&a.kp, &b.kp, sizeof(a.kp)) != 0) return false;
+    GfwCommon ca = a.common, cb = b.common;
+    ca.matrices = cb.matrices = nullptr;              // the per-frame table: carried by GfwFrameDyn
+    if (memcmp(&ca, &cb, sizeof(ca)) != 0) return false;
+    for (int i = 0; i < 4; ++i) if (a.pl[i].src_len != b.pl[i].src_len || a.pl[i].dst_len != b.pl[i].dst_len) return false;
+    return true;
+}
 static bool clip_overlaps(const ClipBatch *b, const gfw_buffers *planes, int nplanes) {
     auto hit = [](const uint8_t *p, size_t pl, const uint8_t *q, size_t ql) { return p && q && p < q + ql && q < p + pl; };
     for (int k = 0; k < b->n; ++k) {
@@ -924,7 +1018,15 @@ static void bake_f(std::string &o, const char *name, float v) {
     char b[128]; snprintf(b, sizeof(b), "#define GFW_BK_%s __builtin_bit_cast(float, 0x%08xu)\n", name, u); o += b;
 }
 static void bake_i(std::string &o, const char *name, long long v) { char b[128]; snprintf(b, sizeof(b), "#define GFW_BK_%s (%lld)\n", name, v); o += b; }
-static std::string bake_header(const GfwYuvArgs &Y) {
+// Luma block rows per lane of a SPECIALISED kernel (its tile = 64 DW x 4 RB DH luma pixels): the ahead-of-time kernels' by default; GFW_JIT_RB_FAST in the
+// environment scans it for the certified first pass (whose cost per pixel — the lattice's nodes, the queue's resolution — is per tile).
+static int jit_rows(bool fast1) {
+    static const int env = [] { const char *e = getenv("GFW_JIT_RB_FAST"); const int v = e ? atoi(e) : 0; return (v >= 1 && v * 4 <= 64) ? v : 0; }();
+    return (fast1 && env > 0) ? env : gfw_yuv_rows_per_lane(fast1, 0);
+}
+static std::string bake_header(const GfwYuvArgs &Y_in, bool fast1) {
+    GfwYuvArgs Y = Y_in;
+    { const int rb = jit_rows(fast1); Y.tiles_y = (Y.ch + 4 * rb - 1) / (4 * rb); }          // (the launch's own tiling: the argument block carries the ahead-of-time kernels')
     std::string o;
     o.reserve(4096);
     bake_i(o, "nplanes", Y.nplanes); bake_i(o, "width", Y.width); bake_i(o, "height", Y.height); bake_i(o, "out_w", Y.out_w); bake_i(o, "out_h", Y.out_h);
@@ -992,7 +1094,7 @@ static std::vector<std::string> jit_defs(const GfwYuvArgs &Y, int bps, int taps,
     snprintf(b, sizeof(b), "GFW_JIT_DW=%d", dw); defs.push_back(b);
     snprintf(b, sizeof(b), "GFW_JIT_DH=%d", dh); defs.push_back(b);
     snprintf(b, sizeof(b), "GFW_JIT_IL=%d", interleaved ? 1 : 0); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_JIT_RB=%d", gfw_yuv_rows_per_lane(fast1, 0)); defs.push_back(b);
+    snprintf(b, sizeof(b), "GFW_JIT_RB=%d", jit_rows(fast1)); defs.push_back(b);
     snprintf(b, sizeof(b), "GFW_JIT_FAST1=%d", fast1 ? 1 : 0); defs.push_back(b);
     if (const char *extra = getenv("GFW_JIT_DEFS")) {                                    // experiments: further ';'-separated definitions for the build
         std::string cur;
@@ -1016,6 +1118,7 @@ static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps,
     GfwYuvArgs K = Y;
     for (int i = 0; i < 4; ++i) { K.pl[i].src = nullptr; K.pl[i].dst = nullptr; K.pl[i].src_len = 0; K.pl[i].dst_len = 0; }
     K.matrices = nullptr; K.p1_table = nullptr; K.p1_rho_max = 0.0f; K.p1_rho_scale = 0.0f; K.p1_eps = 0.0f; K.p1_ew = 0.0f; K.p1_em = 0.0f; K.audit = nullptr; K.grid_limit = 0;
+    memset(K.p1_lat, 0, sizeof(K.p1_lat));
     memset(&K.kp, 0, sizeof(K.kp));
     { const int dig = K.common.digital; memset(&K.common, 0, sizeof(K.common)); K.common.digital = dig; }
     const int key_misc[8] = {bps, taps, n0, dw, dh, interleaved ? 1 : 0, fast1 ? 1 : 0, c->tune_grid};
@@ -1026,7 +1129,7 @@ static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps,
         if (c->jit_dead) return nullptr;                                                 // decided: ahead of time for the rest of the clip, no lookup per frame
     } else {
         c->jit_key = K; memcpy(c->jit_key_misc, key_misc, sizeof(key_misc)); c->jit_key_valid = true;
-        c->jit_header = bake_header(Y); c->jit_seen = 1; c->jit_fn = nullptr; c->jit_dead = false;
+        c->jit_header = bake_header(Y, fast1); c->jit_seen = 1; c->jit_fn = nullptr; c->jit_dead = false;
         c->jit_info = GfwJitInfo{GFW_JIT_UNAVAILABLE, 0.0, std::string()};
     }
     if (c->jit_mode == 1 && c->jit_seen < gfw_ctx::kJitAfter) return nullptr;          // one or two frames are not a clip
@@ -1035,7 +1138,8 @@ static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps,
     hipFunction_t fn = gfw_jit_get(c->device, c->arch, defs, c->jit_header, c->jit_mode == 2, &c->jit_info);
     if (!fn) { c->jit_dead = c->jit_info.state == GFW_JIT_FAILED || c->jit_info.state == GFW_JIT_UNAVAILABLE; return nullptr; }
     int g = c->tune_grid > 0 ? c->tune_grid : c->num_cus * waves;
-    const int per_xcd = (Y.tiles_x * Y.tiles_y + 7) >> 3;
+    const int jrb = jit_rows(fast1);
+    const int per_xcd = (Y.tiles_x * ((Y.ch + 4 * jrb - 1) / (4 * jrb)) + 7) >> 3;
     if (g > per_xcd * 8) g = per_xcd * 8;
     *grid = (g + 7) & ~7;
     c->jit_fn = fn; c->jit_grid = *grid;
@@ -1105,7 +1209,8 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
         if (jf && batch && all_device && c->bslot_cur < 0 && c->mslot_cur < 0) {      // (a table of the cross-stream ring is ordered by events: frame by frame)
             // the frame joins the clip launch being assembled; a frame that does not share the pending ones' kernel or first-pass table goes out behind them
             if (batch->n > 0 && (batch->fn != jf || batch->CA.Y.p1_table != Y.p1_table || batch->CA.Y.p1_rho_max != Y.p1_rho_max ||
-                                 batch->CA.Y.p1_rho_scale != Y.p1_rho_scale || batch->CA.Y.p1_eps != Y.p1_eps || batch->CA.Y.p1_ew != Y.p1_ew || clip_overlaps(batch, planes, nplanes))) {
+                                 batch->CA.Y.p1_rho_scale != Y.p1_rho_scale || batch->CA.Y.p1_eps != Y.p1_eps || batch->CA.Y.p1_ew != Y.p1_ew ||
+                                 !clip_same_params(batch->CA.Y, Y) || clip_overlaps(batch, planes, nplanes))) {
                 const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc;
             }
             if (batch->n == 0) { batch->CA.Y = Y; batch->fn = jf; batch->grid = jgrid; batch->first = planes; batch->backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit"; }
@@ -1170,6 +1275,7 @@ struct PlaneGroup {
     const float *d_matrices = nullptr;           // device-resident tables (GFW_OPT_MATRICES_ON_DEVICE != 0): the pointer every plane must repeat
     std::vector<float> h_matrices;               // host rows: a copy of plane 0's, which later planes must equal
     int matrix_count = 0, matrices_on_device = 0;
+    bool orphan = false;                         // its thread ended in the middle of a frame: deleted by whoever sends the planes on their way
 };
 static std::mutex g_group_mu;
 static std::vector<PlaneGroup *> g_groups;       // at most one per thread that ever coalesced
@@ -1181,7 +1287,7 @@ struct GroupSlot {
     ~GroupSlot() {
         if (!g) return;
         std::lock_guard<std::mutex> lk(g_group_mu);
-        if (g->n != 0) return;
+        if (g->n != 0) { g->orphan = true; return; }
         for (size_t i = 0; i < g_groups.size(); ++i) if (g_groups[i] == g) { g_groups[i] = g_groups.back(); g_groups.pop_back(); break; }
         delete g;
     }
@@ -1189,6 +1295,23 @@ struct GroupSlot {
 static thread_local GroupSlot t_slot;
 #define t_group (t_slot.g)
 
+// Which contexts are planes of multi-plane frames?  The calling thread's previous gfw_undistort_image call is remembered; a call with the NEXT plane index on
+// another context of the same device, lens and matrix count marks both (and through the chain every plane of the frame).  So the first frame of a clip leaves
+// plane by plane, and from the second on its calls are held — while a lone Luma / R32f plane (greyscale, a mask, a depth map) is never held waiting for
+// siblings that do not exist (round 4 held it until gfw_synchronize: ADVICE r4).
+struct LastPlaneCall { gfw_ctx *c = nullptr; int plane_index = -1, matrix_count = 0; bool marked = false; };
+static thread_local LastPlaneCall t_last_plane;
+static void plane_pattern_note(gfw_ctx *c, const gfw_kernel_params *params, int matrix_count) {
+    if (!params) { t_last_plane = LastPlaneCall(); return; }
+    LastPlaneCall &L = t_last_plane;
+    if (L.c && L.c != c && params->plane_index == L.plane_index + 1 && matrix_count == L.matrix_count && !(c->multi_plane && L.marked)) {    // (nothing to learn once both are marked: no lock)
+        std::lock_guard<std::mutex> lk(g_group_mu);
+        bool alive = false;
+        for (gfw_ctx *m : g_live) alive = alive || m == L.c;
+        if (alive && L.c->device == c->device && L.c->model == c->model && L.c->digital == c->digital) { L.c->multi_plane = true; c->multi_plane = true; }
+    }
+    L.c = c; L.plane_index = params->plane_index; L.matrix_count = matrix_count; L.marked = c->multi_plane;
+}
 // Orders the streams of the owner's member contexts behind everything enqueued on the owner's stream so far.
 static int order_members_behind(gfw_ctx *owner) {
     bool recorded = false;
@@ -1220,7 +1343,8 @@ static int group_launch(PlaneGroup *g) {
     gfw_buffers local[4]; gfw_kernel_params params[4]; int types[4];
     const int n = g->n;
     gfw_buffers *planes = local;
-    if (owner->coalesce_frames > 1) {
+    const bool hold_frames = owner->coalesce_frames > 1 && !owner->synchronous;      // (a synchronous owner — GFW_OPT_FRAME_SYNC — completes its frame before the last plane's call returns)
+    if (hold_frames) {
         // the assembled frame may wait for more of its clip — one launch of the specialised kernel for up to coalesce_frames frames, as gfw_undistort_clip
         // issues them; the descriptions a pending launch was validated with must outlive this call
         if (!owner->held) owner->held = new ClipBatch();
@@ -1228,11 +1352,26 @@ static int group_launch(PlaneGroup *g) {
         planes = owner->held_planes.data() + (size_t)4 * (owner->held->n % GFW_CLIP_FRAMES_MAX);
     }
     for (int i = 0; i < n; ++i) { planes[i] = g->pl[i].b; params[i] = g->pl[i].p; types[i] = g->pl[i].pixel_type; }
+    // INPUT side of the ordering (round 5): a member context's caller was stream-ordered on THAT context's stream — the upload or decode of its plane, or a
+    // consumer still reading its destination, may be in flight there.  The fused launch reads and writes those buffers on the owner's stream: it waits for
+    // whatever each member's stream held when the frame was completed (every member's call lies before this point).  Frames held for a clip launch
+    // (GFW_OPT_COALESCE_FRAMES) inherit the wait: the launch is enqueued later on the same in-order stream.
+    for (int i = 1; i < n; ++i) {
+        gfw_ctx *m = g->pl[i].c;
+        if (m == owner || m->stream == owner->stream) continue;
+        bool seen = false;
+        for (int k = 1; k < i; ++k) seen = seen || g->pl[k].c->stream == m->stream;
+        if (seen) continue;
+        if (!m->inputs_ready && hipEventCreateWithFlags(&m->inputs_ready, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); for (int k = 0; k < n; ++k) g->pl[k].c->pending_planes.fetch_sub(1, std::memory_order_relaxed); g->n = 0; return GFW_ERR_HIP; }
+        if (hipEventRecord(m->inputs_ready, m->stream) != hipSuccess || hipStreamWaitEvent(owner->stream, m->inputs_ready, 0) != hipSuccess) {
+            set_error("ordering the owner's stream behind plane %d's failed", i); for (int k = 0; k < n; ++k) g->pl[k].c->pending_planes.fetch_sub(1, std::memory_order_relaxed); g->n = 0; return GFW_ERR_HIP; }
+    }
     for (int i = 1; i < n; ++i) { g->pl[i].c->frame_owner = owner; g->pl[i].c->needs_order = true; }
+    for (int i = 0; i < n; ++i) g->pl[i].c->pending_planes.fetch_sub(1, std::memory_order_relaxed);
     g->n = 0;
     const float *mats = g->matrices_on_device ? g->d_matrices : g->h_matrices.data();
     int rc;
-    if (owner->coalesce_frames > 1) {
+    if (hold_frames) {
         rc = run_planes(owner, n, planes, params, types, mats, g->matrix_count, nullptr, 0, owner->held);
         if (rc == GFW_OK && owner->held->n >= owner->coalesce_frames) rc = flush_held_frames(owner);
         if (rc != GFW_OK) (void)flush_held_frames(owner);
@@ -1245,10 +1384,13 @@ static int group_launch(PlaneGroup *g) {
 // Everything pending that involves `c`: the frame it is a plane of, the frames it holds as an owner, the frames its owner holds.  g_group_mu held.
 static int flush_context_locked(gfw_ctx *c) {
     int rc = GFW_OK;
-    for (PlaneGroup *g : g_groups) {
+    for (size_t gi = 0; gi < g_groups.size(); ) {
+        PlaneGroup *g = g_groups[gi];
         bool member = false;
         for (int i = 0; i < g->n; ++i) member = member || g->pl[i].c == c;
         if (member) { const int r = group_launch(g); if (rc == GFW_OK) rc = r; }
+        if (g->orphan && g->n == 0) { g_groups[gi] = g_groups.back(); g_groups.pop_back(); delete g; continue; }      // its thread is gone: nobody else will
+        ++gi;
     }
     { const int r = flush_held_frames(c); if (rc == GFW_OK) rc = r; }
     if (c->frame_owner && c->frame_owner != c && c->needs_order) { const int r = flush_held_frames(c->frame_owner); if (rc == GFW_OK) rc = r; }
@@ -1273,7 +1415,7 @@ int gfw_flush(gfw_ctx *c) {
 // Entry points other than gfw_undistort_image keep their place in the order of calls: whatever is being held leaves first (no lock when nothing is)
 int flush_if_pending(gfw_ctx *c) {
     if (!c) return GFW_OK;
-    if (!(t_group && t_group->n > 0) && !(c->held && c->held->n > 0) && !c->needs_order) return GFW_OK;
+    if (!(t_group && t_group->n > 0) && !(c->held && c->held->n > 0) && !c->needs_order && c->pending_planes.load(std::memory_order_relaxed) == 0) return GFW_OK;
     return gfw_flush(c);
 }
 extern "C" {
@@ -1288,7 +1430,11 @@ int gfw_undistort_image(gfw_ctx *c, const gfw_buffers *buffers, const gfw_kernel
     const int pt = c->pixel_type;
     // Can this call wait for the rest of its frame?  Only if nothing about it has to happen before the call returns.
     const bool single_channel = pt == GFW_PIX_LUMA8 || pt == GFW_PIX_LUMA16 || pt == GFW_PIX_R32F || pt == GFW_PIX_UV8 || pt == GFW_PIX_UV16;
-    const bool holdable = c->coalesce_planes && !c->synchronous && buffers && params && matrices && single_channel && c->kernel_variant == 0 &&
+    // GFW_OPT_COALESCE_PLANES = 1 holds a call only on a context that has been SEEN as one plane of a multi-plane frame (below): a greyscale or single-float-plane
+    // caller's calls are never held, whatever their plane_index says.  A synchronous context's call may be held only under GFW_OPT_FRAME_SYNC.
+    plane_pattern_note(c, params, matrix_count);
+    const bool may_hold = c->coalesce_planes == 2 || (c->coalesce_planes == 1 && c->multi_plane);
+    const bool holdable = may_hold && (!c->synchronous || c->frame_sync) && buffers && params && matrices && single_channel && c->kernel_variant == 0 &&
                           buffers->input.kind == GFW_BUF_HIP_DEVICE && buffers->output.kind == GFW_BUF_HIP_DEVICE && (!mesh || mesh_len == 0) &&
                           params->plane_index >= 0 && params->plane_index < 4 && matrix_count >= 1;
     // (a context that never took part in a held frame, called by a thread that holds nothing: the round-3 path, no lock)
@@ -1323,10 +1469,17 @@ int gfw_undistort_image(gfw_ctx *c, const gfw_buffers *buffers, const gfw_kernel
     }
     PendingPlane &P = g->pl[g->n++];
     P.c = c; P.b = *buffers; P.p = *params; P.pixel_type = pt;
+    c->pending_planes.fetch_add(1, std::memory_order_relaxed);
     c->last_backend = "held_for_frame";
     // complete?  An interleaved chroma plane ends a frame; planar 8/16-bit frames have three planes (a fourth — alpha — goes by itself), planar float four
     const bool complete = pt == GFW_PIX_UV8 || pt == GFW_PIX_UV16 || ((pt == GFW_PIX_LUMA8 || pt == GFW_PIX_LUMA16) && g->n == 3) || g->n == 4;
-    if (complete) return group_launch(g);
+    if (complete) {
+        gfw_ctx *owner = g->pl[0].c;
+        const int rc = group_launch(g);
+        // GFW_OPT_FRAME_SYNC on a synchronous member of an asynchronous owner: the frame is complete when this call returns (a synchronous owner waited in run_planes)
+        if (rc == GFW_OK && c->synchronous && c != owner) HIP_TRY(hipStreamSynchronize(owner->stream), GFW_ERR_HIP);
+        return rc;
+    }
     return GFW_OK;
 }
 
@@ -1426,7 +1579,7 @@ extern "C" long gfw_debug_jit_compile(const char *arch, const char *defines, con
     std::vector<char> code;
     const long n = gfw_jit_compile_only(arch, defs, bake_header_text, lg, &code);
     if (log && cap) snprintf(log, cap, "%s", lg.c_str());
-    if (n > 0 && out_path && *out_path) { if (FILE *f = fopen(out_path, "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); } }
+    if (n > 0 && out_path && *out_path && !gfw_jit_write_code_object(out_path, code)) return GFW_ERR_UNKNOWN;
     return n;
 }
 
@@ -1456,7 +1609,7 @@ extern "C" int gfw_debug_jit_key(int nplanes, const gfw_buffers *planes, const g
     const std::vector<std::string> defs = jit_defs(Y, bps, params[0].interpolation, n0, dw, dh, interleaved, fast1, jit_model, jit_waves(n0, Y.matrix_count, jit_model, Y.extras, params[0].interpolation, bps, dh));
     std::string d;
     for (const std::string &x : defs) { if (!d.empty()) d += ";"; d += x; }
-    const std::string header = bake_header(Y), name = gfw_jit_cache_name(arch, defs, header);
+    const std::string header = bake_header(Y, fast1), name = gfw_jit_cache_name(arch, defs, header);
     if (d.size() + 1 > defs_cap || header.size() + 1 > header_cap || name.size() + 1 > name_cap) { set_error("output buffers too small"); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
     memcpy(defs_out, d.c_str(), d.size() + 1); memcpy(header_out, header.c_str(), header.size() + 1); memcpy(name_out, name.c_str(), name.size() + 1);
     return GFW_OK;

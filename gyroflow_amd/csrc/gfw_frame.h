@@ -55,6 +55,8 @@ struct GfwYuvArgs {
     float p1_eps, p1_ew, p1_em;       // E = p1_eps + p1_ew * omega + p1_em * mu: bound on |approx - exact| of the projected row/column coordinate, pixels;
                                       // omega, mu = the cancellation measures of the frame's mid-row matrix, evaluated by the kernel
     float p1_f, p1_c;                 // f[1], c[1] (f[0], c[0] for horizontal rolling shutter)
+    float p1_lat[6];                  // lattice form of the first pass: bounds max |s|, max sqrt(rho) |s'|, max rho |s'|, max rho^1.5 |s''| over the table's range
+                                      // (gfw_api.hip p1_prepare_table), the interpolation's own rounding allowance in pixels, [5] != 0: per-pixel form on request
     unsigned long long *audit;        // nullptr, or 8 words: certified, certified-but-wrong, queued, queue-overflow, max |approx-exact| (f32 bits),
                                       // [5] global addresses outside their buffer (audit mode range-checks every tap, store, matrix row and table entry)
     gfw_kernel_params kp;             // plane-0 params, for the non-specialised lens models

@@ -91,6 +91,14 @@
 #define GFW_ROW_CLUSTER 0       // experiment queued for round 5 (tools/r05_first_call.sh; bit-exact on the host interpreter): the luma pair's and the chroma site's taps of a
                                  // 4:2:2 / 4:4:4 planar lane-row fetched in ONE cluster, stores last (the luma store between them is an aliasing barrier: the row waits twice)
 #endif
+#ifndef GFW_P1_LATTICE
+#define GFW_P1_LATTICE 1         // round 5: the certified first pass evaluated at the nodes of a lattice (every 8th luma column of the wave's first and last row: one node per
+                                 // lane, once per tile) and interpolated bilinearly for the pixels, its curvature added to the certificate's half-width (DESIGN.md
+                                 // section 2c); 0: evaluated per pixel (round 2-4; still the path of clips with an r-limit, whose test is per pixel)
+#endif
+#ifndef GFW_P1_LATTICE_MAX_E
+#define GFW_P1_LATTICE_MAX_E 0.04f
+#endif
 #ifndef GFW_FASTROW
 #define GFW_FASTROW 1            // the branch-free lane-row of phase 3 (rd_lean_nobranch + one `__any` / `__all` per stage); 0: the per-pixel divergent code only (A/B)
 #endif
@@ -122,6 +130,10 @@
 #define GFW_CLIP_DIGITAL (A.common.digital)
 #endif
 
+#if GFW_BAKE && defined(GFW_ABLATE_FORCE)
+#undef GFW_BK_ablate                 // timing ablations of a SPECIALISED kernel (GFW_JIT_DEFS=GFW_ABLATE_FORCE=<bits>; the option's 16 + bits reach only the ahead-of-time kernels): wrong output by design
+#define GFW_BK_ablate (GFW_ABLATE_FORCE)
+#endif
 namespace {
 
 // Wave votes as one compare into a scalar pair and one scalar compare with EXEC: the library's __all / __any go through a 0/1 select and a second
@@ -145,6 +157,7 @@ static inline bool gfw_lanes(bool p) { return p; }
 static inline bool gfw_all_lanes(bool v) { return __all(v); }
 static inline bool gfw_vote_select(bool cur, bool cond, bool val) { return cond ? val : cur; }
 static inline bool gfw_vote_lane(bool v, int) { return v; }
+#define gfw_vote_failed(v) __ballot(!(v))
 #else
 typedef unsigned long long GfwVote;
 #define GFW_VOTE_ALL (~0ull)
@@ -152,6 +165,7 @@ typedef unsigned long long GfwVote;
 __device__ __forceinline__ bool gfw_all_lanes(GfwVote v) { const GfwVote e = __builtin_amdgcn_ballot_w64(true); return (v & e) == e; }
 __device__ __forceinline__ GfwVote gfw_vote_select(GfwVote cur, GfwVote cond, GfwVote val) { return (cur & ~cond) | (cond & val); }     // per lane: cond ? val : cur
 __device__ __forceinline__ bool gfw_vote_lane(GfwVote v, int lane) { return ((v >> (unsigned)lane) & 1ull) != 0ull; }
+__device__ __forceinline__ unsigned long long gfw_vote_failed(GfwVote v) { return ~v & __builtin_amdgcn_ballot_w64(true); }       // the active lanes whose predicate was false
 #endif
 
 // 32-phase bicubic / Lanczos4 tap table (one constant copy per translation unit)
@@ -1023,7 +1037,7 @@ __device__ __forceinline__ void feather_store(float ux, float uy, const Feather 
 // else — a percent or two of the pixels — goes through the exact projection: queued in LDS per wave and resolved
 // densely (one exact pass per few rows of the wave instead of one per pixel row).
 struct Mid { float m0, m1, m2, m3, m4, m5, m6, m7, m8; };
-struct P1 { float rho_max, rho_scale, eps, f, c, lim, wmin; };
+struct P1 { float rho_max, rho_scale, eps, f, c, lim, wmin, rho_lim, gap; };     // rho_lim, gap (= 1/2 - E): the lattice form's
 
 template <int MODEL>
 __device__ __forceinline__ int default_row(float ox, float oy, const GfwYuvArgs &A) {
@@ -1069,6 +1083,25 @@ __device__ __forceinline__ bool pass1_fast(float ax, float ay, float aw, float o
     good = good & (outside | (dist > Q.eps));                      // a NaN fails both comparisons
     sy = max(min(gfw_f2i(rintf(v)), (int)Q.lim), 0);
     return good;
+}
+
+// The lattice form (round 5): the same approximate value at ONE point — a node of the wave's lattice — or NaN where the certificate's premises fail there
+// (W not safely positive, rho beyond the table less the cell's margin: a pixel is certified only inside a cell whose four nodes are sound, and W, affine,
+// and rho, Lipschitz by the margin, then satisfy the premises at every point of the cell).  Operation for operation pass1_fast's value.
+__device__ __forceinline__ float pass1_node(float ox, float oy, const Mid &M, const P1 &Q, const float2 *tab, bool hrs) {
+    const float X = __builtin_fmaf(oy, M.m1, __builtin_fmaf(ox, M.m0, M.m2));
+    const float Y = __builtin_fmaf(oy, M.m4, __builtin_fmaf(ox, M.m3, M.m5));
+    const float W = __builtin_fmaf(oy, M.m7, __builtin_fmaf(ox, M.m6, M.m8));
+    const float rw = gfw_hw_rcp(W);
+    const float a = X * rw, b = Y * rw;
+    const float rho = __builtin_fmaf(a, a, b * b);
+    const bool good = (W > Q.wmin) & (rho < Q.rho_lim);            // (a NaN fails both)
+    const float tpos = min_limit(rho, Q.rho_max) * Q.rho_scale;
+    const uint32_t ti = gfw_f2u_trunc(tpos);
+    const float2 e = *reinterpret_cast<const float2 *>(reinterpret_cast<const uint8_t *>(tab) + ti * 8u);
+    const float s = __builtin_fmaf(__builtin_amdgcn_fractf(tpos), e.y, e.x);
+    const float v = __builtin_fmaf((hrs ? a : b) * s, Q.f, Q.c);
+    return good ? v : __builtin_nanf("");
 }
 
 #if GFW_TIMELINE
@@ -1118,7 +1151,11 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     __shared__ unsigned short q_dst[FAST1 ? 4 : 1][FAST1 ? QCAP : 1];           // (owner lane << 6) | slot in s_rows
     __shared__ unsigned short s_rows[RB * NPX][256];                             // phase-1 rows (< 65536: the host keeps larger frames off this path), one column per lane
     __shared__ float s_lut[I == 2 ? 1 : 448];                                    // bicubic / Lanczos4 tap table
-    __shared__ float2 s_p1[FAST1 ? GFW_CLIP_MAX : 1];                            // per frame of the launch: certificate half-width E, W threshold
+    __shared__ float4 s_p1[FAST1 ? GFW_CLIP_MAX : 1];                            // per frame of the launch: certificate half-width E, W threshold, (lattice form) rho limit of a node
+    // the lattice form of the first pass: a wave's nodes sit on every 8th luma column of its 64 * DW columns (both ends: NXN per row) in its first and its last luma row
+    constexpr bool LAT = GFW_P1_LATTICE && FAST1 && (RB * DH > 1);
+    constexpr int NXN = (64 * DW) / 8 + 1, HYR = RB * DH - 1;
+    __shared__ float s_node[LAT ? 4 : 1][LAT ? 64 : 1];
     const int wave = threadIdx.y, lane = threadIdx.x, tid = wave * 64 + lane;
     if (MODEL == GFW_MODEL_OPENCV_FISHEYE) { gfw_atan_lds_init(tid); gfw_atan_key_lds_init(tid); }
     if (I != 2) {
@@ -1143,7 +1180,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     float bg_c[2] = {PL1.bg[0], PL1.bg[1]};
     const float lim_u = PL1.limit, bg_v = PL2.bg[0], lim_v = PL2.limit;
     Mid M{0, 0, 0, 0, 0, 0, 0, 0, 0};
-    P1 Q{0, 0, 0, 0, 0, 0, 0};
+    P1 Q{0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto load_mid = [&]() {                          // first-pass matrix of the current frame: wave-uniform -> scalar loads
         const float *mid = matrices + (size_t)(AF(matrix_count) >> 1) * GFW_MAT_STRIDE;
         M.m0 = mid[0]; M.m1 = mid[1]; M.m2 = mid[2]; M.m3 = mid[3]; M.m4 = mid[4];
@@ -1166,27 +1203,62 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
             const float *mid = matrices + (size_t)(AF(matrix_count) >> 1) * GFW_MAT_STRIDE;
 #endif
             const float m0 = mid[0], m1 = mid[1], m3 = mid[3], m4 = mid[4], m6 = mid[6], m7 = mid[7], m8 = mid[8];
-            const float ax = fmaxf(fabsf(L.t2x), fabsf((float)AF(out_w) + L.t2x)), ay = fmaxf(fabsf(L.t2y), fabsf((float)AF(out_h) + L.t2y));
+            bool lattice = LAT && !(L.rl2 > 0.0f) && A.p1_lat[5] == 0.0f;            // (p1_lat[5]: the per-pixel form on request — audits of that form, A/B runs)
+            // (the lattice's nodes reach up to a tile beyond the frame's last pixel)
+            const float ax = fmaxf(fabsf(L.t2x), fabsf((float)(AF(out_w) + (lattice ? 64 * DW : 0)) + L.t2x)), ay = fmaxf(fabsf(L.t2y), fabsf((float)(AF(out_h) + (lattice ? 4 * RB * DH : 0)) + L.t2y));
             const float px = ax * fabsf(m0) + ay * fabsf(m1), py = ax * fabsf(m3) + ay * fabsf(m4), pw = ax * fabsf(m6) + ay * fabsf(m7);
             const float wmin = fmaxf(0.0009765625f, 0.125f * (pw + fabsf(m8)));
-            const float rden = gfw_hw_rcp(fmaxf(m8 - pw, wmin)) * 3.003f;            // (3x; 1 ulp reciprocal and the roundings of the sums above: inside the 0.1 %)
+            const float wden = fmaxf(m8 - pw, wmin);
+            const float rden = gfw_hw_rcp(wden) * 3.003f;                            // (3x; 1 ulp reciprocal and the roundings of the sums above: inside the 0.1 %)
             const float omega = pw * rden, mu = fmaxf(px, py) * rden;
-            const float E = __builtin_fmaf(A.p1_em, mu, __builtin_fmaf(A.p1_ew, omega, A.p1_eps));
-            bool usable = (E < 0.2f) & (pw + m8 < 3.0e38f);                           // (a NaN or an infinity among the operands fails a comparison)
+            float E = __builtin_fmaf(A.p1_em, mu, __builtin_fmaf(A.p1_ew, omega, A.p1_eps));
+            float rho_lim = A.p1_rho_max;
+            const float E_pixel = E;                           // the per-pixel form's half-width (its nodes ARE the pixels)
+            if (lattice) {
+                // The interpolation's own error: bilinear interpolation of v over a cell of HX x HYR pixels misses it by at most HX^2/8 max|v_xx| + HYR^2/8 max|v_yy|.
+                // v = f c S(rho) + c0 with c = b (a for a horizontal shutter), (a, b) = (X, Y) / W, rho = a^2 + b^2.  Where W >= wden and rho <= rho_max:
+                //   |a_x| <= (|m0| + rmax |m6|) / wden =: a1x, |b_x| <= (|m3| + rmax |m6|) / wden =: b1x, a_xx = -2 m6 a_x / W, b_xx = -2 m6 b_x / W;  n1 = |(a_x, b_x)|, n2 = |(a_xx, b_xx)|;
+                //   |rho_x| <= 2 sqrt(rho) n1, |rho_xx| <= 2 (n1^2 + sqrt(rho) n2)        (Cauchy-Schwarz);
+                //   (c S)_xx = c_xx S + 2 c_x S' rho_x + c (S'' rho_x^2 + S' rho_xx),  |c| <= sqrt(rho):
+                //   |(c S)_xx| <= c2 S0 + 4 c1 n1 U1 + 4 n1^2 T32 + 2 n1^2 U1 + 2 n2 U2
+                // with the host's bounds S0 >= |S|, U1 >= sqrt(rho) |S'|, U2 >= rho |S'|, T32 >= rho^1.5 |S''| over the table's range (gfw_api.hip p1_prepare_table) —
+                // the products are bounded together because S'' falls as rho grows: their separate maxima overstate the curvature twentyfold.  The same with m1, m4, m7 for y.
+                // The node coordinates' own rounding (ox = fl(lx + t2x)) moves v by u |ox| |v_x|: the last term.  1 % on top for this evaluation's own f32 roundings.
+                const float rw = gfw_hw_rcp(wden) * 1.001f, rmax = __builtin_sqrtf(A.p1_rho_max) * 1.0001f;
+                const float S0 = A.p1_lat[0], U1 = A.p1_lat[1], U2 = A.p1_lat[2], T32 = A.p1_lat[3];
+                const float a1x = (fabsf(m0) + rmax * fabsf(m6)) * rw, b1x = (fabsf(m3) + rmax * fabsf(m6)) * rw;
+                const float a1y = (fabsf(m1) + rmax * fabsf(m7)) * rw, b1y = (fabsf(m4) + rmax * fabsf(m7)) * rw;
+                const float k6 = 2.0f * fabsf(m6) * rw, k7 = 2.0f * fabsf(m7) * rw;
+                const float n1x = __builtin_sqrtf(a1x * a1x + b1x * b1x), n1y = __builtin_sqrtf(a1y * a1y + b1y * b1y);
+                const float n2x = k6 * n1x, n2y = k7 * n1y;
+                const float c1x = hrs ? a1x : b1x, c1y = hrs ? a1y : b1y;
+                const float gxx = k6 * c1x * S0 + 4.0f * c1x * n1x * U1 + n1x * n1x * (4.0f * T32 + 2.0f * U1) + 2.0f * n2x * U2;
+                const float gyy = k7 * c1y * S0 + 4.0f * c1y * n1y * U1 + n1y * n1y * (4.0f * T32 + 2.0f * U1) + 2.0f * n2y * U2;
+                const float gx = c1x * S0 + 2.0f * U2 * n1x, gy = c1y * S0 + 2.0f * U2 * n1y;                    // |(c S)_x|, |(c S)_y|
+                const float hx2 = 8.0f, hy2 = (float)(HYR * HYR) * 0.125f;                                       // HX^2 / 8 (HX = 8), HYR^2 / 8
+                E = E + 1.01f * fabsf(AF(p1_f)) * (hx2 * gxx + hy2 * gyy + 5.9604645e-8f * (ax * gx + ay * gy)) + A.p1_lat[4];
+                rho_lim = A.p1_rho_max - 1.01f * 2.0f * rmax * (8.0f * n1x + (float)HYR * n1y);                  // |rho| moves by at most this much between a node and any point of its cells
+                // The curvature term scales with (8 / f)^2: a 4K frame adds a few thousandths of a pixel, a thumbnail whole pixels.  Beyond GFW_P1_LATTICE_MAX_E (every
+                // twelfth pixel undecided) — or a NaN — the frame keeps the per-pixel form and its own, smaller, half-width.
+                if (!(E <= GFW_P1_LATTICE_MAX_E) || !(rho_lim > 0.0f)) { lattice = false; E = E_pixel; rho_lim = A.p1_rho_max; }
+            }
+            bool usable = (E < 0.2f) & (pw + m8 < 3.0e38f) & (rho_lim > 0.0f);        // (a NaN or an infinity among the operands fails a comparison)
             if (L.rl2 > 0.0f) {
                 // :139 in pass1_fast: lhs < 0.9999 rhs must imply the exact path's lhs <= rhs.  The two paths' X^2 + Y^2 differ by at most
                 // 1.05 u W^2 (2 sqrt2 rmax mu + 12.5 rho_max), their r_limit^2 W by r_limit^2 W u (omega + 8); W <= m8 + P_W; 1e-4 / u = 1677.7
                 const float rmax = __builtin_sqrtf(A.p1_rho_max);
                 usable = usable & (1.05f * (m8 + pw) * (2.83f * rmax * mu + 12.5f * A.p1_rho_max) + L.rl2 * (omega + 8.0f) <= 1677.0f * L.rl2);
             }
-            s_p1[tid] = float2{E, usable ? wmin : __builtin_inff()};                 // W > inf never holds: every pixel of the frame goes to the exact path
+            s_p1[tid] = float4{E, usable ? wmin : __builtin_inff(), rho_lim, lattice ? 1.0f : 0.0f};  // W > inf never holds: every pixel of the frame goes to the exact path
             if (AUDIT && usable) atomicMax(&AF(audit)[6], (unsigned long long)gfw_f2u(E));
         }
         __syncthreads();
     }
+    bool p1_lattice = false;                              // the current frame's first pass takes the lattice form
     auto p1_bound = [&](int fi) {
-        const float2 q = s_p1[fi];
-        Q.eps = gfw_uniform(q.x); Q.wmin = gfw_uniform(q.y);
+        const float4 q = s_p1[fi];
+        Q.eps = gfw_uniform(q.x); Q.wmin = gfw_uniform(q.y); Q.rho_lim = gfw_uniform(q.z); Q.gap = 0.5f - Q.eps;
+        p1_lattice = LAT && gfw_uniform(q.w) != 0.0f;
     };
     if (two_pass) {
         load_mid();
@@ -1280,48 +1352,106 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
             }
         };
         // ---- phase 1: rolling-shutter row of every luma pixel of this lane ----------------------------
-        if (two_pass) {
+        if (two_pass && FAST1) {
+            // Certified first pass.  Lattice form (round 5; chosen per frame by the certificate's evaluation): the first pass's value v is smooth across a tile and what
+            // phase 3 needs of it is clamp(round(v)).  Lanes 0 .. 2 NXN - 1 evaluate v at one node each — columns 0, 8, ..., 64 DW of the wave's span, in its first and its
+            // last luma row — every lane then interpolates its own pixels bilinearly between the four nodes around them (a lane's DW pixels never straddle a node column)
+            // and certifies the rounded value when no half-integer lies within E of it; E carries the interpolation's error.  A node whose premises fail is NaN, and so is
+            // everything interpolated from it: those pixels fail the comparison and are queued for the exact projection like any other undecided pixel.
+            // Per-pixel form (rounds 2-4; clips with an r-limit, whose test is per pixel, and frames whose curvature term is too wide): pass1_fast at every pixel.
+            const bool lat = LAT && p1_lattice;
+            float Tn[DW], Dn[DW];                             // lattice form: the lane's columns — v in the wave's first row, and its change down to the last
+            #pragma unroll
+            for (int i = 0; i < DW; ++i) { Tn[i] = 0.0f; Dn[i] = 0.0f; }
+            if (LAT && lat) {
+                int ln = lane, wv = wave;
+                asm("" : "+v"(ln));               // opaque: the nodes' offsets and LDS addresses are a handful of instructions per tile; hoisted out of the tile walk they
+                asm("" : "+v"(wv));               // lived in registers for the whole kernel, and two of them spilled
+                const int niy = ln >= NXN ? 1 : 0, nix = ln - niy * NXN;                      // (lanes beyond 2 NXN evaluate a point nobody reads)
+                const float nox = (float)(tx * (64 * DW) + nix * 8) + L.t2x, noy = (float)(cy0 * DH + niy * HYR) + L.t2y;
+                s_node[wv][ln] = pass1_node(nox, noy, M, Q, A.p1_table, hrs);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int ci = (ln * DW) >> 3;
+                const float v00 = s_node[wv][ci], v01 = s_node[wv][ci + 1], v10 = s_node[wv][NXN + ci], v11 = s_node[wv][NXN + ci + 1];
+                const float dT = v01 - v00, dB = v11 - v10;
+                #pragma unroll
+                for (int i = 0; i < DW; ++i) {
+                    const float txi = (float)((ln * DW + i) & 7) * 0.125f;
+                    Tn[i] = __builtin_fmaf(txi, dT, v00);
+                    Dn[i] = __builtin_fmaf(txi, dB, v10) - Tn[i];
+                }
+            }
+            #pragma unroll 1
+            for (int q = 0; q < RB * DH; ++q) {                // the lane's luma rows, top to bottom
+                const int r = q / DH, j = q % DH;
+                const int ly = cy0 * DH + q;
+                const float oy = (float)ly + L.t2y;
+                // every lane evaluates (a dead lane's coordinates are as good as any); "certified" travels as a wave mask — the compare's own result, in scalar registers
+                GfwVote good[DW]; int sy[DW]; float v_fast[DW];
+                if (LAT && lat) {
+                    const float ty = (float)q * (1.0f / (float)(HYR > 0 ? HYR : 1));
+                    #pragma unroll
+                    for (int i = 0; i < DW; ++i) {
+                        v_fast[i] = __builtin_fmaf(ty, Dn[i], Tn[i]);
+                        const float n = rintf(v_fast[i]);
+                        good[i] = gfw_lanes(fabsf(v_fast[i] - n) < Q.gap);           // (NaN: not certified)
+                        sy[i] = max(min(gfw_f2i(n), (int)Q.lim), 0);
+                    }
+                } else {
+                    #pragma unroll
+                    for (int i = 0; i < DW; ++i) {
+                        const float ox = (float)(cx * DW + i) + L.t2x;
+                        const float ax = __builtin_fmaf(ox, M.m0, M.m2), ay = __builtin_fmaf(ox, M.m3, M.m5), aw = __builtin_fmaf(ox, M.m6, M.m8);
+                        good[i] = gfw_lanes(pass1_fast(ax, ay, aw, oy, M, Q, A.p1_table, hrs, L.rl2, sy[i], v_fast[i], AUDIT ? AF(audit) : nullptr));
+                    }
+                }
+                #pragma unroll
+                for (int i = 0; i < DW; ++i) {
+                    const int lx = cx * DW + i;
+                    const bool live = WHOLE || (lane_ok && lx < AF(out_w) && ly < AF(out_h));
+                    if (!WHOLE) good[i] = good[i] | gfw_lanes(!live);
+                    s_rows[r * NPX + j * DW + i][tid] = (unsigned short)(live ? sy[i] : 0);
+                    if (AUDIT && gfw_vote_lane(good[i], lane) && live) {           // audit: every certificate is checked
+                        const float ox = (float)lx + L.t2x;
+                        atomicAdd(&AF(audit)[0], 1ull);
+                        if (pass1_exact<MODEL>(ox, oy, M, matrices, L, A) != sy[i]) atomicAdd(&AF(audit)[1], 1ull);
+                        const GfwPt ex = rd<MODEL>(ox, oy, float4{M.m0, M.m1, M.m2, M.m3}, float4{M.m4, M.m5, M.m6, M.m7}, M.m8, matrices + (size_t)(AF(matrix_count) / 2) * GFW_MAT_STRIDE + 8, L, A);
+                        if (ex.ok) atomicMax(&AF(audit)[4], (unsigned long long)gfw_f2u(fabsf((hrs ? ex.x : ex.y) - v_fast[i])));
+                    }
+                }
+                unsigned long long undecided[DW], any_und = 0ull;
+                #pragma unroll
+                for (int i = 0; i < DW; ++i) { undecided[i] = gfw_vote_failed(good[i]); any_und |= undecided[i]; }
+                if (any_und) {                                 // uniform: the usual row certifies every pixel
+                    #pragma unroll
+                    for (int i = 0; i < DW; ++i) {
+                        if (!gfw_vote_lane(good[i], lane)) {
+                            const unsigned slot = n_q + __builtin_amdgcn_mbcnt_hi((unsigned)(undecided[i] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)undecided[i], 0u));   // < QCAP: flushed before it can fill
+                            q_x[wave][slot] = (float)(cx * DW + i) + L.t2x; q_y[wave][slot] = oy;
+                            q_dst[wave][slot] = (unsigned short)((lane << 6) | (r * NPX + j * DW + i));
+                            if (AUDIT) atomicAdd(&AF(audit)[2], 1ull);
+                        }
+                        n_q += (unsigned)__popcll(undecided[i]);
+                    }
+                }
+                flush_queue(q == RB * DH - 1);                 // (a look at the queue per row: at most 64 DW new entries since the last)
+            }
+        } else if (two_pass) {
             #pragma unroll 1
             for (int r = 0; r < RB; ++r) {
-              {
                 #pragma unroll (NPX <= 2 ? NPX : 1)
                 for (int k = 0; k < NPX; ++k) {
                     const int i = k % DW, j = k / DW;
                     const int lx = cx * DW + i, ly = (cy0 + r) * DH + j;
                     const bool live = WHOLE || (lane_ok && lx < AF(out_w) && ly < AF(out_h));
                     int sy = 0;
-                    if (FAST1) {
-                        // every lane evaluates (a dead lane's coordinates are as good as any): the ballot below is in uniform control flow
-                        const float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
-                        float v_fast;
-                        const float ax = __builtin_fmaf(ox, M.m0, M.m2), ay = __builtin_fmaf(ox, M.m3, M.m5), aw = __builtin_fmaf(ox, M.m6, M.m8);
-                        const bool good = pass1_fast(ax, ay, aw, oy, M, Q, A.p1_table, hrs, L.rl2, sy, v_fast, AUDIT ? AF(audit) : nullptr) | !live;
-                        const unsigned long long undecided = __ballot(!good);
-                        if (undecided) {
-                            if (!good) {
-                                const unsigned slot = n_q + __builtin_amdgcn_mbcnt_hi((unsigned)(undecided >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)undecided, 0u));   // < QCAP: flushed before it can fill
-                                q_x[wave][slot] = ox; q_y[wave][slot] = oy;
-                                q_dst[wave][slot] = (unsigned short)((lane << 6) | (r * NPX + k));
-                                if (AUDIT) atomicAdd(&AF(audit)[2], 1ull);
-                            }
-                            n_q += (unsigned)__popcll(undecided);
-                        }
-                        if (AUDIT && good && live) {                                  // audit: every certificate is checked
-                            atomicAdd(&AF(audit)[0], 1ull);
-                            if (pass1_exact<MODEL>(ox, oy, M, matrices, L, A) != sy) atomicAdd(&AF(audit)[1], 1ull);
-                            const GfwPt ex = rd<MODEL>(ox, oy, float4{M.m0, M.m1, M.m2, M.m3}, float4{M.m4, M.m5, M.m6, M.m7}, M.m8, matrices + (size_t)(AF(matrix_count) / 2) * GFW_MAT_STRIDE + 8, L, A);
-                            if (ex.ok) atomicMax(&AF(audit)[4], (unsigned long long)gfw_f2u(fabsf((hrs ? ex.x : ex.y) - v_fast)));
-                        }
-                    } else if (live) {
+                    if (live) {
                         float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
                         if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (AF(extras) & 8)) gfw_lens_correction_blend<(MODEL == GFW_MODEL_GENERIC_EXTRA ? -1 : MODEL)>(ox, oy, A.kp, A.common, AF(model), GFW_CLIP_DIGITAL);   // :429-460
                         sy = pass1_exact<MODEL>(ox, oy, M, matrices, L, A);
                     }
                     s_rows[r * NPX + k][tid] = (unsigned short)(live ? sy : 0);
-                    if (FAST1 && NPX > QSTEP && (k % QSTEP) == QSTEP - 1 && k != NPX - 1) flush_queue(false);      // 4:2:0: a look at the queue per pixel pair
                 }
-              }
-                if (FAST1) flush_queue(r == RB - 1);
             }
         }
 

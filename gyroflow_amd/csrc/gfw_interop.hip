@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <string>
 #include <string.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "../../include/gfwarp.h"
@@ -51,7 +52,12 @@ extern "C" int gfw_import_external_fd(int fd, size_t size, unsigned long long dr
         const ssize_t n = readlink(link, target, sizeof(target) - 1);
         if (n <= 0) { gfw_set_error_text("gfw_import_external_fd: not an open file descriptor"); return GFW_ERR_INVALID_ARGUMENT; }
         target[n] = 0;
-        if (!strstr(target, "dmabuf")) {
+        // (a prefix match on the link text — "/dmabuf:" or "anon_inode:dmabuf" — plus fstat: a regular file, directory, device node or socket whose PATH merely
+        // contains the word is not one; a dma-buf's inode is none of those types)
+        struct stat st;
+        const bool named = strncmp(target, "/dmabuf:", 8) == 0 || strncmp(target, "anon_inode:dmabuf", 17) == 0 || strncmp(target, "anon_inode:[dmabuf", 18) == 0;
+        const bool plain = fstat(fd, &st) != 0 || S_ISREG(st.st_mode) || S_ISDIR(st.st_mode) || S_ISCHR(st.st_mode) || S_ISBLK(st.st_mode) || S_ISSOCK(st.st_mode) || S_ISFIFO(st.st_mode);
+        if (!named || plain) {
             char buf[384];
             snprintf(buf, sizeof(buf), "descriptor %d (%s) is not a dma-buf: nothing the device can map", fd, target);
             gfw_set_error_text(buf);

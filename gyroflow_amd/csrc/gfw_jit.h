@@ -15,4 +15,5 @@ hipFunction_t gfw_jit_get(int device, const std::string &arch, const std::vector
 long gfw_jit_compile_only(const std::string &arch, const std::vector<std::string> &defines, const std::string &bake_header, std::string &log,
                           std::vector<char> *code_out);
 hipError_t gfw_jit_launch(hipFunction_t fn, const GfwClipArgs &C, int grid, hipStream_t s);
+bool gfw_jit_write_code_object(const std::string &path, const std::vector<char> &code);
 bool gfw_jit_read_symbol(hipFunction_t fn, const char *name, void *dst, size_t bytes);

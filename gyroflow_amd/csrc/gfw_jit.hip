@@ -17,6 +17,7 @@
 #include <unistd.h>
 #include <atomic>
 #include <chrono>
+#include <dirent.h>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -40,6 +41,8 @@ struct Rtc {
     int (*code_size)(rtcProgram, size_t *) = nullptr;
     int (*code)(rtcProgram, char *) = nullptr;
     int (*destroy)(rtcProgram *) = nullptr;
+    int (*version)(int *, int *) = nullptr;
+    int ver_major = 0, ver_minor = 0;            // hiprtcVersion of the library that was found (0.0: none): two ROCm releases compile one source into kernels of different speed
     bool ok = false;
     Rtc() {
         if (const char *e = getenv("GFW_NO_HIPRTC")) { if (e[0] == '1') return; }        // tests: behave like a box without libhiprtc.so
@@ -53,7 +56,9 @@ struct Rtc {
         GFW_RTC_SYM(log_size, "hiprtcGetProgramLogSize"); GFW_RTC_SYM(log, "hiprtcGetProgramLog");
         GFW_RTC_SYM(code_size, "hiprtcGetCodeSize"); GFW_RTC_SYM(code, "hiprtcGetCode"); GFW_RTC_SYM(destroy, "hiprtcDestroyProgram");
 #undef GFW_RTC_SYM
+        version = reinterpret_cast<decltype(version)>(dlsym(lib, "hiprtcVersion"));
         ok = create && compile && log_size && log && code_size && code && destroy;
+        if (ok && version) (void)version(&ver_major, &ver_minor);
     }
 };
 void join_all_workers();
@@ -120,32 +125,62 @@ static std::string full_key(const std::string &arch, const std::vector<std::stri
     key += std::to_string(sizeof(GFW_JIT_SOURCE)) + ":" + key_hash(GFW_JIT_SOURCE);          // the embedded source itself
     return key;
 }
+// A code object read back must at least be one: an ELF header and a plausible size (a file cut short by an interrupted writer used to be loaded, fail in
+// hipModuleLoadData and mark the clip's kernel dead for the rest of the clip).
+static bool looks_like_code_object(const std::vector<char> &c) {
+    return c.size() > 64 && c[0] == 0x7f && c[1] == 'E' && c[2] == 'L' && c[3] == 'F';
+}
+static bool read_code_object(const std::string &path, std::vector<char> &code) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+    bool ok = n > 0;
+    if (ok) { code.resize((size_t)n); ok = fread(code.data(), 1, (size_t)n, f) == (size_t)n; }
+    fclose(f);
+    return ok && looks_like_code_object(code);
+}
+// The shipped directory next to the library is part of THIS build (its kernels were compiled by the build's own compiler, like the ahead-of-time ones): its files
+// are named by the key alone.  $GFW_JIT_CACHE may be shared across hosts and ROCm upgrades, and the compiler is part of what a kernel is (same source, ROCm 7.0
+// against 7.2: 64 against 78 us per C2 bicubic frame, profiles/r04_ab_lut_rows.txt): its files carry the hiprtc version that produced them,
+// <hash>.rtc<major>.<minor>.co, and a process finds only its own compiler's.  A process WITHOUT hiprtc cannot compile at all and takes any version's kernel.
+static std::string rtc_tag() { Rtc &R = rtc(); return R.ok ? ".rtc" + std::to_string(R.ver_major) + "." + std::to_string(R.ver_minor) : std::string(); }
 static bool cache_load(const std::string &hash, std::vector<char> &code, std::string &from) {
-    std::vector<std::string> dirs;
     const std::string ld = lib_dir();
-    if (!ld.empty()) dirs.push_back(ld + "/jit_cache");
-    if (const char *e = getenv("GFW_JIT_CACHE")) if (*e) dirs.push_back(e);
-    for (const std::string &d : dirs) {
-        const std::string path = d + "/" + hash + ".co";
-        if (FILE *f = fopen(path.c_str(), "rb")) {
-            fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
-            bool ok = n > 0;
-            if (ok) { code.resize((size_t)n); ok = fread(code.data(), 1, (size_t)n, f) == (size_t)n; }
-            fclose(f);
-            if (ok) { from = path; return true; }
+    if (!ld.empty()) {
+        const std::string path = ld + "/jit_cache/" + hash + ".co";
+        if (read_code_object(path, code)) { from = path; return true; }
+    }
+    const char *e = getenv("GFW_JIT_CACHE");
+    if (!e || !*e) return false;
+    const std::string tag = rtc_tag();
+    if (!tag.empty()) {
+        const std::string path = std::string(e) + "/" + hash + tag + ".co";
+        if (read_code_object(path, code)) { from = path; return true; }
+        return false;
+    }
+    if (DIR *d = opendir(e)) {                     // no compiler here: whichever version's kernel the farm left
+        std::string found;
+        while (struct dirent *ent = readdir(d)) {
+            const std::string n = ent->d_name;
+            if (n.size() > hash.size() + 3 && n.compare(0, hash.size(), hash) == 0 && n.compare(n.size() - 3, 3, ".co") == 0 && (found.empty() || n > found)) found = n;
         }
+        closedir(d);
+        if (!found.empty() && read_code_object(std::string(e) + "/" + found, code)) { from = std::string(e) + "/" + found; return true; }
     }
     return false;
 }
+static bool write_atomically(const std::string &path, const std::vector<char> &code) {
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) { remove(tmp.c_str()); return false; }
+    return true;
+}
 static void cache_store(const std::string &hash, const std::vector<char> &code) {
     const char *e = getenv("GFW_JIT_CACHE");
-    if (!e || !*e || code.empty()) return;
-    const std::string path = std::string(e) + "/" + hash + ".co", tmp = path + ".tmp" + std::to_string((long)getpid());
-    if (FILE *f = fopen(tmp.c_str(), "wb")) {
-        const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
-        fclose(f);
-        if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
-    }
+    if (!e || !*e || !looks_like_code_object(code)) return;
+    (void)write_atomically(std::string(e) + "/" + hash + rtc_tag() + ".co", code);
 }
 
 void join_all_workers() {
@@ -178,6 +213,8 @@ void compile_entry(Entry *e, std::string source, std::vector<std::string> opts, 
 
 }  // namespace
 
+// a code object to a file, through a temporary name (tools/build_jit_cache.py via gfw_debug_jit_compile: an interrupted build leaves no truncated entry behind)
+bool gfw_jit_write_code_object(const std::string &path, const std::vector<char> &code) { return looks_like_code_object(code) && write_atomically(path, code); }
 bool gfw_jit_available() { return rtc().ok; }      // (kernels cached on disk are served without it: gfw_jit_get)
 // The file name a specialised kernel has in the on-disk caches (tools/build_jit_cache.py fills the shipped one through gfw_debug_jit_key).
 std::string gfw_jit_cache_name(const std::string &arch, const std::vector<std::string> &defines, const std::string &bake_header) {

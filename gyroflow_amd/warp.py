@@ -87,6 +87,10 @@ class Backend:
     def set_stream(self, stream_ptr):
         self._check(self.lib.gfw_set_stream(self.ctx, stream_ptr))
 
+    def get_stream(self):
+        """hipStream_t the context enqueues on (an int), after whatever it holds for a frame or a launch has been enqueued (gfw_get_stream flushes)."""
+        return self.lib.gfw_get_stream(self.ctx)
+
     def jit_status(self):
         """(state, compile milliseconds, compiler log) of the context's run-time specialised kernel; state 0 none / unavailable,
         1 compiling, 2 ready, 3 failed (gfw_jit_status)."""

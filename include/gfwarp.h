@@ -273,7 +273,8 @@ enum {
                                         sets it for every clip that has such data); with 1 the roll's cos/sin are
                                         evaluated on the device with the host libm's own routines (gfw_math.h). */
     GFW_OPT_KERNEL_VARIANT     = 3,  /* (further values: gfwarp_testing.h)  0 auto; 1 generic per-plane kernel; 2 fused kernel with the exact first pass;
-                                        3 fused kernel, certified first pass in audit mode (see gfw_get_audit);
+                                        3 fused kernel, certified first pass in audit mode (see gfw_get_audit); 4 the same with the first pass evaluated
+                                        per pixel (the form of rounds 2-4; by default a frame takes the lattice form where its certificate allows);
                                         16 + bits: timing ablations of the fused kernel (wrong output by design) */
     GFW_OPT_PROFILE            = 4,  /* 1: bracket every warp-kernel launch with hipEvents on the context stream */
     GFW_OPT_TUNE_ROWS          = 5,  /* reserved (ignored) */
@@ -283,19 +284,32 @@ enum {
                                         frames with the same clip constants, frames run ahead-of-time until it is ready; 2 built at the first
                                         frame, which waits for it (~1 s).  Same results bit for bit; the environment variable GFW_JIT sets
                                         the default of new contexts.  Without libhiprtc.so the option has no effect. */
-    GFW_OPT_COALESCE_PLANES    = 8,  /* 1 (default): the planes of a frame that arrive one per gfw_undistort_image call — the reference's render loop issues
+    GFW_OPT_COALESCE_PLANES    = 8,  /* the planes of a frame that arrive one per gfw_undistort_image call — the reference's render loop issues
                                         process_pixels once per plane, each plane through its own Stabilization / backend object
                                         (src/rendering/mod.rs:494-545) — leave as ONE fused launch.  Applies to calls that are stream-ordered anyway:
-                                        GFW_OPT_SYNCHRONOUS = 0, HIP_DEVICE buffers on both sides.  Such a call validates its arguments, keeps a copy and
-                                        returns; the frame is enqueued (on the stream of the context that took plane_index 0, every other member's stream
-                                        ordered behind it) when its last plane arrives — a UV8 / UV16 plane, the third Luma plane, the fourth R32f plane —
-                                        or when anything else is asked of a member context (gfw_synchronize, gfw_flush, an option, a plane that does not
-                                        continue the frame, gfw_destroy).  COMPLETION CONTRACT: observe completion through gfw_synchronize / gfw_flush of any
-                                        member context (or events recorded after them), not by synchronising the raw stream alone.  Results are bit-identical
-                                        to the per-plane launches.  0: every call launches its own plane (round-3 behaviour). */
-    GFW_OPT_COALESCE_FRAMES    = 9   /* frames assembled by GFW_OPT_COALESCE_PLANES that are held for one launch of the run-time specialised kernel
+                                        GFW_OPT_SYNCHRONOUS = 0 (or GFW_OPT_FRAME_SYNC), HIP_DEVICE buffers on both sides.  Such a call validates its
+                                        arguments, keeps a copy and returns; the frame is enqueued on the stream of the context that took plane_index 0
+                                        when its last plane arrives — a UV8 / UV16 plane, the third Luma plane, the fourth R32f plane — or when anything
+                                        else is asked of a member context (gfw_synchronize, gfw_flush, gfw_get_stream, an option, a plane that does not
+                                        continue the frame, gfw_destroy).
+                                        1 (default): only calls on contexts that have been SEEN as planes of a multi-plane frame are held (a call with
+                                        plane_index k + 1 following, on the same thread, a call with plane_index k on another context of the same device,
+                                        lens and matrix count): a clip's first frame leaves plane by plane, a lone greyscale / float plane is never held.
+                                        2: every eligible call is held from the first frame on.  0: every call launches its own plane.
+                                        ORDERING CONTRACT: the fused launch waits for everything that was enqueued on EACH member context's stream before
+                                        the frame was completed (a plane's upload or decode, a consumer still reading its destination), and every member's
+                                        stream is ordered behind the launch.  Observe completion through gfw_synchronize / gfw_flush / gfw_get_stream of
+                                        any member context (or events recorded after them).  Results are bit-identical to the per-plane launches. */
+    GFW_OPT_COALESCE_FRAMES    = 9,  /* frames assembled by GFW_OPT_COALESCE_PLANES that are held for one launch of the run-time specialised kernel
                                         (1..GFW_CLIP_FRAMES_MAX; default 1: a frame leaves when it is complete).  Larger values trade latency for the
-                                        throughput of gfw_undistort_clip (the occupancy tail of one frame filled by the next). */
+                                        throughput of gfw_undistort_clip (the occupancy tail of one frame filled by the next).  Ignored by a
+                                        synchronous owner (GFW_OPT_FRAME_SYNC). */
+    GFW_OPT_FRAME_SYNC         = 10  /* 0 (default).  1: on a SYNCHRONOUS context (GFW_OPT_SYNCHRONOUS = 1, the reference's contract: opencl.rs:413) with
+                                        HIP_DEVICE buffers, "complete on return" is relaxed to "the FRAME is complete when its LAST plane's call returns":
+                                        the calls of the frame's earlier planes validate, are held (GFW_OPT_COALESCE_PLANES) and return at once, the last
+                                        plane's call launches the fused kernel and waits for it.  This is what the render loop needs — it consumes a
+                                        frame's planes only after all of its process_pixels calls (rendering/mod.rs:494-545) — but it is NOT what a caller
+                                        that reads plane 0 right after plane 0's call gets; hence opt-in, on every context of the frame. */
 };
 int   gfw_set_option(gfw_ctx *ctx, int option, int64_t value);
 /* Enqueues whatever gfw_undistort_image calls GFW_OPT_COALESCE_PLANES / _FRAMES are holding for a frame or launch this context belongs to

@@ -2,7 +2,7 @@
 (not only the oracle) to the reference's numbers without a GPU.
 
 What is built: the text libgfwarp.so embeds for hiprtc (tools/gen_jit_source.py: gfw_frame.hip + its headers), unedited except that its seven
-inline-asm statements (AMD mnemonics) become calls of same-named C functions; in front of it tests/emu/emu_prelude.h (what hiprtc's implicit
+inline-asm statements (AMD mnemonics; two of them empty optimisation barriers) become calls of same-named C functions; in front of it tests/emu/emu_prelude.h (what hiprtc's implicit
 HIP environment provides: vector types, threadIdx, __shared__, the handful of amdgcn builtins the source uses) and the clip's bake header
 (tests/_bake.py, the test-side restatement of gfw_api.hip's); behind it tests/emu/emu_driver.inc (the launch, lane by lane: 256 cooperative
 fibers per workgroup, rendezvous at __syncthreads and at wavefront fences).  Compiled as C++17 for x86-64 with -ffp-contract=off, like the
@@ -56,7 +56,7 @@ def guarded(data, at_end):
     return arr
 
 
-def kernel_source(top="gfw_frame.hip", n_asm=7):
+def kernel_source(top="gfw_frame.hip", n_asm=9):
     """`top` + the project headers it includes as one text (gen_jit_source.expand, without its typedef prelude: the host has <stdint.h>), asm -> emu_*()."""
     out = []
     G.expand(os.path.join(G.CSRC, top), set(), out)
@@ -74,7 +74,7 @@ def kernel_source(top="gfw_frame.hip", n_asm=7):
     return src
 
 
-def build(defs, header, top="gfw_frame.hip", n_asm=7, driver="emu_driver.inc", extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=1"), opt="-O1"):
+def build(defs, header, top="gfw_frame.hip", n_asm=9, driver="emu_driver.inc", extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=1"), opt="-O1"):
     """-> path of the host library for these template arguments (+ bake header) (cached under build/emu/ by content)."""
     if not CXX.endswith("clang++"):
         import pytest
@@ -96,6 +96,40 @@ def build(defs, header, top="gfw_frame.hip", n_asm=7, driver="emu_driver.inc", e
         os.replace(cpp, os.path.join(OUT, "emu_%s.cpp" % key))
         os.replace(tmp, so)
     return so
+
+
+def _A_derivs(rho):
+    """A(rho) = atan(sqrt rho) / sqrt rho and its first two derivatives (gfw_api.hip p1_A_derivs)"""
+    if rho < 1.0 / 64.0:
+        A = A1 = A2 = 0.0
+        pw = 1.0
+        for n in range(14):
+            A += pw / (2 * n + 1)
+            pw *= -rho
+        p1 = 1.0
+        for n in range(1, 14):
+            A1 += -float(n) / (2 * n + 1) * p1
+            p1 *= -rho
+        p2 = 1.0
+        for n in range(2, 14):
+            A2 += float(n) * (n - 1) / (2 * n + 1) * p2
+            p2 *= -rho
+        return A, A1, A2
+    r = math.sqrt(rho)
+    A = math.atan(r) / r
+    A1 = (1.0 / (1.0 + rho) - A) / (2.0 * rho)
+    A2 = (-1.0 / ((1.0 + rho) * (1.0 + rho)) - 3.0 * A1) / (2.0 * rho)
+    return A, A1, A2
+
+
+def s_derivs(rho, k):
+    """s(rho) = A P(w), w = rho A^2, and its first two derivatives (gfw_api.hip p1_s_derivs)"""
+    A, A1, A2 = _A_derivs(rho)
+    w, w1, w2 = rho * A * A, A / (1.0 + rho), A1 / (1.0 + rho) - A / ((1.0 + rho) * (1.0 + rho))
+    P = 1.0 + w * (k[0] + w * (k[1] + w * (k[2] + w * k[3])))
+    P1 = k[0] + w * (2.0 * k[1] + w * (3.0 * k[2] + w * 4.0 * k[3]))
+    P2 = 2.0 * k[1] + w * (6.0 * k[2] + w * 12.0 * k[3])
+    return A * P, A1 * P + A * P1 * w1, A2 * P + 2.0 * A1 * P1 * w1 + A * (P2 * w1 * w1 + P1 * w2)
 
 
 def p1_table(p0, matrices, matrix_count):
@@ -126,34 +160,50 @@ def p1_table(p0, matrices, matrix_count):
     h = rho_max / n
     s = [s_of(i * h) for i in range(n + 1)]
     tab = np.zeros((n + 1, 2), dtype=np.float32)
-    etab = smax = slope = 0.0
     for i in range(n):
         tab[i] = (s[i], s[i + 1] - s[i])
-        s_at = s[i]
-        for q in range(1, 9):
-            s_q = s[i + 1] if q == 8 else s_of((i + q / 8.0) * h)
-            if q < 8:
-                etab = max(etab, abs(float(tab[i, 0]) + q / 8.0 * float(tab[i, 1]) - s_q))
-            slope = max(slope, abs(s_q - s_at) * 8.0 / h)
-            s_at = s_q
-        smax = max(smax, abs(s[i]), abs(s[i + 1]))
     tab[n] = (s[n], 0.0)
-    kappa = 3.0
+    # derived bounds on s and its derivatives over [0, rho_max] (gfw_api.hip p1_prepare_table: the comment there has the derivation)
+    smax, slope, s2max, u1, u2, t32, kappa = 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 3.0
     if any(v != 0.0 for v in k):
-        tmax = math.atan(math.sqrt(rho_max))
+        wm = math.atan(math.sqrt(rho_max)) ** 2
+        a0, a1, a2, a3 = (abs(v) for v in k)
+        P0 = 1.0 + wm * (a0 + wm * (a1 + wm * (a2 + wm * a3)))
+        Pd1 = a0 + wm * (2.0 * a1 + wm * (3.0 * a2 + wm * 4.0 * a3))
+        Pd2 = 2.0 * a1 + wm * (6.0 * a2 + wm * 12.0 * a3)
+        Pd3 = 6.0 * a2 + wm * 24.0 * a3
+        L1 = P0 / 3.0 + Pd1
+        L2 = 0.4 * P0 + 2.0 * Pd1 + Pd2
+        L3 = (6.0 / 7.0) * P0 + 1.2 * Pd1 + (Pd2 + Pd1 * 4.0 / 3.0) + (Pd3 + 4.0 * Pd2 + Pd1 * 46.0 / 15.0)
+        ng = 4096
+        g = rho_max / ng
+        smax = 0.0
+        for i in range(ng):
+            ds, ds1, ds2 = s_derivs(i * g, k)
+            hi = (i + 1) * g
+            b0, b1, b2 = abs(ds) + g * L1, abs(ds1) + g * L2, abs(ds2) + g * L3
+            smax, slope, s2max = max(smax, b0), max(slope, b1), max(s2max, b2)
+            u1, u2, t32 = max(u1, math.sqrt(hi) * b1), max(u2, hi * b1), max(t32, hi * math.sqrt(hi) * b2)
+        slack = 1.0 + 1e-9
+        smax, slope, s2max, u1, u2, t32 = smax * slack, slope * slack, s2max * slack, u1 * slack, u2 * slack, t32 * slack
         rp, kp = 0.0, 1.0
+        gw = wm / 4096.0
         for i in range(4097):
-            t2 = (tmax * i / 4096.0) ** 2
+            t2 = gw * i
             t4 = t2 * t2
             t6, t8 = t4 * t2, t4 * t4
-            P = 1.0 + k[0] * t2 + k[1] * t4 + k[2] * t6 + k[3] * t8
-            Pabs = 1.0 + abs(k[0]) * t2 + abs(k[1]) * t4 + abs(k[2]) * t6 + abs(k[3]) * t8
-            dPabs = 2.0 * abs(k[0]) * t2 + 4.0 * abs(k[1]) * t4 + 6.0 * abs(k[2]) * t6 + 8.0 * abs(k[3]) * t8
-            if not abs(P) > 1e-3:
+            P = abs(1.0 + k[0] * t2 + k[1] * t4 + k[2] * t6 + k[3] * t8) - gw * Pd1
+            t2h = t2 + gw
+            t4h = t2h * t2h
+            t6h, t8h = t4h * t2h, t4h * t4h
+            Pabs = 1.0 + a0 * t2h + a1 * t4h + a2 * t6h + a3 * t8h
+            dPabs = 2.0 * a0 * t2h + 4.0 * a1 * t4h + 6.0 * a2 * t6h + 8.0 * a3 * t8h
+            if not P > 1e-3:
                 rp = kp = 1e30
                 break
-            rp, kp = max(rp, dPabs / abs(P)), max(kp, Pabs / abs(P))
+            rp, kp = max(rp, dPabs / P), max(kp, Pabs / P)
         kappa = 4.5 * rp + 4.0 * kp + 6.5
+    etab = h * h / 8.0 * s2max + (smax + h * slope) / 16777216.0
     f = abs(float(p0.f[0] if hrs else p0.f[1]))
     c = abs(float(p0.c[0] if hrs else p0.c[1]))
     rmax = math.sqrt(rho_max)
@@ -171,7 +221,8 @@ def p1_table(p0, matrices, matrix_count):
     eps = e0 + ew * 3.0 * pw / wden + em * 3.0 * max(px, py) / wden
     if matrix_count <= 1 or not eps < 0.2:
         return None
-    return tab, rho_max, float(np.float32(n / rho_max)), (float(np.float32(e0)), float(np.float32(ew)), float(np.float32(em)), float(eps))
+    lat = np.array([smax * (1.0 + 1e-6), u1 * (1.0 + 1e-6), u2 * (1.0 + 1e-6), t32 * (1.0 + 1e-6), 4.0 * u24 * vmag + 1.0 / 131072.0, 0.0], dtype=np.float32)
+    return tab, rho_max, float(np.float32(n / rho_max)), (float(np.float32(e0)), float(np.float32(ew)), float(np.float32(em)), float(eps)), lat
 
 
 SAMPLE_KIND = {"Luma8": (1, 1), "Luma16": (2, 1), "RGB8": (1, 3), "RGBA8": (1, 4), "BGRA8": (1, 4), "RGB16": (2, 3), "RGBA16": (2, 4), "AYUV16": (2, 4),
@@ -322,7 +373,7 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=F
     small = len(frames) * p0.output_width * p0.output_height < 400000              # small launches: an unoptimised build compiles faster than it runs slower
     lib = C.CDLL(build(defs, header, opt="-O0" if small else "-O1", extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=%d" % (1 if baked else 0), "-DEMU_VOTES=%d" % votes, "-DEMU_HW_ULP=%d" % hw_ulp, "-DEMU_AUDIT=%d" % (1 if audit else 0))))
     lib.gfw_emu_launch.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
-                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     n = len(frames)
     pints, pfloats = np.zeros(24, np.int32), np.zeros(20, np.float32)        # the plane descriptors of the argument block (build_yuv_args); [16..23]: declared lengths
     for i, pl in enumerate(fr0.planes):
@@ -360,7 +411,8 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=F
         com.mesh, com.mesh_len = mesh.ctypes.data, mesh.size
     kp = fr0.planes[0]["params"]
     rc = lib.gfw_emu_launch(n, srcs, dsts, mats, tab.ctypes.data, p1[1] if fast1 else 0.0, p1[2] if fast1 else 0.0, *(p1[3][:3] if fast1 else (0.0, 0.0, 0.0)),
-                            C.cast(C.byref(kp), C.c_void_p), C.cast(C.byref(com), C.c_void_p), grid, pints.ctypes.data, pfloats.ctypes.data)
+                            C.cast(C.byref(kp), C.c_void_p), C.cast(C.byref(com), C.c_void_p), grid, pints.ctypes.data, pfloats.ctypes.data,
+                            p1[4].ctypes.data if fast1 else None)
     assert rc == 0, "gfw_emu_launch -> %d" % rc
     if audit:
         words = (C.c_ulonglong * 8)()

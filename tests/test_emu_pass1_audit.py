@@ -31,7 +31,8 @@ def test_every_certificate_of_a_random_clip(seed):
         pytest.skip("no certified first pass for this clip (E >= 0.2 px or a single matrix)")
     outs, a = _emu.run_frames([fr], audit=True)
     assert a["wrong"] == 0 and a["queue_overflow"] == 0 and a["out_of_range"] == 0, a
-    assert a["certified"] > 0 and a["gap_px"] < 0.5 * a["eps_px"], a
+    # (the bound itself: the lattice form of round 5 spends part of E on the interpolation's curvature, so the measured gap is no longer a small fraction of it)
+    assert a["certified"] > 0 and a["gap_px"] < a["eps_px"], a
     assert all(np.array_equal(x, y) for x, y in zip(O.run_frame(fr), outs[0]))
 
 

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 class PlaneLoop:
     """What the render loop holds per plane: a backend object (context) of its own; `frame()` issues the per-plane calls of one frame in order."""
 
-    def __init__(self, frames, device_matrices=True, jit=0, frames_per_launch=1, shared_stream=False, synchronous=False):
+    def __init__(self, frames, device_matrices=True, jit=0, frames_per_launch=1, shared_stream=False, synchronous=False, coalesce=2, own_streams=False, frame_sync=False):
         import torch
         self.torch, self.dev = torch, torch.device("cuda", 0)
         assert abi.load_library().gfw_set_device(0) == 0
@@ -33,11 +33,17 @@ class PlaneLoop:
         self.be = []
         stream = torch.cuda.Stream(self.dev) if shared_stream else None
         self.stream = stream
+        self.streams = [torch.cuda.Stream(self.dev) for _ in fr0.planes] if own_streams else None      # a caller-owned stream per plane context (the decoder's, say)
         for p, pl in enumerate(fr0.planes):
             be = warp.Backend(pl["params"], pl["pixel_type"], fr0.model, fr0.digital, self.bufs[0][p])
             if stream is not None:
                 be.set_stream(stream.cuda_stream)
+            if self.streams is not None:
+                be.set_stream(self.streams[p].cuda_stream)
             be.set_option(abi.OPT_SYNCHRONOUS, 1 if synchronous else 0)
+            be.set_option(abi.OPT_COALESCE_PLANES, coalesce)        # (2: held from the first frame on — what these tests were written against; 1 = the default: test below)
+            if frame_sync:
+                be.set_option(abi.OPT_FRAME_SYNC, 1)
             if device_matrices:
                 be.set_option(abi.OPT_MATRICES_ON_DEVICE, 2)
             be.set_option(abi.OPT_JIT, jit)
@@ -182,5 +188,116 @@ def test_option_off_restores_the_per_plane_launches():
         for be in loop.be:
             be.synchronize()
         loop.check(0, "coalescing off")
+    finally:
+        loop.close()
+
+
+def test_default_holds_only_contexts_seen_as_planes_of_a_multi_plane_frame():
+    """GFW_OPT_COALESCE_PLANES = 1 (the default): the first frame of a clip leaves plane by plane — nothing has shown yet that these contexts are planes of one
+    frame — and marks them; from the second frame on the calls are held and leave fused.  A lone luma context (greyscale) is never held: its call launches."""
+    loop = PlaneLoop(clip("YUV422P16LE", 320, 192, 3), coalesce=1)
+    try:
+        loop.frame(0)
+        names = [warp.Backend.last_backend_of(be) for be in loop.be]
+        assert "held_for_frame" not in names and names[1] == names[2] == "plane_generic", names
+        for j in (1, 2):
+            loop.frame(j, planes=(0, 1))
+            assert warp.Backend.last_backend_of(loop.be[1]) == "held_for_frame"
+            loop.frame(j, planes=(2,))
+            names = [warp.Backend.last_backend_of(be) for be in loop.be]
+            assert all(n.startswith("yuv_fused") for n in names), names
+        loop.be[1].synchronize()
+        for j in range(3):
+            loop.check(j, "default option")
+    finally:
+        loop.close()
+    grey = PlaneLoop([S.SyntheticFrame("YUV422P16LE", 320, 192, seed=0xC0A1 + j) for j in range(3)], coalesce=1)
+    try:
+        for j in range(3):
+            grey.frame(j, planes=(0,))                   # one context, plane_index 0, again and again: never a multi-plane pattern
+            assert warp.Backend.last_backend_of(grey.be[0]) != "held_for_frame"
+        import torch
+        torch.cuda.current_stream().synchronize()
+        torch.cuda.synchronize()                         # raw device synchronisation, no gfw call: the planes must be there
+        for j in range(3):
+            fr = grey.frames[j]
+            ref = O.run_frame(_View(fr, [t.cpu().numpy() for t in grey.d_src[j]]))
+            assert_plane_equal(ref[0], grey.outputs(j)[0], "Luma16", "greyscale frame %d" % j)
+    finally:
+        grey.close()
+
+
+def test_the_fused_launch_waits_for_work_queued_on_a_member_contexts_stream():
+    """Input-side ordering: each plane context has its caller's stream; the U plane's pixels are UPLOADED on the U context's stream right before
+    its call, behind a long-running kernel.  The fused launch runs on the Y context's stream: it must wait for the U stream's pending work, else it reads the
+    plane before the upload lands."""
+    import torch
+    loop = PlaneLoop(clip("YUV422P16LE", 640, 360, 2), own_streams=True)
+    try:
+        for j in range(2):
+            good = [t.clone() for t in loop.d_src[j]]
+            for p in (1, 2):
+                loop.d_src[j][p].fill_(0x11)             # stale content
+            torch.cuda.synchronize()
+            for p in (1, 2):
+                with torch.cuda.stream(loop.streams[p]):
+                    torch.cuda._sleep(40_000_000)        # ~20 ms of GPU time ahead of the upload on this plane's stream
+                    loop.d_src[j][p].copy_(good[p], non_blocking=True)
+            loop.frame(j)
+            loop.be[0].synchronize()
+            torch.cuda.synchronize()
+            loop.check(j, "member-stream upload")
+    finally:
+        loop.close()
+
+
+def test_frames_with_their_own_parameters_do_not_share_a_clip_launch():
+    """GFW_OPT_COALESCE_FRAMES > 1 with per-call parameters that move from frame to frame (dynamic zoom: fov; a keyframed lens correction is the same
+    mechanism): a launch shares ONE parameter block, so a frame whose block differs must not join it — every frame matches the oracle fed
+    ITS parameters."""
+    n = 6
+    frames = [S.SyntheticFrame("YUV422P16LE", 384, 208, seed=0xC0A1 + j, timestamp_ms=1000.0 + 33.3 * j, fov=1.0 + 0.05 * (j // 2), base_overrides={"lens_correction_amount": 0.8}) for j in range(n)]
+    loop = PlaneLoop(frames, jit=2, frames_per_launch=4)
+    try:
+        for j in range(n):
+            loop.frame(j)
+        loop.be[1].synchronize()
+        for j in range(n):
+            loop.check(j, "per-frame fov")
+    finally:
+        loop.close()
+
+
+def test_frame_sync_holds_the_planes_of_synchronous_contexts_until_the_last():
+    """GFW_OPT_FRAME_SYNC: synchronous contexts (the reference's contract) whose caller consumes a frame only after its last plane's call: the earlier planes
+    are held, the last plane's call launches the fused kernel and returns when the frame is complete — no synchronize call afterwards."""
+    loop = PlaneLoop(clip("YUV422P16LE", 640, 360, 3), synchronous=True, frame_sync=True)
+    try:
+        for j in range(3):
+            loop.frame(j, planes=(0, 1))
+            assert warp.Backend.last_backend_of(loop.be[1]) == "held_for_frame"
+            loop.frame(j, planes=(2,))
+            names = [warp.Backend.last_backend_of(be) for be in loop.be]
+            assert all(n.startswith("yuv_fused") for n in names), names
+            loop.check(j, "frame sync")                  # straight after the last plane's call
+    finally:
+        loop.close()
+
+
+def test_get_stream_sends_held_planes_on_their_way():
+    """A consumer that orders itself behind the context's stream (an event, a synchronise of the raw stream) asks for the stream first: gfw_get_stream flushes."""
+    import torch
+    loop = PlaneLoop(clip("YUV422P16LE", 320, 192, 1))
+    try:
+        loop.frame(0, planes=(0, 1))
+        assert warp.Backend.last_backend_of(loop.be[1]) == "held_for_frame"
+        assert loop.be[1].get_stream() is not None
+        assert warp.Backend.last_backend_of(loop.be[1]) != "held_for_frame"
+        torch.cuda.synchronize()
+        fr = loop.frames[0]
+        ref = O.run_frame(_View(fr, [t.cpu().numpy() for t in loop.d_src[0]]))
+        out = loop.outputs(0)
+        for p in (0, 1):
+            assert_plane_equal(ref[p], out[p], fr.planes[p]["pixel_type"], "after gfw_get_stream, plane %d" % p)
     finally:
         loop.close()

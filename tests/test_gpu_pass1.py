@@ -47,7 +47,13 @@ def test_certificates_never_disagree_with_the_exact_row(seed, size):
     total = size[0] * size[1]
     assert certified + queued + overflow == total
     assert wrong == 0
+    assert gap < LAST_FULL["pass1_eps_px"], "approximation gap %g px exceeds the certificate half-width %g" % (gap, LAST_FULL["pass1_eps_px"])
+    # the per-pixel form (rounds 2-4) keeps its margin: the gap is rounding noise, far inside even the floor of E
+    (certified, wrong, queued, overflow, gap), outs2 = audit(fr, variant=4)
+    assert certified + queued + overflow == total and wrong == 0
     assert gap < 0.5 * eps_of(fr), "approximation gap %g px is not well inside the certificate half-width" % gap
+    for a, b in zip(outs, outs2):
+        assert np.array_equal(a, b)
     assert queued + overflow < 0.15 * total, "certificate rejects too many pixels: %d of %d" % (queued + overflow, total)
     ref = O.run_frame(fr)
     for a, b in zip(ref, outs):
@@ -106,13 +112,13 @@ def test_the_kernel_widens_the_certificate_for_a_matrix_with_cancellation():
     beyond the lens-only bound of rounds 2-3."""
     from test_emu_pass1_audit import shifted_frame
     fr = shifted_frame(3e4, w=1280, h=720)
-    be_audit, outs = audit(fr)
+    be_audit, outs = audit(fr, variant=4)          # (the per-pixel form: its gap is rounding noise alone; the lattice form's includes the interpolation's)
     certified, wrong, queued, overflow, gap = be_audit
     assert wrong == 0 and certified > 0
     eps_shifted = LAST_FULL["pass1_eps_px"]
     assert gap < eps_shifted
     plain = S.SyntheticFrame("YUV422P16LE", 1280, 720, seed=3)
-    (_, _, _, _, gap_plain), _ = audit(plain)
+    (_, _, _, _, gap_plain), _ = audit(plain, variant=4)
     assert gap > 5.0 * gap_plain and eps_shifted > 3.0 * LAST_FULL["pass1_eps_px"]
     ref = O.run_frame(fr)
     for a, b in zip(ref, outs):
@@ -120,6 +126,11 @@ def test_the_kernel_widens_the_certificate_for_a_matrix_with_cancellation():
     # device-resident matrices: the host has no view of them, the kernel's own E decides
     got = warp.run_frame(fr)
     for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    # the lattice form on the same frame: a wider E, every certificate still right
+    (certified, wrong, queued, overflow, gap), outs3 = audit(fr)
+    assert wrong == 0 and certified > 0 and gap < LAST_FULL["pass1_eps_px"]
+    for a, b in zip(ref, outs3):
         assert np.array_equal(a, b)
     fr = shifted_frame(3e5, w=1280, h=720)
     (certified, wrong, queued, overflow, gap), outs = audit(fr)

@@ -85,7 +85,7 @@ def test_two_hundred_random_clips_never_produce_a_wrong_certificate():
         served += 1
         assert a["certified1_wrong"] == 0 and a["out_of_range"] == 0, (i, w, h, a)
         assert a["certified1"] + a["queued1"] + a["queue_overflow"] == w * h, (i, a)
-        assert a["pass1_eps_px"] > 0.0 and a["pass1_gap_px"] < 0.5 * a["pass1_eps_px"], (i, w, h, a)
+        assert a["pass1_eps_px"] > 0.0 and a["pass1_gap_px"] < a["pass1_eps_px"], (i, w, h, a)      # (E is a bound; the lattice form of round 5 spends part of it on the interpolation's curvature)
         worst_ratio = max(worst_ratio, a["pass1_gap_px"] / a["pass1_eps_px"])
         pixels += w * h
         certified += a["certified1"]

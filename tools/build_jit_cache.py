@@ -78,8 +78,8 @@ def main():
         if "--list" in sys.argv:
             print("%-36s %s %s" % (label, name, "present" if os.path.exists(path) else "missing"))
             continue
-        if os.path.exists(path):
-            continue
+        if os.path.exists(path) and os.path.getsize(path) > 64 and open(path, "rb").read(4) == b"\x7fELF":
+            continue                                    # (anything else under that name — a file cut short — is rebuilt; the library writes through a temporary name)
         log = C.create_string_buffer(1 << 16)
         n = lib.gfw_debug_jit_compile(ARCH, defs, header, path.encode(), log, len(log))
         if n == -2:
@@ -91,7 +91,7 @@ def main():
     # kernels of other sources / options: stale entries would never be found again (the name hashes the source), so they only cost space
     keep = {key_of(lib, bench_frame(**kw))[2] for _, kw in CONFIGS}
     for f in os.listdir(OUT):
-        if f.endswith(".co") and f not in keep:
+        if (f.endswith(".co") and f not in keep) or ".co.tmp" in f:
             os.remove(os.path.join(OUT, f))
     if "--list" not in sys.argv:
         print("jit_cache: %d kernels (%d built now)" % (len(keep), built))
