@@ -88,7 +88,7 @@
 #define GFW_TAP_ROW_UNROLL(I, T) ((I) == 4 ? 4 : (sizeof(T) == 1 ? 4 : 2))
 #endif
 #ifndef GFW_ROW_CLUSTER
-#define GFW_ROW_CLUSTER 0       // experiment queued for round 5 (tools/r05_first_call.sh; bit-exact on the host interpreter): the luma pair's and the chroma site's taps of a
+#define GFW_ROW_CLUSTER 0       // measured in round 5 (46.4 = 46.4 us; with the row's stores held back behind the NEXT row's matrix fetches 44.3 against 42.3: profiles/r05_ab_ablations.txt): the luma pair's and the chroma site's taps of a
                                  // 4:2:2 / 4:4:4 planar lane-row fetched in ONE cluster, stores last (the luma store between them is an aliasing barrier: the row waits twice)
 #endif
 #ifndef GFW_P1_LATTICE
@@ -228,14 +228,17 @@ __device__ __forceinline__ float map_c(float x, float mul, float den, float rcp)
 // The chroma plane's source_rect map of a coordinate x whose luma map l = map_c(x, mul_l, den, rcp) is already known (baked builds: the
 // multipliers are literals, the branches fold).  Same multiplier (4:2:2's rows, 4:4:4): the same operations, l itself.  Half the
 // multiplier (a subsampled axis): every operation of map_c scales exactly by 1/2 — power-of-two scaling commutes with round-to-nearest
-// while nothing underflows — so the result is l/2; coordinates below 2^-100 (where the residual of the division could go subnormal)
-// send the whole wave through the full evaluation.
+// while nothing underflows — so the result is l/2; coordinates below 2^-100 (where the residual of the division could go subnormal) land in
+// the same bins either way (below).
 template <bool INF_SAFE>
 __device__ __forceinline__ float chroma_from_luma(float l, float x, float mul_c, float mul_l, float den, float rcp) {
     if (mul_c == mul_l) return l;
     if (2.0f * mul_c == mul_l) {
-        const bool tiny = fabsf(l) < 0x1p-100f && l != 0.0f;
-        if (__builtin_expect(!gfw_any(tiny), 1)) return 0.5f * l;
+        // Every consumer of a chroma coordinate bins it first: round((c - OFFSET) * 32), OFFSET 0 / 1 / 3 (raw_bin, make_bins2).  Where the halving is exact — all but
+        // |l| < 2^-100, whose residual could go subnormal — l/2 IS the map's value.  Below 2^-100 both l/2 and the map's own value are below 2^-100 in magnitude, and
+        // every bin computed from such a coordinate is the same: 32 c rounds to 0, c - OFFSET is -OFFSET exactly.  (Round 4 sent the whole wave through the full
+        // evaluation on a tiny lane: a compare, a select and the map itself, twelve instructions per lane-row for a case that changes nothing.)
+        return 0.5f * l;
     }
     return map_c<INF_SAFE>(x, mul_c, den, rcp);
 }
@@ -759,9 +762,11 @@ template <typename T, int N>
 __device__ __forceinline__ void taps_inside2(const uint8_t *src, int off0, int stride, const Bins2 &b, float limit, float *out) {
     // all four taps inside: off0 >= 0 and the plane is < 2 GiB (host-checked), so both rows are zero-extended 32-bit lane offsets on the
     // uniform plane base — the saddr + voffset form of global_load, one address instruction per row instead of a 64-bit add chain
-    const T *row0 = reinterpret_cast<const T *>(src + (uint32_t)off0);
+    // (the two taps of a 16-bit row as the ALIGNED dwordx2 around them + v_alignbit — the form the bicubic / Lanczos4 rows need — measured 42.3 = 42.4 us per C2 frame:
+    //  neighbouring lanes' fetches coalesce either way; profiles/r05_c2_memory_path.txt)
     uint32_t off1 = (uint32_t)off0 + (uint32_t)stride;
     asm("" : "+v"(off1));             // opaque: keeps the second row a 32-bit lane offset too (a pitch beyond the 12-bit immediate otherwise becomes a 64-bit add chain)
+    const T *row0 = reinterpret_cast<const T *>(src + (uint32_t)off0);
     const T *row1 = reinterpret_cast<const T *>(src + off1);
     #pragma unroll
     for (int c = 0; c < N; ++c) {
@@ -1149,7 +1154,10 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     constexpr bool INF_COORDS = MODEL != GFW_MODEL_OPENCV_FISHEYE || GFW_BAKED_DIGITAL;
     __shared__ float q_x[FAST1 ? 4 : 1][FAST1 ? QCAP : 1], q_y[FAST1 ? 4 : 1][FAST1 ? QCAP : 1];
     __shared__ unsigned short q_dst[FAST1 ? 4 : 1][FAST1 ? QCAP : 1];           // (owner lane << 6) | slot in s_rows
-    __shared__ unsigned short s_rows[RB * NPX][256];                             // phase-1 rows (< 65536: the host keeps larger frames off this path), one column per lane
+    // phase-1 rows, already clamped to the matrix table (min(sy, matrix_count - 1): cpu_undistort.rs:482; < 65536: the host keeps larger frames off this path): per luma row
+    // of the tile and lane the lane's DW horizontally adjacent pixels side by side — a pair leaves and arrives as one dword
+    __shared__ unsigned short s_rows[RB * DH][256][DW];
+    auto srow = [&](int slot, int t) -> unsigned short & { return s_rows[slot / DW][t][slot % DW]; };      // slot = r * NPX + j * DW + i (the queue's numbering)
     __shared__ float s_lut[I == 2 ? 1 : 448];                                    // bicubic / Lanczos4 tap table
     __shared__ float4 s_p1[FAST1 ? GFW_CLIP_MAX : 1];                            // per frame of the launch: certificate half-width E, W threshold, (lattice form) rho limit of a node
     // the lattice form of the first pass: a wave's nodes sit on every 8th luma column of its 64 * DW columns (both ends: NXN per row) in its first and its last luma row
@@ -1342,10 +1350,29 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         auto flush_queue = [&](bool last) {
             if (last || n_q + 64u * QSTEP > (unsigned)QCAP) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // the entries the other lanes wrote
-                for (unsigned e = lane; e < n_q; e += 64) {
-                    const int sy = pass1_exact<MODEL>(q_x[wave][e], q_y[wave][e], M, matrices, L, A);
-                    const unsigned d = q_dst[wave][e];
-                    s_rows[d & 63u][wave * 64 + (d >> 6)] = (unsigned short)sy;
+                const int row_top = AF(matrix_count) - 1;
+                if constexpr (GFW_FASTROW && MODEL == GFW_MODEL_OPENCV_FISHEYE && !AUDIT && !GFW_BAKED_DIGITAL) {
+                    // the branch-free projection of phase 3 with the mid-row matrix (round 5): rounds of 64 entries in uniform control flow (its votes ask the wave), the
+                    // odd lane — operands outside what the lean sequence is proven for — through pass1_exact itself.  (pass1_exact for all: ~220 issue slots per
+                    // round with its divergent branches; this: ~120.)
+                    for (unsigned e0 = 0; e0 < n_q; e0 += 64) {
+                        const unsigned e = e0 + (unsigned)lane;
+                        const bool act = e < n_q;
+                        const float ox = q_x[wave][act ? e : 0u], oy = q_y[wave][act ? e : 0u];
+                        const float4 ma{M.m0, M.m1, M.m2, M.m3}, mb{M.m4, M.m5, M.m6, M.m7};
+                        float pu, pv; bool odd;
+                        rd_lean_nobranch<1>(&ox, &oy, &ma, &mb, &M.m8, L, A, &pu, &pv, &odd);
+                        const int lim = AF(hrs) ? AF(width) : AF(height);
+                        int sy = max(min(round_i32(AF(hrs) ? pu : pv), lim), 0);
+                        if (__builtin_expect(gfw_any(odd & act), 0)) { if (odd & act) sy = pass1_exact<MODEL>(ox, oy, M, matrices, L, A); }
+                        if (act) { const unsigned d = q_dst[wave][e]; srow((int)(d & 63u), wave * 64 + (int)(d >> 6)) = (unsigned short)min(sy, row_top); }
+                    }
+                } else {
+                    for (unsigned e = lane; e < n_q; e += 64) {
+                        const int sy = pass1_exact<MODEL>(q_x[wave][e], q_y[wave][e], M, matrices, L, A);
+                        const unsigned d = q_dst[wave][e];
+                        srow((int)(d & 63u), wave * 64 + (int)(d >> 6)) = (unsigned short)min(sy, row_top);
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 n_q = 0;
@@ -1410,15 +1437,17 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     const int lx = cx * DW + i;
                     const bool live = WHOLE || (lane_ok && lx < AF(out_w) && ly < AF(out_h));
                     if (!WHOLE) good[i] = good[i] | gfw_lanes(!live);
-                    s_rows[r * NPX + j * DW + i][tid] = (unsigned short)(live ? sy[i] : 0);
+                    sy[i] = live ? min(sy[i], AF(matrix_count) - 1) : 0;
+                    if constexpr (DW != 2) s_rows[q][tid][i] = (unsigned short)sy[i];
                     if (AUDIT && gfw_vote_lane(good[i], lane) && live) {           // audit: every certificate is checked
                         const float ox = (float)lx + L.t2x;
                         atomicAdd(&AF(audit)[0], 1ull);
-                        if (pass1_exact<MODEL>(ox, oy, M, matrices, L, A) != sy[i]) atomicAdd(&AF(audit)[1], 1ull);
+                        if (min(pass1_exact<MODEL>(ox, oy, M, matrices, L, A), AF(matrix_count) - 1) != sy[i]) atomicAdd(&AF(audit)[1], 1ull);
                         const GfwPt ex = rd<MODEL>(ox, oy, float4{M.m0, M.m1, M.m2, M.m3}, float4{M.m4, M.m5, M.m6, M.m7}, M.m8, matrices + (size_t)(AF(matrix_count) / 2) * GFW_MAT_STRIDE + 8, L, A);
                         if (ex.ok) atomicMax(&AF(audit)[4], (unsigned long long)gfw_f2u(fabsf((hrs ? ex.x : ex.y) - v_fast[i])));
                     }
                 }
+                if constexpr (DW == 2) *reinterpret_cast<uint32_t *>(&s_rows[q][tid][0]) = (uint32_t)sy[0] | ((uint32_t)sy[1] << 16);       // the pair as one dword
                 unsigned long long undecided[DW], any_und = 0ull;
                 #pragma unroll
                 for (int i = 0; i < DW; ++i) { undecided[i] = gfw_vote_failed(good[i]); any_und |= undecided[i]; }
@@ -1450,7 +1479,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                         if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (AF(extras) & 8)) gfw_lens_correction_blend<(MODEL == GFW_MODEL_GENERIC_EXTRA ? -1 : MODEL)>(ox, oy, A.kp, A.common, AF(model), GFW_CLIP_DIGITAL);   // :429-460
                         sy = pass1_exact<MODEL>(ox, oy, M, matrices, L, A);
                     }
-                    s_rows[r * NPX + k][tid] = (unsigned short)(live ? sy : 0);
+                    srow(r * NPX + k, tid) = (unsigned short)(live ? min(sy, AF(matrix_count) - 1) : 0);
                 }
             }
         }
@@ -1490,7 +1519,9 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                 // rd_lean_nobranch, mapped and binned without a divergent branch; the wave is asked ONCE per stage — `__any(rare)` sends the odd lanes
                 // through rd<> itself, `__all(interior)` picks between the branch-free taps (pair stored as one word) and sample_store2.
                 constexpr bool FASTROW = GFW_FASTROW && MODEL == GFW_MODEL_OPENCV_FISHEYE && N0 == 1 && !AUDIT && !GFW_BAKED_DIGITAL;
-                const bool fastrow = FASTROW && !AF(ablate) && !AF(hstretch_div) && !AF(vstretch_div) && !AF(rot_on);       // (a stretched or rotated clip: the per-pixel path)
+                // (timing ablations, wrong output by design — baked builds only, GFW_ABLATE_FORCE: 1 no first pass, 2 no luma taps (the store stays), 4 no chroma, 8 no projection,
+                //  16 no luma store, 32 every pixel's matrix = the mid row's (no per-lane matrix fetch); the ahead-of-time kernels' ablations (option 16 + bits) take the per-pixel path)
+                const bool fastrow = FASTROW && (GFW_BAKE || !AF(ablate)) && !AF(hstretch_div) && !AF(vstretch_div) && !AF(rot_on);       // (a stretched or rotated clip: the per-pixel path)
                 if (fastrow) {
                     #pragma unroll (NPX <= 2 ? DH : 1)
                     for (int j = 0; j < DH; ++j) {
@@ -1499,16 +1530,32 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                         GfwVote okp[DW];                 // which lanes hold a valid point: a wave mask in scalar registers (a per-lane bool would live in a VGPR across the vote below)
                         {
                             float ox[DW], oy[DW], m8[DW]; float4 ma[DW], mb[DW];
+                            uint32_t rows2 = 0u;                  // the pair's two rows, one dword (already clamped to the table)
+                            if constexpr (DW == 2) if (two_pass) rows2 = *reinterpret_cast<const uint32_t *>(&s_rows[r * DH + j][tid][0]);
+                            int row[DW];
                             #pragma unroll
                             for (int i = 0; i < DW; ++i) {
                                 const int lx = cx * DW + i;
                                 ox[i] = (float)lx + L.t2x; oy[i] = (float)ly + L.t2y;
-                                const int sy = two_pass ? s_rows[r * NPX + j * DW + i][tid] : default_row<MODEL>(ox[i], oy[i], A);
-                                const int row = min(sy, AF(matrix_count) - 1);
-                                const float *m = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(matrices) + (uint32_t)row * (uint32_t)(GFW_MAT_STRIDE * sizeof(float)));
+                                row[i] = two_pass ? (DW == 2 ? (int)(i == 0 ? (rows2 & 0xffffu) : (rows2 >> 16)) : (int)s_rows[r * DH + j][tid][i])
+                                                  : min(default_row<MODEL>(ox[i], oy[i], A), AF(matrix_count) - 1);
+                            }
+                            // (the rows of a lane-row through a 16-row LDS window — one cooperative dwordx4 instead of these six fetches — measured 42.3 = 42.3 us per C2
+                            //  frame with 27 % fewer L1 accesses: profiles/r05_c2_memory_path.txt; not kept)
+                            #pragma unroll
+                            for (int i = 0; i < DW; ++i) {
+                                const float *m = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(matrices) + (uint32_t)row[i] * (uint32_t)(GFW_MAT_STRIDE * sizeof(float)));
                                 ma[i] = *reinterpret_cast<const float4 *>(m); mb[i] = *reinterpret_cast<const float4 *>(m + 4); m8[i] = m[8];
                             }
+                            if (GFW_BAKE && (AF(ablate) & 32)) {
+                                #pragma unroll
+                                for (int i = 0; i < DW; ++i) { ma[i] = float4{M.m0, M.m1, M.m2, M.m3}; mb[i] = float4{M.m4, M.m5, M.m6, M.m7}; m8[i] = M.m8; }
+                            }
                             rd_lean_nobranch<DW>(ox, oy, ma, mb, m8, L, A, pu, pv, odd);         // (the pair side by side or one after the other: 46.2 = 46.4 us)
+                            if (GFW_BAKE && (AF(ablate) & 8)) {
+                                #pragma unroll
+                                for (int i = 0; i < DW; ++i) { pu[i] = ox[i] * 0.5f; pv[i] = oy[i] * 0.5f; odd[i] = false; }
+                            }
                             #pragma unroll
                             for (int i = 0; i < DW; ++i) { okp[i] = GFW_VOTE_ALL; any_odd = any_odd | odd[i]; }
                         }
@@ -1519,8 +1566,8 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                                 if (odd[i]) {
                                     const int lx = cx * DW + i;
                                     const float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
-                                    const int sy = two_pass ? s_rows[r * NPX + j * DW + i][tid] : default_row<MODEL>(ox, oy, A);
-                                    const GfwPt p = rd_row<MODEL>(ox, oy, min(sy, AF(matrix_count) - 1), matrices, L, A);
+                                    const int row = two_pass ? (int)s_rows[r * DH + j][tid][i] : min(default_row<MODEL>(ox, oy, A), AF(matrix_count) - 1);
+                                    const GfwPt p = rd_row<MODEL>(ox, oy, row, matrices, L, A);
                                     pu[i] = p.x; pv[i] = p.y; ok_i = p.ok;
                                 }
                                 okp[i] = gfw_vote_select(okp[i], gfw_lanes(odd[i]), gfw_lanes(ok_i));
@@ -1577,11 +1624,13 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                             uint32_t val[DW];
                             #pragma unroll
                             for (int i = 0; i < DW; ++i) {
-                                if constexpr (I == 2) val[i] = inside_value1<T>(PL0.src, PL0.src_stride, bins2_of(bx[i], by[i]), bg_y, lim_y);
+                                if (GFW_BAKE && (AF(ablate) & 2)) val[i] = (uint32_t)(bx[i] ^ by[i]) & 0xffu;
+                                else if constexpr (I == 2) val[i] = inside_value1<T>(PL0.src, PL0.src_stride, bins2_of(bx[i], by[i]), bg_y, lim_y);
                                 else val[i] = inside_value1_lut<T, I>(PL0.src, PL0.src_stride, bx[i], by[i], bg_y, lim_y, s_lut);
                             }
                             const int doff = row_off(ly, PL0.dst_stride) + (cx * DW) * (int)sizeof(T);
-                            if constexpr (DW == 2) store_pair1<T>(PL0.dst, doff, val[0], val[1]);
+                            if (GFW_BAKE && (AF(ablate) & 16)) { if (lane == 99 && val[0] == 0x12345u) PL0.dst[0] = 1; }
+                            else if constexpr (DW == 2) store_pair1<T>(PL0.dst, doff, val[0], val[1]);
                             else store_value1<T>(PL0.dst, doff, val[0]);
                         } else {
                             #pragma unroll
@@ -1602,7 +1651,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     if (!WHOLE && (lx >= AF(out_w) || ly >= AF(out_h))) continue;
                     float ox = (float)lx + L.t2x, oy = (float)ly + L.t2y;
                     if (MODEL != GFW_MODEL_OPENCV_FISHEYE && (AF(extras) & 8)) gfw_lens_correction_blend<(MODEL == GFW_MODEL_GENERIC_EXTRA ? -1 : MODEL)>(ox, oy, A.kp, A.common, AF(model), GFW_CLIP_DIGITAL);       // :429-460
-                    const int sy = two_pass ? s_rows[r * NPX + k][tid] : default_row<MODEL>(ox, oy, A);
+                    const int sy = two_pass ? (int)srow(r * NPX + k, tid) : default_row<MODEL>(ox, oy, A);      // (two_pass: already clamped to the table; the min below is then idle)
                     GfwPt p;
                     if (AF(ablate) & 8) { p.x = ox * 0.5f; p.y = oy * 0.5f; p.ok = true; }              // timing ablation only
                     else {
