@@ -51,7 +51,7 @@ N_RESIDENT = 64                  # distinct source frames + per-row matrix table
 CLIP_FRAMES = 16                 # most frames gfw_undistort_clip puts into one launch (GFW_CLIP_FRAMES_MAX)
 N_DST = 8                        # destination frame sets written round-robin (the frames of one clip launch are in flight together: one set each)
 N_CHECK = 3                      # frames of the timed region compared with the oracle afterwards
-TRAFFIC_FILE = os.path.join("profiles", "r04_c2_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r05_c2_traffic.json")       # rocprofv3 PMC passes of the C2 workload; names the kernel source it was taken on (abi.kernel_source_id)
 
 
 # coefficient sets of the other physical lens models (the ones tests/test_gpu_lens_models.py runs), for --lens-model
@@ -95,6 +95,11 @@ def parse_args(argv):
     ap.add_argument("--c5", action="store_true", help="C5: a --frames long 4K clip dealt round-robin to the ranks (strong scaling); per-row "
                                                       "matrices built on the device per frame; per-frame checksums all-gathered")
     ap.add_argument("--frames", type=int, default=10000, help="--c5: frames in the clip")
+    ap.add_argument("--sum-stream", type=int, default=0, choices=(0, 1),
+                    help="--c5: 0 (default) the per-frame checksums in order on the warp's stream; 1: on a stream of their own, beside the warp of the next launch (two groups of "
+                         "destination sets ordered by events, one wave slot per SIMD left free for them) — built in round 5 to take the verification off the critical path and "
+                         "measured SLOWER: 70.2 against 53.3 us per frame (the 66 MB reads of eight checksums beside a launch slow its warp from 42 to 50 us per frame and "
+                         "the event chain serialises the rest: profiles/r05_bench_c5.txt)")
     ap.add_argument("--host-buffers", action="store_true",
                     help="PCIe-inclusive run: source and destination planes live in host memory (BufferSource::Cpu), every "
                          "call stages H2D, warps, copies D2H and synchronises — never the headline value")
@@ -114,6 +119,9 @@ def parse_args(argv):
                     help="the reference's own call sequence: one gfw_undistort_image per plane, each plane through a backend object (context) of its own "
                          "(rendering/mod.rs:494-545), asynchronous device buffers — GFW_OPT_COALESCE_PLANES turns the calls of a frame into one fused launch; "
                          "--clip N holds N assembled frames for one launch of the specialised kernel (GFW_OPT_COALESCE_FRAMES)")
+    ap.add_argument("--frame-sync", action="store_true",
+                    help="--per-plane on SYNCHRONOUS contexts (GFW_OPT_SYNCHRONOUS = 1, the reference's contract) with GFW_OPT_FRAME_SYNC: a frame's earlier planes are held, "
+                         "its last plane's call launches the fused kernel and returns when the frame is complete")
     ap.add_argument("--build-matrices", action="store_true",
                     help="build every frame's per-row matrices on the device from quaternion tracks (gfw_build_matrices, "
                          "the 'next' row f-1) inside the timed region instead of using pre-packed resident tables")
@@ -266,6 +274,9 @@ def worker(args):
     global N_DST
     # the frames of a clip launch write one destination set each; clip launches dealt to S streams: a group of sets per stream
     N_DST = max(8, min(args.clip, CLIP_FRAMES)) * (args.streams if args.clip > 1 else 1)
+    sum_stream_on = bool(args.c5 and args.sum_stream and args.clip > 1)
+    if sum_stream_on:
+        N_DST = 2 * min(args.clip, CLIP_FRAMES)         # two groups of destination sets: launch c + 1 writes one while the checksums of launch c read the other
     W, H = args.width, args.height
     readout = 0.0 if args.c1 else 16.0
     cquat = S.quat_from_euler_deg(5.0, 2.0, 3.0) if args.c1 else None
@@ -391,6 +402,9 @@ def worker(args):
             plane_bes.append(b2)
         for b2 in [be] + plane_bes:
             b2.set_option(abi.OPT_COALESCE_FRAMES, hold)
+            if args.frame_sync:                      # the reference's synchronous contract, relaxed to "the frame is complete when its last plane's call returns"
+                b2.set_option(abi.OPT_SYNCHRONOUS, 1)
+                b2.set_option(abi.OPT_FRAME_SYNC, 1)
         calls = [warp.PlaneCalls([be] + plane_bes, bufsets[j * N_DST + (j % N_DST)], tmpl,
                                  frames[j].matrices if args.upload_matrices else d_mat[j].data_ptr(), rows_n) for j in range(NR)]
     # --streams S: S contexts, each on a stream of its own, take the frames in turn.  Frame k writes destination set k mod N_DST and
@@ -429,6 +443,8 @@ def worker(args):
         f = own[k] if args.c5 else k
         j = f % NR
         if device_built:
+            if sum_stream_on:
+                return f, j, (k % clip_n) + ((k // clip_n) % 2) * clip_n
             return f, j, (k % clip_n if clip_n > 1 else k % N_DST)
         return f, j, j % N_DST
 
@@ -436,6 +452,18 @@ def worker(args):
         d_sums = torch.zeros(max(1, n_steps), dtype=torch.int64, device=dev)
         sum_fn, sum_base = be.lib.gfw_checksum64, d_sums.data_ptr()
         dst_ptrs = [b.data_ptr() for b in d_dstbuf]
+    sum_stream, sum_ctxp, sums_done, be_sum = None, None, {}, None
+    if sum_stream_on:
+        # the verification off the warp's critical path: a context of its own on a stream of its own takes the checksums; the warp's persistent grid
+        # (8 workgroups per CU by default) leaves one wave slot per SIMD so that the checksum kernel's workgroups find room beside it
+        sum_stream = torch.cuda.Stream(dev)
+        be_sum = warp.Backend(tmpl[0], types[0], frames[0].model, frames[0].digital, bufsets[0][0])
+        be_sum.set_stream(sum_stream.cuda_stream)
+        be_sum.set_option(abi.OPT_SYNCHRONOUS, 0)
+        sum_ctxp = be_sum.ctx
+        sums_done = {0: None, clip_n: None}
+        if not args.grid:
+            be.set_option(abi.OPT_TUNE_GRID, torch.cuda.get_device_properties(dev).multi_processor_count * 7)
 
     clip_cache = {}
 
@@ -443,13 +471,16 @@ def worker(args):
         """pre-marshalled gfw_undistort_clip call for steps k0 .. k0+ln-1 (with --streams S, launch c goes to context c mod S)"""
         js = tuple(plan(k0 + i)[1] for i in range(ln))
         sidx = (k0 // clip_n) % n_streams
+        par = ((k0 // clip_n) % 2) * clip_n if sum_stream_on else 0          # the launch's group of destination sets
+        if par:
+            sidx = -1                                   # (key only: the second group's calls)
         call = clip_cache.get((sidx, js))
-        if call is None and sidx:
+        if call is None and sidx > 0:
             call = warp.ClipCall(all_bes[sidx], [bufsets[j * N_DST + (j % N_DST)] for j in js], tmpl, types, [d_mat[j].data_ptr() for j in js], rows_n)
             clip_cache[(sidx, js)] = call
         if call is None:
             if device_built:                            # C5: frame i of the call writes destination set i; its table pointer is set per call
-                call = warp.ClipCall(be, [bufsets[j * N_DST + i] for i, j in enumerate(js)], tmpl, types, [table0] * ln, rows_n)
+                call = warp.ClipCall(be, [bufsets[j * N_DST + par + i] for i, j in enumerate(js)], tmpl, types, [table0] * ln, rows_n)
             else:
                 call = warp.ClipCall(be, [bufsets[j * N_DST + (j % N_DST)] for j in js], tmpl, types, [d_mat[j].data_ptr() for j in js], rows_n)
             clip_cache[(sidx, js)] = call
@@ -467,6 +498,19 @@ def worker(args):
                     be._check(rc)
             for i in range(ln):
                 call.marr[i] = tptrs[(k0 + i) % BATCH]
+        if sum_stream_on:
+            par = ((k0 // clip_n) % 2) * clip_n
+            if sums_done[par] is not None:
+                stream.wait_event(sums_done[par])       # this launch overwrites the sets launch c - 2 wrote: its checksums must have read them
+            call()
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            sum_stream.wait_event(ev)
+            for i in range(ln):                         # each frame's checksum on the second stream, beside the next launch's warp
+                sum_fn(sum_ctxp, dst_ptrs[par + i], dst_total, sum_base + 8 * (k0 + i))
+            sums_done[par] = torch.cuda.Event()
+            sums_done[par].record(sum_stream)
+            return
         call()
         if args.c5:
             for i in range(ln):                         # each frame's checksum, in order on the same stream
@@ -636,8 +680,11 @@ def worker(args):
         tpath = os.path.join(ROOT, TRAFFIC_FILE)
         if (W, H, args.fmt, args.interp, args.crop, args.variant, args.host_buffers, bool(args.digital or args.lens_model or args.lca != 1.0)) == (WIDTH, HEIGHT, FMT, 2, False, 0, False, False) and os.path.exists(tpath):
             tj = json.load(open(tpath))                  # per frame; a launch carries fpl of them
-            traffic = int((tj["fetch_size_kib_per_frame"] * tj["fetch_correction"] + tj["write_size_kib_per_frame"]) * 1024 * fpl)
-            tsrc = "%s (stored rocprofv3 PMC passes of this workload and library, not measured in this run)" % TRAFFIC_FILE
+            if tj.get("kernel_source_id") and tj.get("kernel_source_id") == abi.kernel_source_id():
+                traffic = int((tj["fetch_size_kib_per_frame"] * tj["fetch_correction"] + tj["write_size_kib_per_frame"]) * 1024 * fpl)
+                tsrc = "%s (stored rocprofv3 PMC passes of this workload on this kernel source, not measured in this run)" % TRAFFIC_FILE
+            else:                                        # counters of another kernel say nothing about this one: no figure rather than a stale one
+                tsrc = "%s was taken on kernel source %s, the loaded library is %s: not quoted" % (TRAFFIC_FILE, tj.get("kernel_source_id"), abi.kernel_source_id())
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                            "kernel": warp.last_backend(), "kernel_ms_per_launch": round(per_launch_ms, 5),
@@ -733,6 +780,8 @@ def worker(args):
                                              "mean %.3f Mpix/s; the same frame on ONE thread: %.2f Mpix/s" % (len(times), hw, why, luma_px * len(times) / sum(times) / 1e6, luma_px / t_one / 1e6)}
     for b in extra_bes:
         b.close()
+    if be_sum is not None:
+        be_sum.close()
     be.close()
     if rank == 0:
         print(json.dumps(out), flush=True)

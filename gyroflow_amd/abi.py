@@ -163,6 +163,7 @@ def bind(lib):
     lib.gfw_debug_math.argtypes = [i32, vp, vp, vp, sz]; lib.gfw_debug_math.restype = i32
     lib.gfw_debug_selftest.argtypes = [i32, C.c_ulonglong, C.c_ulonglong]; lib.gfw_debug_selftest.restype = C.c_longlong
     lib.gfw_last_error.restype = C.c_char_p
+    lib.gfw_debug_source_id.argtypes = [C.c_char_p, sz]; lib.gfw_debug_source_id.restype = i32
     lib.gfw_pixel_type_info.argtypes = [i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_float)]
     lib.gfw_pixel_type_info.restype = i32
     return lib
@@ -171,7 +172,7 @@ def bind(lib):
 EXPORTS = ["gfw_abi_version", "gfw_list_devices", "gfw_set_device", "gfw_get_info", "gfw_is_buffer_supported",
            "gfw_create", "gfw_destroy", "gfw_undistort_image", "gfw_undistort_frame", "gfw_set_option",
            "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_flush", "gfw_import_external_fd", "gfw_release_external", "gfw_last_backend", "gfw_get_profile", "gfw_last_error", "gfw_debug_math", "gfw_debug_jit_key", "gfw_debug_selftest", "gfw_get_audit", "gfw_pack_matrices", "gfw_checksum64", "gfw_set_quaternion_tracks", "gfw_build_matrices", "gfw_build_matrices_stab", "gfw_set_sync_offsets", "gfw_build_matrices_batch", "gfw_stmap_undistort", "gfw_undistort_points",
-           "gfw_pixel_type_info", "gfw_undistort_clip", "gfw_jit_status", "gfw_get_profile_frames", "gfw_debug_jit_compile"]
+           "gfw_pixel_type_info", "gfw_undistort_clip", "gfw_jit_status", "gfw_get_profile_frames", "gfw_debug_jit_compile", "gfw_debug_source_id"]
 
 
 def load_library(path=None):
@@ -188,3 +189,10 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def kernel_source_id():
+    """identity of the fused kernel's source inside the loaded library (gfw_debug_source_id): what a stored measurement must name to be quoted for it"""
+    buf = C.create_string_buffer(128)
+    n = load_library().gfw_debug_source_id(buf, len(buf))
+    return buf.value.decode() if n > 0 else ""

@@ -563,374 +563,8 @@ static bool int_products_exact(int n_max, int n) {
     return (int64_t)(n_max - 1) * odd < (1 << 24);
 }
 
-// s(rho) = theta_d(atan(r)) / r with r = sqrt(rho) (opencv_fisheye.rs:72-95), tabulated for the certified first pass.
-static double p1_s_of_rho(double rho, const float *k) {
-    // all four k zero: the reference skips the atan scaling altogether and returns (x/z, y/z) (opencv_fisheye.rs:75),
-    // which the exact path honours through k_all_zero — the table must describe the same map, s == 1
-    if (k[0] == 0.0f && k[1] == 0.0f && k[2] == 0.0f && k[3] == 0.0f) return 1.0;
-    const double r = sqrt(rho);
-    if (r == 0.0) return 1.0;
-    const double t = atan(r), t2 = t * t;
-    return t * (1.0 + t2 * ((double)k[0] + t2 * ((double)k[1] + t2 * ((double)k[2] + t2 * (double)k[3])))) / r;
-}
-// ---- derivative bounds of s(rho), derived (round 5) -------------------------------------------------------------------------
-// s = A(rho) P(w):  A(rho) = atan(sqrt rho) / sqrt rho = int_0^1 dt / (1 + rho t^2),  w(rho) = atan^2(sqrt rho) = rho A^2 (= theta^2),
-// P(w) = 1 + k0 w + k1 w^2 + k2 w^3 + k3 w^4.  From the integral: |d^n A / d rho^n| <= n! / (2n + 1) for every rho >= 0 (A, -A', A'', ... are positive and
-// decreasing);  w' = A / (1 + rho) in (0, 1],  w'' = A' / (1 + rho) - A / (1 + rho)^2,  w(3) = A'' / (1 + rho) - 2 A' / (1 + rho)^2 + 2 A / (1 + rho)^3:
-// |w''| <= 4/3, |w(3)| <= 46/15.  The values of s', s'' at a point come from the closed forms below (a series under rho = 1/64, where the closed forms
-// cancel); between two points of a grid of spacing g the next derivative's GLOBAL bound (products of the bounds above) carries the value:
-// |s''(rho)| <= |s''(rho_i)| + g L3 on [rho_i, rho_i + g].  Nothing here is sampled-and-doubled: every number the certificate uses is a bound.
-static void p1_A_derivs(double rho, double &A, double &A1, double &A2) {
-    if (rho < 1.0 / 64.0) {                     // alternating series, terms falling by >= 64 each: 14 terms leave < 2^-84
-        A = A1 = A2 = 0.0;
-        double pw = 1.0;                         // (-rho)^n
-        for (int n = 0; n < 14; ++n) { A += pw / (2 * n + 1); pw *= -rho; }
-        double p1 = 1.0;                         // (-rho)^(n-1)
-        for (int n = 1; n < 14; ++n) { A1 += -(double)n / (2 * n + 1) * p1; p1 *= -rho; }
-        double p2 = 1.0;                         // (-rho)^(n-2)
-        for (int n = 2; n < 14; ++n) { A2 += (double)n * (n - 1) / (2 * n + 1) * p2; p2 *= -rho; }
-        return;
-    }
-    const double r = sqrt(rho);
-    A = atan(r) / r;
-    A1 = (1.0 / (1.0 + rho) - A) / (2.0 * rho);                               // from (rho A^2)' = A / (1 + rho)
-    A2 = (-1.0 / ((1.0 + rho) * (1.0 + rho)) - 3.0 * A1) / (2.0 * rho);       // the same identity differentiated once more
-}
-struct P1Derivs { double s, s1, s2; };
-static P1Derivs p1_s_derivs(double rho, const float *k) {
-    double A, A1, A2;
-    p1_A_derivs(rho, A, A1, A2);
-    const double w = rho * A * A, w1 = A / (1.0 + rho), w2 = A1 / (1.0 + rho) - A / ((1.0 + rho) * (1.0 + rho));
-    const double k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3];
-    const double P = 1.0 + w * (k0 + w * (k1 + w * (k2 + w * k3)));
-    const double P1 = k0 + w * (2.0 * k1 + w * (3.0 * k2 + w * 4.0 * k3));
-    const double P2 = 2.0 * k1 + w * (6.0 * k2 + w * 12.0 * k3);
-    P1Derivs d;
-    d.s = A * P;
-    d.s1 = A1 * P + A * P1 * w1;
-    d.s2 = A2 * P + 2.0 * A1 * P1 * w1 + A * (P2 * w1 * w1 + P1 * w2);
-    return d;
-}
-static int p1_prepare_table(gfw_ctx *c, const gfw_kernel_params &p, float rho_max) {
-    if (c->p1_valid && memcmp(c->p1_k, p.k, sizeof(c->p1_k)) == 0 && rho_max <= c->p1_rho_max && rho_max >= 0.5f * c->p1_rho_max) return GFW_OK;
-    const int N = GFW_P1_TABLE_N;
-    std::vector<float2> tab(N + 1);
-    const double h = (double)rho_max / N;
-    double s_prev = p1_s_of_rho(0.0, p.k);
-    for (int i = 0; i < N; ++i) {
-        const double s_next = p1_s_of_rho((i + 1) * h, p.k);
-        tab[i] = float2{(float)s_prev, (float)(s_next - s_prev)};
-        s_prev = s_next;
-    }
-    tab[N] = float2{(float)s_prev, 0.0f};
-    const bool k_zero = p.k[0] == 0.0f && p.k[1] == 0.0f && p.k[2] == 0.0f && p.k[3] == 0.0f;
-    // global bounds over [0, rho_max]: P and its derivatives over w in [0, w_max] by the triangle inequality, then the products (header comment)
-    double smax = 1.0, slope = 0.0, s2max = 0.0, u1 = 0.0, u2 = 0.0, t32 = 0.0;
-    double kappa = 3.0;                                             // all four k zero: the exact path is (X/W) * f + c, s == 1, every derivative 0
-    if (!k_zero) {
-        const double tmax = atan(sqrt((double)rho_max)), wm = tmax * tmax;
-        const double a0 = fabs((double)p.k[0]), a1 = fabs((double)p.k[1]), a2 = fabs((double)p.k[2]), a3 = fabs((double)p.k[3]);
-        const double P0 = 1.0 + wm * (a0 + wm * (a1 + wm * (a2 + wm * a3)));
-        const double Pd1 = a0 + wm * (2.0 * a1 + wm * (3.0 * a2 + wm * 4.0 * a3));
-        const double Pd2 = 2.0 * a1 + wm * (6.0 * a2 + wm * 12.0 * a3);
-        const double Pd3 = 6.0 * a2 + wm * 24.0 * a3;
-        const double L1 = P0 / 3.0 + Pd1;                                                   // |s'|   <= |A'| P + A |P'| w'
-        const double L2 = 0.4 * P0 + 2.0 * Pd1 + Pd2;                                       // |s''|  <= |A''| P + 2 |A'| |P'| w' + A (|P''| w'^2 + |P'| |w''|)
-        const double L3 = (6.0 / 7.0) * P0 + 1.2 * Pd1 + (Pd2 + Pd1 * 4.0 / 3.0)            // |s(3)| <= |A(3)| P + 3 |A''| |(P)'| + 3 |A'| |(P)''| + A |(P)(3)|
-                        + (Pd3 + 4.0 * Pd2 + Pd1 * 46.0 / 15.0);
-        const int NG = 4096;
-        const double g = (double)rho_max / NG;
-        smax = 0.0;
-        for (int i = 0; i < NG; ++i) {
-            const P1Derivs d = p1_s_derivs(i * g, p.k);
-            const double hi = (i + 1) * g;
-            const double b0 = fabs(d.s) + g * L1, b1 = fabs(d.s1) + g * L2, b2 = fabs(d.s2) + g * L3;     // bounds over [i g, (i + 1) g]
-            smax = fmax(smax, b0); slope = fmax(slope, b1); s2max = fmax(s2max, b2);
-            u1 = fmax(u1, sqrt(hi) * b1); u2 = fmax(u2, hi * b1); t32 = fmax(t32, hi * sqrt(hi) * b2);
-        }
-        const double slack = 1.0 + 1e-9;                            // the f64 evaluation itself
-        smax *= slack; slope *= slack; s2max *= slack; u1 *= slack; u2 *= slack; t32 *= slack;
-        // the exact path's theta_d / r as a function of its (already rounded) rho: sqrt (1 rounding), glibc atanf (< 1 ulp = 2 roundings), the polynomial
-        // 1 + k0 t^2 + k1 t^4 + k2 t^6 + k3 t^8 (powers by repeated products: 2, 4, 6, 8 roundings on the terms, 4 on the partial sums), t * poly, / r:
-        // relative error <= u * kappa, kappa = 3.5 (1 + R) + (R + 4 K) + 3 with R = max sum (2i |k_i| t^2i) / |P| (both t P'/P's bound and the terms' own
-        // roundings) and K = max sum |terms| / |P| (the partial sums)  (DESIGN.md section 2c).  |P| from below: its value on a grid of w = t^2 less the
-        // grid step times the bound on |dP/dw|; the sums of absolute terms at the interval's upper end.
-        double rp = 0.0, kp = 1.0;
-        const double gw = wm / 4096.0;
-        for (int i = 0; i <= 4096; ++i) {
-            const double t2 = gw * i, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
-            const double P = fabs(1.0 + p.k[0] * t2 + p.k[1] * t4 + p.k[2] * t6 + p.k[3] * t8) - gw * Pd1;
-            const double t2h = t2 + gw, t4h = t2h * t2h, t6h = t4h * t2h, t8h = t4h * t4h;
-            const double Pabs = 1.0 + a0 * t2h + a1 * t4h + a2 * t6h + a3 * t8h;
-            const double dPabs = 2.0 * a0 * t2h + 4.0 * a1 * t4h + 6.0 * a2 * t6h + 8.0 * a3 * t8h;
-            if (!(P > 1e-3)) { rp = kp = 1e30; break; }           // theta_d's polynomial (nearly) vanishes inside the range: no certificate
-            rp = fmax(rp, dPabs / P); kp = fmax(kp, Pabs / P);
-        }
-        kappa = 4.5 * rp + 4.0 * kp + 6.5;
-    }
-    // the table's own error against s: the chord of a function with |s''| <= s2max over an interval h, the float rounding of the entry s_i (u |s|) and of
-    // the entry s_{i+1} - s_i (u h |s'|, times a fraction <= 1); the fma that combines them is counted with the first pass's roundings (section 2c, item 4)
-    const double etab = h * h / 8.0 * s2max + (smax + h * slope) / 16777216.0;
-    if (!(etab == etab) || !(smax == smax) || !(slope == slope) || !(kappa == kappa) || !(t32 == t32)) { c->p1_valid = false; return GFW_OK; }
-    if (!c->dry) {
-        HIP_TRY(c->d_p1_table.ensure((N + 1) * sizeof(float2)), GFW_ERR_HIP);
-        HIP_TRY(hipMemcpyAsync(c->d_p1_table.ptr, tab.data(), (N + 1) * sizeof(float2), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
-        HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);      // `tab` is a stack-lifetime source
-    }
-    memcpy(c->p1_k, p.k, sizeof(c->p1_k));
-    c->p1_rho_max = rho_max; c->p1_etab = etab; c->p1_smax = smax; c->p1_slope = slope; c->p1_kappa = kappa; c->p1_valid = true;
-    c->p1_u1 = u1; c->p1_u2 = u2; c->p1_t32 = t32;
-    return GFW_OK;
-}
-// Fill the first-pass fields of the fused kernel's arguments; returns true when the certified pass may be used.
-static bool p1_setup(gfw_ctx *c, const gfw_kernel_params &p0, const float *h_matrices, int matrix_count, GfwYuvArgs &Y, bool &table_ok) {
-    Y.p1_table = nullptr; Y.audit = nullptr; table_ok = false;
-    if (c->kernel_variant == 2) return false;                   // forced exact first pass (tests / A-B benchmarking)
-    if (c->model != GFW_MODEL_OPENCV_FISHEYE || Y.hstretch_div || Y.vstretch_div) return false;
-    const bool hrs = (p0.flags & GFW_FLAG_HORIZONTAL_RS) != 0;
-    // rho range over the output frame under the mid-row matrix (corners + edge midpoints), in double
-    double rho_max = 0.0;
-    if (h_matrices) {
-        const float *m = h_matrices + (size_t)(matrix_count >> 1) * 14;
-        const double xs[3] = {0.0, p0.output_width * 0.5, (double)p0.output_width}, ys[3] = {0.0, p0.output_height * 0.5, (double)p0.output_height};
-        for (double y : ys) for (double x : xs) {
-            const double ox = x + p0.translation2d[0], oy = y + p0.translation2d[1];
-            const double X = ox * m[0] + oy * m[1] + m[2], Yy = ox * m[3] + oy * m[4] + m[5], W = ox * m[6] + oy * m[7] + m[8];
-            if (!(W > 0.05)) { rho_max = 1e9; continue; }
-            rho_max = fmax(rho_max, (X * X + Yy * Yy) / (W * W));
-        }
-        rho_max = rho_max * 1.25 + 0.01;
-    } else {
-        // device-resident matrices: no host view of the geometry.  Bound the corner ray from the intrinsics
-        // (new_k = f / fov, frame_transform.rs:37-51) and allow 15 degrees of stabilisation rotation on top (rays beyond it simply take the exact path).
-        const double hx = 0.5 * p0.output_width * (double)p0.fov / fmax(fabs((double)p0.f[0]), 1e-6) + fabs((double)p0.translation2d[0]) * (double)p0.fov / fmax(fabs((double)p0.f[0]), 1e-6);
-        const double hy = 0.5 * p0.output_height * (double)p0.fov / fmax(fabs((double)p0.f[1]), 1e-6) + fabs((double)p0.translation2d[1]) * (double)p0.fov / fmax(fabs((double)p0.f[1]), 1e-6);
-        const double ang = atan(sqrt(hx * hx + hy * hy)) + 0.26;
-        rho_max = ang < 1.45 ? tan(ang) * tan(ang) : 64.0;
-    }
-    if (!(rho_max == rho_max)) return false;
-    if (rho_max > 64.0) rho_max = 64.0;
-    if (!(c->p1_valid && memcmp(c->p1_k, p0.k, sizeof(c->p1_k)) == 0 && rho_max <= c->p1_rho_max && rho_max >= 0.5 * c->p1_rho_max))
-        rho_max = fmin(rho_max * 1.15, 64.0);                   // head-room so that frame-to-frame motion does not rebuild the table
-    if (p1_prepare_table(c, p0, (float)rho_max) != GFW_OK || !c->p1_valid) return false;
-    const double f = fabs((double)(hrs ? p0.f[0] : p0.f[1])), cc = fabs((double)(hrs ? p0.c[0] : p0.c[1]));
-    const double rmax = sqrt((double)c->p1_rho_max);
-    const double vmag = f * rmax * c->p1_smax + cc;
-    // E >= |approx - exact| (derived operation by operation): with u = 2^-24,
-    //   E = 1.05 u { G * (mu + rmax omega + 10 rmax) + 6 |f| rmax rho_max S' + |f| rmax smax (kappa + 4) + 2 vmag } + 2 |f| rmax e_table + 2^-14,
-    //   G = |f| smax + 2 sqrt2 |f| rmax^2 S',   S' = max |ds/drho|,
-    // mu and omega measure the rounding error of the mid-row matrix's linear forms relative to W (gfw_frame.hip: p1_bound): the kernel
-    // evaluates them from the matrix it actually uses (device-resident tables included) and forms E = p1_eps + p1_ew * omega + p1_em * mu per frame.
-    const double u24 = 1.05 / 16777216.0;
-    const double G = f * c->p1_smax + 2.0 * M_SQRT2 * f * rmax * rmax * c->p1_slope;
-    const double e0 = u24 * (G * 10.0 * rmax + 6.0 * f * rmax * (double)c->p1_rho_max * c->p1_slope + f * rmax * c->p1_smax * (c->p1_kappa + 4.0) + 2.0 * vmag)
-                    + 2.0 * f * rmax * c->p1_etab + 1.0 / 16384.0;
-    const double ew = u24 * G * rmax, em = u24 * G;
-    // the host's own view of omega, mu (only to decide whether the certified pass is worth launching and to report E; the kernel's value decides)
-    double omega = 1.0, mu = 6.0 * (rmax + 1.0);
-    if (h_matrices) {
-        const float *m = h_matrices + (size_t)(matrix_count >> 1) * 14;
-        const double x0 = p0.translation2d[0], x1 = x0 + p0.output_width, y0 = p0.translation2d[1], y1 = y0 + p0.output_height;
-        const double ax = fmax(fabs(x0), fabs(x1)), ay = fmax(fabs(y0), fabs(y1));
-        const double px = ax * fabs(m[0]) + ay * fabs(m[1]), py = ax * fabs(m[3]) + ay * fabs(m[4]), pw = ax * fabs(m[6]) + ay * fabs(m[7]);
-        const double wden = fmax((double)m[8] - pw, fmax(1.0 / 1024.0, (pw + fabs(m[8])) / 8.0));
-        omega = 3.0 * pw / wden; mu = 3.0 * fmax(px, py) / wden;
-    }
-    const double eps = e0 + ew * omega + em * mu;
-    Y.p1_table = (const float2 *)c->d_p1_table.ptr;
-    Y.p1_rho_max = c->p1_rho_max; Y.p1_rho_scale = (float)(GFW_P1_TABLE_N / (double)c->p1_rho_max);
-    Y.p1_eps = (float)e0; Y.p1_ew = (float)ew; Y.p1_em = (float)em;
-    // the lattice form of the first pass (gfw_frame.hip, phase 1): bounds on s and its derivatives for the curvature of v across a cell, and the roundings of the
-    // interpolation itself (node differences, three fmas, the row fraction: < 4 u vmag; 2^-17 px on top)
-    Y.p1_lat[0] = (float)(c->p1_smax * (1.0 + 1e-6)); Y.p1_lat[1] = (float)(c->p1_u1 * (1.0 + 1e-6)); Y.p1_lat[2] = (float)(c->p1_u2 * (1.0 + 1e-6));
-    Y.p1_lat[3] = (float)(c->p1_t32 * (1.0 + 1e-6)); Y.p1_lat[4] = (float)(4.0 * u24 * vmag + 1.0 / 131072.0); Y.p1_lat[5] = 0.0f;
-    c->p1_eps_last = (float)eps;
-    Y.p1_f = hrs ? p0.f[0] : p0.f[1]; Y.p1_c = hrs ? p0.c[0] : p0.c[1];
-    table_ok = true;
-    {   // the per-pixel form of the first pass on request: GFW_OPT_KERNEL_VARIANT = 4 (audit of that form) or GFW_P1_LATTICE=0 in the environment (A/B runs)
-        static const bool env_off = [] { const char *e = getenv("GFW_P1_LATTICE"); return e && e[0] == '0' && e[1] == 0; }();
-        if (c->kernel_variant == 4 || env_off) Y.p1_lat[5] = 1.0f;
-    }
-    if (c->kernel_variant == 3 || c->kernel_variant == 4) {     // audit mode: count certificates and check each one
-        const bool fresh = c->d_audit.cap == 0;
-        if (c->d_audit.ensure(8 * sizeof(unsigned long long)) != hipSuccess) { table_ok = false; return false; }
-        if (fresh) (void)hipMemsetAsync(c->d_audit.ptr, 0, 8 * sizeof(unsigned long long), c->stream);
-        Y.audit = (unsigned long long *)c->d_audit.ptr;
-    }
-    if (matrix_count <= 1) return false;                        // a single matrix: no first pass to certify (the table still serves the second)
-    if (!(eps < 0.2)) return false;                             // certificate would reject most pixels: use the exact pass
-    return true;
-}
-
-// Decide whether the frame qualifies for the fused YUV kernel and, if so, build its argument block.
-// Anything not proven here runs through the generic per-plane kernel (same results, slower).
-static bool build_yuv_args(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params, const int *pixel_types,
-                           const GfwPlane *launches, const float *h_matrices, int matrix_count, size_t mesh_len,
-                           GfwYuvArgs &Y, int &bytes_per_sample, int &n0, int &dw, int &dh, bool &interleaved, bool &fast1) {
-    if (c->kernel_variant == 1) return false;                       // forced generic (tests / A-B benchmarking)
-    if (nplanes < 1 || nplanes > 4) return false;
-    const gfw_kernel_params &p0 = params[0];
-    const int t0 = pixel_types[0];
-    // plane 0: sample kind (1 = u8, 2 = u16, 4 = f32) and channel count; RGBAf16 / UV-as-plane-0 stay on the generic kernel
-    switch (t0) {
-    case GFW_PIX_LUMA8:  bytes_per_sample = 1; n0 = 1; break;
-    case GFW_PIX_LUMA16: bytes_per_sample = 2; n0 = 1; break;
-    case GFW_PIX_RGB8:   bytes_per_sample = 1; n0 = 3; break;
-    case GFW_PIX_RGBA8: case GFW_PIX_BGRA8: bytes_per_sample = 1; n0 = 4; break;
-    case GFW_PIX_RGB16:  bytes_per_sample = 2; n0 = 3; break;
-    case GFW_PIX_RGBA16: case GFW_PIX_AYUV16: bytes_per_sample = 2; n0 = 4; break;
-    case GFW_PIX_RGBAF:  bytes_per_sample = 4; n0 = 4; break;
-    case GFW_PIX_R32F:   bytes_per_sample = 4; n0 = 1; break;
-    default: return false;
-    }
-    if (n0 > 1 && nplanes != 1) return false;
-    interleaved = false;
-    if (nplanes >= 2) {
-        const int t1 = pixel_types[1];
-        if (bytes_per_sample != 4 && t1 == (bytes_per_sample == 1 ? GFW_PIX_UV8 : GFW_PIX_UV16)) { if (nplanes != 2) return false; interleaved = true; }
-        else { for (int i = 1; i < nplanes; ++i) if (pixel_types[i] != t0) return false; }
-    }
-    int extras = 0;
-    if (mesh_len != 0) extras |= 32;
-    if (c->digital != GFW_MODEL_NONE && (p0.flags & GFW_FLAG_HAS_DIGITAL_LENS)) extras |= 2;
-    if (c->model < GFW_MODEL_OPENCV_FISHEYE || c->model > GFW_MODEL_GOPRO) return false;
-    // plane-invariant parameters must really be invariant, and inside the fused kernel's feature set
-    for (int i = 0; i < nplanes; ++i) {
-        const gfw_kernel_params &p = params[i];
-        if ((p.interpolation != 2 && p.interpolation != 4 && p.interpolation != 8) || p.interpolation != p0.interpolation) return false;
-        if (p.background_mode < 0 || p.background_mode > 3 || p.background_mode != p0.background_mode || p.input_rotation != p0.input_rotation || !(p.input_rotation == p.input_rotation)) return false;
-        if (p.background_mode == 3) {
-            if (p.background_margin != p0.background_margin || p.background_margin_feather != p0.background_margin_feather) return false;
-            extras |= 16;                                                        // two samples + blend (:576-613), generic-model instantiation
-        }
-        if (!(p.lens_correction_amount == p.lens_correction_amount) || p.lens_correction_amount != p0.lens_correction_amount) return false;
-        if (p.lens_correction_amount < 1.0f) extras |= 8;                        // the blend of :429-460 (generic-model instantiation)
-        if (!(p.light_refraction_coefficient == p.light_refraction_coefficient) || p.light_refraction_coefficient != p0.light_refraction_coefficient) return false;
-        if (p.light_refraction_coefficient != 1.0f && p.light_refraction_coefficient > 0.0f) extras |= 4;
-        if ((p.flags ^ p0.flags) & GFW_FLAG_HAS_DIGITAL_LENS) return false;
-        if (mesh_len != 0 && ((p.flags ^ p0.flags) & 128)) return false;          // the mesh terms read flag 128 (vertically flipped frame buffer)
-        if (memcmp(p.digital_lens_params, p0.digital_lens_params, sizeof(p.digital_lens_params))) return false;
-        if (p.flags & GFW_FLAG_FIX_COLOR_RANGE) return false;                       // (a macOS VideoToolbox workaround: per plane)
-        if ((p.flags ^ p0.flags) & GFW_FLAG_FILL_WITH_BACKGROUND) return false;
-        if (p.translation3d[0] != 0.0f || p.translation3d[1] != 0.0f || p.translation3d[2] != 0.0f) return false;
-        if (p.width != p0.width || p.height != p0.height || p.output_width != p0.output_width || p.output_height != p0.output_height) return false;
-        if (p.matrix_count != p0.matrix_count || ((p.flags ^ p0.flags) & GFW_FLAG_HORIZONTAL_RS)) return false;
-        if (memcmp(p.f, p0.f, sizeof(p.f)) || memcmp(p.c, p0.c, sizeof(p.c)) || memcmp(p.k, p0.k, sizeof(p.k))) return false;
-        if (memcmp(p.translation2d, p0.translation2d, sizeof(p.translation2d)) || p.r_limit != p0.r_limit || p.fov != p0.fov) return false;
-        if (p.input_horizontal_stretch != p0.input_horizontal_stretch || p.input_vertical_stretch != p0.input_vertical_stretch) return false;
-        // full-plane rects: source_rect = (0,0,pw,ph), output_rect = (0,0,opw,oph), buffers sized accordingly
-        const gfw_buffers &b = planes[i];
-        if (p.source_rect[0] || p.source_rect[1] || p.source_rect[2] != b.input.width || p.source_rect[3] != b.input.height) return false;
-        if (p.output_rect[0] || p.output_rect[1] || p.output_rect[2] != b.output.width || p.output_rect[3] != b.output.height) return false;
-        if (p.stride <= 0 || b.output.stride <= 0) return false;
-        if ((int64_t)b.input.height * p.stride > (int64_t)b.input.len) return false;
-        if ((int64_t)b.output.height * b.output.stride > (int64_t)b.output.len) return false;
-        if ((int64_t)b.output.width * p.bytes_per_pixel > b.output.stride) return false;
-        // rows of the buffer beyond the plane would be visited (and skipped) by the reference; require none carry pixels
-        if ((bytes_per_sample == 2) && ((p.stride | b.output.stride) & 1)) return false;
-        if ((bytes_per_sample == 4) && ((p.stride | b.output.stride) & 3)) return false;
-        if ((int64_t)b.input.height * p.stride >= (1ll << 31) || (int64_t)b.output.height * b.output.stride >= (1ll << 31)) return false;   // 32-bit offsets
-        if (p.stride >= (1 << 23) || b.output.stride >= (1 << 23) || b.input.height >= (1 << 23) || b.output.height >= (1 << 23)) return false;   // 24-bit row-offset multiplies
-    }
-    // stretch divisions (cpu_undistort.rs:222-223): "skipped" (<= 0.001) and the identity x / 1 cost nothing; a real divisor (anamorphic lens profiles) is an
-    // IEEE division at the end of the projection, served since round 4 (not together with the lens-correction blend, whose inverse the kernel does not stretch)
-    if (!(p0.input_horizontal_stretch == p0.input_horizontal_stretch) || !(p0.input_vertical_stretch == p0.input_vertical_stretch)) return false;
-    const bool hdiv = p0.input_horizontal_stretch > 0.001f && p0.input_horizontal_stretch != 1.0f, vdiv = p0.input_vertical_stretch > 0.001f && p0.input_vertical_stretch != 1.0f;
-    if ((hdiv || vdiv) && ((extras & 8) || !std::isfinite(p0.input_horizontal_stretch) || !std::isfinite(p0.input_vertical_stretch))) return false;
-    for (int i = 0; i < 12; ++i) { const float k = p0.k[i]; if (!(k == k) || fabsf(k) > 1024.0f) return false; }
-    if (!std::isfinite(p0.f[0]) || !std::isfinite(p0.f[1]) || !std::isfinite(p0.c[0]) || !std::isfinite(p0.c[1])) return false;
-    if (!(p0.translation2d[0] == p0.translation2d[0]) || !(p0.translation2d[1] == p0.translation2d[1])) return false;
-    // luma plane is full resolution on both sides
-    if (planes[0].input.width != p0.width || planes[0].input.height != p0.height) return false;
-    if (planes[0].output.width != p0.output_width || planes[0].output.height != p0.output_height) return false;
-    dw = 1; dh = 1;
-    if (nplanes >= 2) {
-        const int cw = planes[1].output.width, ch = planes[1].output.height;
-        if (cw <= 0 || ch <= 0 || p0.output_width % cw || p0.output_height % ch) return false;
-        dw = p0.output_width / cw; dh = p0.output_height / ch;
-        if (!((dw == 1 && dh == 1) || (dw == 2 && dh == 1) || (dw == 2 && dh == 2))) return false;
-        if (bytes_per_sample == 4 && !(dw == 1 && dh == 1)) return false;
-        for (int i = 1; i < nplanes; ++i) {
-            if (planes[i].output.width != cw || planes[i].output.height != ch) return false;
-            if (planes[i].input.width * dw != p0.width || planes[i].input.height * dh != p0.height) return false;
-            // planar chroma planes share one set of offsets in the kernel
-            if (params[i].stride != params[1].stride || planes[i].output.stride != planes[1].output.stride) return false;
-        }
-        // chroma site -> luma position identity: xc*ow exact and (xc*ow)/(ow/dw) = dw*xc   (util.rs:144-147)
-        if (!int_products_exact(cw, p0.output_width) || !int_products_exact(ch, p0.output_height)) return false;
-    }
-    // luma output pixel -> output space identity: x*ow/ow = x
-    if (!int_products_exact(p0.output_width, p0.output_width) || !int_products_exact(p0.output_height, p0.output_height)) return false;
-    if (p0.output_width >= (1 << 23) || p0.output_height >= (1 << 23)) return false;
-    if (p0.width > 65535 || p0.height > 65535) return false;                // the first pass keeps its row / column indices in 16 bits (s_rows)
-    // IBIS/OIS terms (matrices[9..13]): host matrices are scanned, device matrices rely on the flag (get_kernel_flags sets
-    // it whenever the clip has IBIS/OIS data, mod.rs:226-251); packed device rows carry cos/sin of the roll from
-    // gfw_pack_matrices, raw device rows[14] get them from gfw_repack_matrices_kernel (the same libm routines, restated)
-    if (h_matrices) {
-        for (int r = 0; r < matrix_count && !(extras & 1); ++r) { const float *m = h_matrices + (size_t)r * 14;
-            if (m[9] != 0.0f || m[10] != 0.0f || m[11] != 0.0f || m[12] != 0.0f || m[13] != 0.0f) extras |= 1; }
-    } else if (p0.flags & GFW_FLAG_HAS_IBIS_DATA) {
-        extras |= 1;
-    }
-    // source_rect map constants: u * pw / W  (cpu_undistort.rs:511-514 with frame_size = (width, height))
-    // (frame_size: the source frame, turned by input_rotation — cpu_undistort.rs:484-490; fill_common evaluates the same expression for the kernels' uniforms)
-    float Wf = (float)p0.width, Hf = (float)p0.height;
-    if (p0.input_rotation != 0.0f) {
-        if (extras & (8 | 16 | 32)) return false;                       // with the lens-correction blend, margin feather or the Sony mesh: per plane
-        GfwCommon rc; fill_common(c, &p0, nullptr, nullptr, 0, rc);
-        Wf = rc.frame_w; Hf = rc.frame_h;
-        if (!(Wf >= 1.0f) || !(Hf >= 1.0f)) return false;
-    }
-    if (!map_const_valid(Wf) || !map_const_valid(Hf)) return false;
-
-    // bicubic / Lanczos4 taps of single-channel integer planes are fetched as aligned dwords at 32-bit offsets from the plane base (taps_inside): the base itself
-    // must be dword aligned (every allocator's is; a caller's odd sub-buffer goes the per-plane way)
-    if (p0.interpolation != 2 && bytes_per_sample != 4)
-        for (int i = 0; i < nplanes; ++i) if ((uintptr_t)launches[i].src & 3u) return false;
-    memset(&Y, 0, sizeof(Y));
-    for (int i = 0; i < nplanes; ++i) {
-        GfwYuvPlane &P = Y.pl[i];
-        P.src = launches[i].src; P.dst = launches[i].dst;
-        P.src_stride = params[i].stride; P.dst_stride = planes[i].output.stride;
-        P.w = planes[i].input.width; P.h = planes[i].input.height;
-        for (int ch = 0; ch < 4; ++ch) P.bg[ch] = params[i].background[ch] * params[i].max_pixel_value;
-        P.limit = params[i].pixel_value_limit;
-        P.src_len = (int32_t)(planes[i].input.len < 0x7fffffffull ? planes[i].input.len : 0x7fffffffull);
-        P.dst_len = (int32_t)(planes[i].output.len < 0x7fffffffull ? planes[i].output.len : 0x7fffffffull);
-    }
-    Y.nplanes = nplanes;
-    Y.width = p0.width; Y.height = p0.height;
-    Y.out_w = p0.output_width; Y.out_h = p0.output_height;
-    Y.cw = (p0.output_width + dw - 1) / dw; Y.ch = (p0.output_height + dh - 1) / dh;
-    Y.matrix_count = matrix_count;
-    Y.hrs = (p0.flags & GFW_FLAG_HORIZONTAL_RS) ? 1 : 0;
-    Y.background_mode = p0.background_mode;
-    Y.model = c->model;
-    Y.extras = extras;
-    Y.k_all_zero = (p0.k[0] == 0.0f && p0.k[1] == 0.0f && p0.k[2] == 0.0f && p0.k[3] == 0.0f) ? 1 : 0;
-    Y.hstretch = p0.input_horizontal_stretch; Y.vstretch = p0.input_vertical_stretch;
-    Y.hstretch_div = hdiv ? 1 : 0; Y.vstretch_div = vdiv ? 1 : 0;
-    Y.fill_bg = (p0.flags & GFW_FLAG_FILL_WITH_BACKGROUND) ? 1 : 0;
-    Y.rot_on = p0.input_rotation != 0.0f ? 1 : 0;
-    memcpy(Y.f, p0.f, sizeof(Y.f)); memcpy(Y.c, p0.c, sizeof(Y.c)); memcpy(Y.k, p0.k, sizeof(Y.k));
-    Y.t2[0] = p0.translation2d[0]; Y.t2[1] = p0.translation2d[1];
-    Y.r_limit_sq = p0.r_limit * p0.r_limit;
-    Y.map_lx = GfwMapConst{(float)planes[0].input.width, Wf, 1.0f / Wf};
-    Y.map_ly = GfwMapConst{(float)planes[0].input.height, Hf, 1.0f / Hf};
-    if (nplanes >= 2) {
-        Y.map_cx = GfwMapConst{(float)planes[1].input.width, Wf, 1.0f / Wf};
-        Y.map_cy = GfwMapConst{(float)planes[1].input.height, Hf, 1.0f / Hf};
-    }
-    Y.kp = p0;
-    Y.grid_limit = c->tune_grid > 0 ? c->tune_grid : c->num_cus * 6;
-    Y.ablate = (c->kernel_variant >= 16) ? (c->kernel_variant - 16) : 0;      // timing ablations (results are wrong by design)
-    bool table_ok = false;
-    fast1 = (extras || p0.output_width > 65535 || p0.output_height > 65535) ? false : p1_setup(c, p0, h_matrices, matrix_count, Y, table_ok);   // deferred pixels are parked as (x | y << 16)
-    const int rb = gfw_yuv_rows_per_lane(fast1, Y.audit ? 0 : c->tune_rb);
-    Y.tiles_x = (Y.cw + 63) / 64; Y.tiles_y = (Y.ch + 4 * rb - 1) / (4 * rb);
-    return true;
-}
-
+#include "gfw_api_certificate.inc"
+#include "gfw_api_eligibility.inc"
 // Frames of one gfw_undistort_clip call waiting to go out in one launch of the specialised kernel.
 static_assert(GFW_CLIP_MAX == GFW_CLIP_FRAMES_MAX, "gfw_frame.h and gfwarp.h disagree on the frames of a clip launch");
 struct ClipBatch {
@@ -1008,144 +642,7 @@ static int clip_flush(gfw_ctx *c, ClipBatch *b) {
     return GFW_OK;
 }
 
-// ---- run-time specialisation (gfw_jit.hip) ----------------------------------------------------------------------------------------
-// The bake header: every clip-invariant field of the fused kernel's argument block as a literal, GFW_BK_<field> (floats by bit
-// pattern; gfw_frame.hip reads them through AF()).  What stays
-// an argument: plane pointers and lengths, the matrix table, the first-pass table and its three range constants (the table may be
-// rebuilt mid-clip), the grid.  Two frames with the same header run the same specialised kernel.
-static void bake_f(std::string &o, const char *name, float v) {
-    uint32_t u; memcpy(&u, &v, 4);
-    char b[128]; snprintf(b, sizeof(b), "#define GFW_BK_%s __builtin_bit_cast(float, 0x%08xu)\n", name, u); o += b;
-}
-static void bake_i(std::string &o, const char *name, long long v) { char b[128]; snprintf(b, sizeof(b), "#define GFW_BK_%s (%lld)\n", name, v); o += b; }
-// Luma block rows per lane of a SPECIALISED kernel (its tile = 64 DW x 4 RB DH luma pixels): the ahead-of-time kernels' by default; GFW_JIT_RB_FAST in the
-// environment scans it for the certified first pass (whose cost per pixel — the lattice's nodes, the queue's resolution — is per tile).
-static int jit_rows(bool fast1) {
-    static const int env = [] { const char *e = getenv("GFW_JIT_RB_FAST"); const int v = e ? atoi(e) : 0; return (v >= 1 && v * 4 <= 64) ? v : 0; }();
-    return (fast1 && env > 0) ? env : gfw_yuv_rows_per_lane(fast1, 0);
-}
-static std::string bake_header(const GfwYuvArgs &Y_in, bool fast1) {
-    GfwYuvArgs Y = Y_in;
-    { const int rb = jit_rows(fast1); Y.tiles_y = (Y.ch + 4 * rb - 1) / (4 * rb); }          // (the launch's own tiling: the argument block carries the ahead-of-time kernels')
-    std::string o;
-    o.reserve(4096);
-    bake_i(o, "nplanes", Y.nplanes); bake_i(o, "width", Y.width); bake_i(o, "height", Y.height); bake_i(o, "out_w", Y.out_w); bake_i(o, "out_h", Y.out_h);
-    bake_i(o, "cw", Y.cw); bake_i(o, "ch", Y.ch); bake_i(o, "tiles_x", Y.tiles_x); bake_i(o, "tiles_y", Y.tiles_y); bake_i(o, "matrix_count", Y.matrix_count);
-    bake_i(o, "hrs", Y.hrs); bake_i(o, "model", Y.model); bake_i(o, "k_all_zero", Y.k_all_zero);
-    bake_i(o, "background_mode", Y.background_mode); bake_i(o, "extras", Y.extras); bake_i(o, "ablate", 0);
-    bake_i(o, "digital", (Y.extras & 2) ? Y.common.digital : 0);
-    bake_i(o, "fill_bg", Y.fill_bg); bake_i(o, "rot_on", Y.rot_on);
-    bake_i(o, "hstretch_div", Y.hstretch_div); bake_i(o, "vstretch_div", Y.vstretch_div); bake_f(o, "hstretch", Y.hstretch); bake_f(o, "vstretch", Y.vstretch);
-    o += "#define GFW_BK_audit ((unsigned long long *)nullptr)\n";
-    char nm[48];
-    for (int i = 0; i < 2; ++i) { snprintf(nm, sizeof(nm), "f_%d", i); bake_f(o, nm, Y.f[i]); snprintf(nm, sizeof(nm), "c_%d", i); bake_f(o, nm, Y.c[i]);
-                                  snprintf(nm, sizeof(nm), "t2_%d", i); bake_f(o, nm, Y.t2[i]); }
-    for (int i = 0; i < 4; ++i) { snprintf(nm, sizeof(nm), "k_%d", i); bake_f(o, nm, Y.k[i]); }
-    bake_f(o, "r_limit_sq", Y.r_limit_sq);
-    const GfwMapConst *maps[4] = {&Y.map_lx, &Y.map_ly, &Y.map_cx, &Y.map_cy};
-    const char *mn[4] = {"map_lx", "map_ly", "map_cx", "map_cy"};
-    for (int i = 0; i < 4; ++i) {
-        snprintf(nm, sizeof(nm), "%s_mul", mn[i]); bake_f(o, nm, maps[i]->mul);
-        snprintf(nm, sizeof(nm), "%s_den", mn[i]); bake_f(o, nm, maps[i]->den);
-        snprintf(nm, sizeof(nm), "%s_rcp", mn[i]); bake_f(o, nm, maps[i]->rcp);
-    }
-    bake_f(o, "p1_f", Y.p1_f); bake_f(o, "p1_c", Y.p1_c);
-    for (int i = 0; i < 4; ++i) {
-        const GfwYuvPlane &P = Y.pl[i];
-        snprintf(nm, sizeof(nm), "pl%d_src_stride", i); bake_i(o, nm, P.src_stride);
-        snprintf(nm, sizeof(nm), "pl%d_dst_stride", i); bake_i(o, nm, P.dst_stride);
-        snprintf(nm, sizeof(nm), "pl%d_w", i); bake_i(o, nm, P.w);
-        snprintf(nm, sizeof(nm), "pl%d_h", i); bake_i(o, nm, P.h);
-        for (int ch = 0; ch < 4; ++ch) { snprintf(nm, sizeof(nm), "pl%d_bg_%d", i, ch); bake_f(o, nm, P.bg[ch]); }
-        snprintf(nm, sizeof(nm), "pl%d_limit", i); bake_f(o, nm, P.limit);
-    }
-    return o;
-}
-// Waves per SIMD the specialised instantiation is budgeted for.  Measured on MI355X (us per frame, priority step of its time; gpurun_out/r03b-m,
-// profiles/r03_ab_waves_priority.txt): C2 bilinear 6 -> 65.4, 7 -> 57.0-59.3, 8 -> 55.0; NV12 64.6 -> 60.5, P010 71.4 -> 67.8, planar f32 97.7 -> 91.5,
-// Lanczos4 180.5 -> 173.6, bicubic 96.3 -> 95.4, fisheye + SuperView 117.3 -> 103.7 at 7 -> 8.  Eight waves lose where a wave's life is short or
-// its registers are many: one matrix per frame (C1 1080p: 9.30 at 7, 10.2 at 8) and packed RGBA planes (C4: 73.0 at 7, 74.7 at 8) stay at seven.
-// The generic-model body keeps the rule — the lens-correction blend too, although it spills a few dwords at eight waves (GoPro lens, blend 0.5:
-// 141.5 us at 6 waves, 139.2 at 7, 134.4 at 8; fisheye + blend 140.5 / 137.4 / 135.9) — except with background mode 3 or the Sony mesh (two
-// samples per pixel, f64 splines: up to 80 registers), which get six.
-static int jit_waves(int n0, int matrix_count, int jit_model, int extras, int taps, int bps, int dh) {
-    static const int forced = getenv("GFW_JIT_WAVES") ? atoi(getenv("GFW_JIT_WAVES")) : 0;      // experiments
-    if (forced >= 1 && forced <= 8) return forced;
-    if (jit_model < 0 && (extras & (16 | 32))) return 6;
-    // bicubic / Lanczos4 on single-channel integer planes: registers for the tap rows in flight are worth more than the seventh and eighth wave
-    // (gfw_frame.hip GFW_TAP_ROW_UNROLL; profiles/r04_ab_lut_rows.txt).  Not for bicubic on 16-bit planes with full-height chroma (C2's 4:2:2): there the six-wave
-    // build is 64 us from the ROCm 7.0 hiprtc that torch brings into the benchmark process and 78 us from the system's ROCm 7.2 (the build step's kernel cache, any host
-    // without torch) — against a steady 67.6 at eight waves from both.
-    if (n0 == 1 && bps <= 2 && taps == 4 && (bps == 1 || dh == 2)) return 6;
-    if (n0 == 1 && bps <= 2 && taps == 8) return bps == 1 ? 5 : 6;
-    return (n0 == 1 && matrix_count > 1) ? 8 : 7;
-}
-// The definition list of a specialised build (with the bake header: everything that names the kernel)
-static std::vector<std::string> jit_defs(const GfwYuvArgs &Y, int bps, int taps, int n0, int dw, int dh, bool interleaved, bool fast1, int jit_model, int waves) {
-    (void)Y;
-    char b[64];
-    std::vector<std::string> defs;
-    snprintf(b, sizeof(b), "GFW_FRAME_KIND=%d", bps); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_FRAME_TAPS=%d", taps); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_JIT_WAVES=%d", waves); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_JIT_MODEL=%d", jit_model); defs.push_back(b);
-    defs.push_back(bps == 1 ? "GFW_JIT_T=uint8_t" : bps == 2 ? "GFW_JIT_T=uint16_t" : "GFW_JIT_T=float");
-    snprintf(b, sizeof(b), "GFW_JIT_N0=%d", n0); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_JIT_DW=%d", dw); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_JIT_DH=%d", dh); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_JIT_IL=%d", interleaved ? 1 : 0); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_JIT_RB=%d", jit_rows(fast1)); defs.push_back(b);
-    snprintf(b, sizeof(b), "GFW_JIT_FAST1=%d", fast1 ? 1 : 0); defs.push_back(b);
-    if (const char *extra = getenv("GFW_JIT_DEFS")) {                                    // experiments: further ';'-separated definitions for the build
-        std::string cur;
-        for (const char *p = extra; ; ++p) { if (*p == ';' || *p == 0) { if (!cur.empty()) defs.push_back(cur); cur.clear(); if (!*p) break; } else cur += *p; }
-    }
-    return defs;
-}
-static int jit_model_of(const GfwYuvArgs &Y) {
-    return (Y.model == GFW_MODEL_OPENCV_FISHEYE && (Y.extras & ~2) == 0) ? GFW_MODEL_OPENCV_FISHEYE : ((Y.extras & (16 | 32)) ? -2 : -1);
-}
-// The specialised kernel for this frame's arguments, or nullptr (not eligible / not wanted / not ready / failed): the caller then
-// launches the ahead-of-time kernel.
-static hipFunction_t jit_for(gfw_ctx *c, const GfwYuvArgs &Y, int bps, int taps, int n0, int dw, int dh, bool interleaved, bool fast1, int *grid) {
-    // every frame the fused kernel serves can be specialised: the fisheye model alone or under a digital lens (extras 0 / 2) takes the lean
-    // projection (MODEL = 1); everything else the generic-model body with the lens model, the digital lens and the feature bits as literals
-    // (MODEL = -1, or -2 with background mode 3 / the Sony mesh) — the run-time switch over 14 lens models folds to the one in use
-    if (c->jit_mode == 0 || c->kernel_variant != 0 || Y.audit || Y.ablate) return nullptr;
-    const int jit_model = jit_model_of(Y);
-    // the same clip as the previous frame?  Compared on the argument block itself with its per-frame fields blanked (the header text and the
-    // cache lookup cost ~15 us of host time, a frame's worth of validation): header, key and function are rebuilt only when it changes
-    GfwYuvArgs K = Y;
-    for (int i = 0; i < 4; ++i) { K.pl[i].src = nullptr; K.pl[i].dst = nullptr; K.pl[i].src_len = 0; K.pl[i].dst_len = 0; }
-    K.matrices = nullptr; K.p1_table = nullptr; K.p1_rho_max = 0.0f; K.p1_rho_scale = 0.0f; K.p1_eps = 0.0f; K.p1_ew = 0.0f; K.p1_em = 0.0f; K.audit = nullptr; K.grid_limit = 0;
-    memset(K.p1_lat, 0, sizeof(K.p1_lat));
-    memset(&K.kp, 0, sizeof(K.kp));
-    { const int dig = K.common.digital; memset(&K.common, 0, sizeof(K.common)); K.common.digital = dig; }
-    const int key_misc[8] = {bps, taps, n0, dw, dh, interleaved ? 1 : 0, fast1 ? 1 : 0, c->tune_grid};
-    const bool same = c->jit_key_valid && memcmp(&K, &c->jit_key, sizeof(K)) == 0 && memcmp(key_misc, c->jit_key_misc, sizeof(key_misc)) == 0;
-    if (same) {
-        if (c->jit_seen < (1 << 30)) ++c->jit_seen;
-        if (c->jit_fn) { *grid = c->jit_grid; return c->jit_fn; }                        // ready and loaded: nothing else to do
-        if (c->jit_dead) return nullptr;                                                 // decided: ahead of time for the rest of the clip, no lookup per frame
-    } else {
-        c->jit_key = K; memcpy(c->jit_key_misc, key_misc, sizeof(key_misc)); c->jit_key_valid = true;
-        c->jit_header = bake_header(Y, fast1); c->jit_seen = 1; c->jit_fn = nullptr; c->jit_dead = false;
-        c->jit_info = GfwJitInfo{GFW_JIT_UNAVAILABLE, 0.0, std::string()};
-    }
-    if (c->jit_mode == 1 && c->jit_seen < gfw_ctx::kJitAfter) return nullptr;          // one or two frames are not a clip
-    const int waves = jit_waves(n0, Y.matrix_count, jit_model, Y.extras, taps, bps, dh);
-    const std::vector<std::string> defs = jit_defs(Y, bps, taps, n0, dw, dh, interleaved, fast1, jit_model, waves);
-    hipFunction_t fn = gfw_jit_get(c->device, c->arch, defs, c->jit_header, c->jit_mode == 2, &c->jit_info);
-    if (!fn) { c->jit_dead = c->jit_info.state == GFW_JIT_FAILED || c->jit_info.state == GFW_JIT_UNAVAILABLE; return nullptr; }
-    int g = c->tune_grid > 0 ? c->tune_grid : c->num_cus * waves;
-    const int jrb = jit_rows(fast1);
-    const int per_xcd = (Y.tiles_x * ((Y.ch + 4 * jrb - 1) / (4 * jrb)) + 7) >> 3;
-    if (g > per_xcd * 8) g = per_xcd * 8;
-    *grid = (g + 7) & ~7;
-    c->jit_fn = fn; c->jit_grid = *grid;
-    return fn;
-}
-
+#include "gfw_api_bake.inc"
 static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params, const int *pixel_types,
                       const float *matrices, int matrix_count, const float *mesh, size_t mesh_len, ClipBatch *batch = nullptr) {
     if (!c) { set_error("null context"); return GFW_ERR_INVALID_ARGUMENT; }
@@ -1259,150 +756,7 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
     return GFW_OK;
 }
 
-// ---- plane coalescing (GFW_OPT_COALESCE_PLANES) --------------------------------------------------------------------------------------
-// The reference's render loop warps a frame plane by plane: three process_pixels<T> calls (Y, U, V) with the same FrameTransform, each plane through its own
-// Stabilization and therefore its own backend object (src/rendering/mod.rs:494-545).  Bound as INTEGRATION.md shows, that is three gfw_undistort_image
-// calls on three contexts per frame — which used to mean three launches of the per-plane kernel (373 us per C2 frame) while the fused frame kernel does
-// the same work in 46-52.  A PlaneGroup collects those calls: a call that is stream-ordered anyway (asynchronous context, device buffers both sides) is
-// validated, copied and held; when the frame's last plane arrives the group goes through run_planes exactly as one gfw_undistort_frame call would —
-// on the context that took plane 0 (it owns the clip state: specialised kernel, first-pass table), with every other member's stream ordered behind
-// that launch by an event.  Groups are per calling thread; anything else asked of a member context flushes its group first.
-struct PendingPlane { gfw_ctx *c; gfw_buffers b; gfw_kernel_params p; int pixel_type; };
-struct PlaneGroup {
-    std::thread::id thread;
-    int n = 0;
-    PendingPlane pl[4];
-    const float *d_matrices = nullptr;           // device-resident tables (GFW_OPT_MATRICES_ON_DEVICE != 0): the pointer every plane must repeat
-    std::vector<float> h_matrices;               // host rows: a copy of plane 0's, which later planes must equal
-    int matrix_count = 0, matrices_on_device = 0;
-    bool orphan = false;                         // its thread ended in the middle of a frame: deleted by whoever sends the planes on their way
-};
-static std::mutex g_group_mu;
-static std::vector<PlaneGroup *> g_groups;       // at most one per thread that ever coalesced
-static std::vector<gfw_ctx *> g_live;            // every context alive (frame_owner links are cleared when their target goes)
-// The calling thread's group.  A thread that ends with an empty group takes it along; one that ends in the middle of a frame leaves the planes where the contexts'
-// own flushes (gfw_synchronize, gfw_flush, gfw_destroy, the next call) find them.
-struct GroupSlot {
-    PlaneGroup *g = nullptr;
-    ~GroupSlot() {
-        if (!g) return;
-        std::lock_guard<std::mutex> lk(g_group_mu);
-        if (g->n != 0) { g->orphan = true; return; }
-        for (size_t i = 0; i < g_groups.size(); ++i) if (g_groups[i] == g) { g_groups[i] = g_groups.back(); g_groups.pop_back(); break; }
-        delete g;
-    }
-};
-static thread_local GroupSlot t_slot;
-#define t_group (t_slot.g)
-
-// Which contexts are planes of multi-plane frames?  The calling thread's previous gfw_undistort_image call is remembered; a call with the NEXT plane index on
-// another context of the same device, lens and matrix count marks both (and through the chain every plane of the frame).  So the first frame of a clip leaves
-// plane by plane, and from the second on its calls are held — while a lone Luma / R32f plane (greyscale, a mask, a depth map) is never held waiting for
-// siblings that do not exist (round 4 held it until gfw_synchronize: ADVICE r4).
-struct LastPlaneCall { gfw_ctx *c = nullptr; int plane_index = -1, matrix_count = 0; bool marked = false; };
-static thread_local LastPlaneCall t_last_plane;
-static void plane_pattern_note(gfw_ctx *c, const gfw_kernel_params *params, int matrix_count) {
-    if (!params) { t_last_plane = LastPlaneCall(); return; }
-    LastPlaneCall &L = t_last_plane;
-    if (L.c && L.c != c && params->plane_index == L.plane_index + 1 && matrix_count == L.matrix_count && !(c->multi_plane && L.marked)) {    // (nothing to learn once both are marked: no lock)
-        std::lock_guard<std::mutex> lk(g_group_mu);
-        bool alive = false;
-        for (gfw_ctx *m : g_live) alive = alive || m == L.c;
-        if (alive && L.c->device == c->device && L.c->model == c->model && L.c->digital == c->digital) { L.c->multi_plane = true; c->multi_plane = true; }
-    }
-    L.c = c; L.plane_index = params->plane_index; L.matrix_count = matrix_count; L.marked = c->multi_plane;
-}
-// Orders the streams of the owner's member contexts behind everything enqueued on the owner's stream so far.
-static int order_members_behind(gfw_ctx *owner) {
-    bool recorded = false;
-    for (gfw_ctx *m : g_live) {
-        if (m == owner || m->frame_owner != owner || !m->needs_order) continue;
-        m->needs_order = false;
-        m->last_backend = owner->last_backend;
-        if (m->stream == owner->stream) continue;
-        if (!recorded) {
-            if (!owner->group_done && hipEventCreateWithFlags(&owner->group_done, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return GFW_ERR_HIP; }
-            HIP_TRY(hipEventRecord(owner->group_done, owner->stream), GFW_ERR_HIP);
-            recorded = true;
-        }
-        HIP_TRY(hipStreamWaitEvent(m->stream, owner->group_done, 0), GFW_ERR_HIP);
-    }
-    return GFW_OK;
-}
-static int flush_held_frames(gfw_ctx *owner) {
-    if (!owner->held || owner->held->n == 0) return GFW_OK;
-    HIP_TRY(select_device(owner->device), GFW_ERR_HIP);
-    const int rc = clip_flush(owner, owner->held);
-    const int orc = order_members_behind(owner);
-    return rc != GFW_OK ? rc : orc;
-}
-// Sends the group through run_planes (as one frame).  g_group_mu held by the caller.
-static int group_launch(PlaneGroup *g) {
-    if (g->n == 0) return GFW_OK;
-    gfw_ctx *owner = g->pl[0].c;
-    gfw_buffers local[4]; gfw_kernel_params params[4]; int types[4];
-    const int n = g->n;
-    gfw_buffers *planes = local;
-    const bool hold_frames = owner->coalesce_frames > 1 && !owner->synchronous;      // (a synchronous owner — GFW_OPT_FRAME_SYNC — completes its frame before the last plane's call returns)
-    if (hold_frames) {
-        // the assembled frame may wait for more of its clip — one launch of the specialised kernel for up to coalesce_frames frames, as gfw_undistort_clip
-        // issues them; the descriptions a pending launch was validated with must outlive this call
-        if (!owner->held) owner->held = new ClipBatch();
-        if (owner->held_planes.size() < (size_t)4 * GFW_CLIP_FRAMES_MAX) owner->held_planes.resize((size_t)4 * GFW_CLIP_FRAMES_MAX);
-        planes = owner->held_planes.data() + (size_t)4 * (owner->held->n % GFW_CLIP_FRAMES_MAX);
-    }
-    for (int i = 0; i < n; ++i) { planes[i] = g->pl[i].b; params[i] = g->pl[i].p; types[i] = g->pl[i].pixel_type; }
-    // INPUT side of the ordering (round 5): a member context's caller was stream-ordered on THAT context's stream — the upload or decode of its plane, or a
-    // consumer still reading its destination, may be in flight there.  The fused launch reads and writes those buffers on the owner's stream: it waits for
-    // whatever each member's stream held when the frame was completed (every member's call lies before this point).  Frames held for a clip launch
-    // (GFW_OPT_COALESCE_FRAMES) inherit the wait: the launch is enqueued later on the same in-order stream.
-    for (int i = 1; i < n; ++i) {
-        gfw_ctx *m = g->pl[i].c;
-        if (m == owner || m->stream == owner->stream) continue;
-        bool seen = false;
-        for (int k = 1; k < i; ++k) seen = seen || g->pl[k].c->stream == m->stream;
-        if (seen) continue;
-        if (!m->inputs_ready && hipEventCreateWithFlags(&m->inputs_ready, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); for (int k = 0; k < n; ++k) g->pl[k].c->pending_planes.fetch_sub(1, std::memory_order_relaxed); g->n = 0; return GFW_ERR_HIP; }
-        if (hipEventRecord(m->inputs_ready, m->stream) != hipSuccess || hipStreamWaitEvent(owner->stream, m->inputs_ready, 0) != hipSuccess) {
-            set_error("ordering the owner's stream behind plane %d's failed", i); for (int k = 0; k < n; ++k) g->pl[k].c->pending_planes.fetch_sub(1, std::memory_order_relaxed); g->n = 0; return GFW_ERR_HIP; }
-    }
-    for (int i = 1; i < n; ++i) { g->pl[i].c->frame_owner = owner; g->pl[i].c->needs_order = true; }
-    for (int i = 0; i < n; ++i) g->pl[i].c->pending_planes.fetch_sub(1, std::memory_order_relaxed);
-    g->n = 0;
-    const float *mats = g->matrices_on_device ? g->d_matrices : g->h_matrices.data();
-    int rc;
-    if (hold_frames) {
-        rc = run_planes(owner, n, planes, params, types, mats, g->matrix_count, nullptr, 0, owner->held);
-        if (rc == GFW_OK && owner->held->n >= owner->coalesce_frames) rc = flush_held_frames(owner);
-        if (rc != GFW_OK) (void)flush_held_frames(owner);
-    } else {
-        rc = run_planes(owner, n, planes, params, types, mats, g->matrix_count, nullptr, 0);
-    }
-    if (!(owner->held && owner->held->n > 0)) { const int orc = order_members_behind(owner); if (rc == GFW_OK) rc = orc; }
-    return rc;
-}
-// Everything pending that involves `c`: the frame it is a plane of, the frames it holds as an owner, the frames its owner holds.  g_group_mu held.
-static int flush_context_locked(gfw_ctx *c) {
-    int rc = GFW_OK;
-    for (size_t gi = 0; gi < g_groups.size(); ) {
-        PlaneGroup *g = g_groups[gi];
-        bool member = false;
-        for (int i = 0; i < g->n; ++i) member = member || g->pl[i].c == c;
-        if (member) { const int r = group_launch(g); if (rc == GFW_OK) rc = r; }
-        if (g->orphan && g->n == 0) { g_groups[gi] = g_groups.back(); g_groups.pop_back(); delete g; continue; }      // its thread is gone: nobody else will
-        ++gi;
-    }
-    { const int r = flush_held_frames(c); if (rc == GFW_OK) rc = r; }
-    if (c->frame_owner && c->frame_owner != c && c->needs_order) { const int r = flush_held_frames(c->frame_owner); if (rc == GFW_OK) rc = r; }
-    return rc;
-}
-static void gfw_forget_context(gfw_ctx *c) {
-    std::lock_guard<std::mutex> lk(g_group_mu);
-    if (c->held) { delete c->held; c->held = nullptr; }
-    for (size_t i = 0; i < g_live.size(); ++i) if (g_live[i] == c) { g_live[i] = g_live.back(); g_live.pop_back(); break; }
-    for (gfw_ctx *m : g_live) if (m->frame_owner == c) { m->frame_owner = nullptr; m->needs_order = false; }
-}
-static void gfw_register_context(gfw_ctx *c) { std::lock_guard<std::mutex> lk(g_group_mu); g_live.push_back(c); }
+#include "gfw_api_coalesce.inc"
 
 extern "C" {
 
@@ -1581,6 +935,13 @@ extern "C" long gfw_debug_jit_compile(const char *arch, const char *defines, con
     if (log && cap) snprintf(log, cap, "%s", lg.c_str());
     if (n > 0 && out_path && *out_path && !gfw_jit_write_code_object(out_path, code)) return GFW_ERR_UNKNOWN;
     return n;
+}
+
+extern "C" int gfw_debug_source_id(char *out, size_t cap) {
+    if (!out || cap == 0) return GFW_ERR_INVALID_ARGUMENT;
+    const std::string id = gfw_jit_source_id();
+    snprintf(out, cap, "%s", id.c_str());
+    return (int)id.size();
 }
 
 // Build-time helper of the shipped kernel cache (tools/build_jit_cache.py; no device involved): what the library WOULD specialise a frame of these planes to —

@@ -14,7 +14,7 @@ struct GfwYuvPlane {
     float bg[4];                      // background[c] * max_pixel_value
     float limit;                      // pixel_value_limit
     int32_t src_len, dst_len;         // bytes the caller declared for the two buffers (< 2 GiB on this path): audit mode range-checks against them
-    int32_t pad_;
+    int32_t fix;                      // FIX_COLOR_RANGE (flags & 1, cpu_undistort.rs:254-260, :619-621): 0 off, 1 the luma scale (plane_index 0), 2 the chroma scale
 };
 
 #define GFW_P1_TABLE_N 8192      // intervals of the s(rho) table of the certified first pass (64 KB)
@@ -34,6 +34,7 @@ struct GfwYuvArgs {
     int32_t model;
     int32_t k_all_zero;               // k[0..3] all zero (opencv_fisheye.rs:75)
     int32_t hstretch_div, vstretch_div;
+    int32_t fix_range;                // some plane has `fix` set: the frame takes the per-pixel path (the range fix sits between the sample and the store)
     int32_t fill_bg;                  // FILL_WITH_BACKGROUND (flags & 4, cpu_undistort.rs:558-561): every pixel of the output rect is the background
     int32_t rot_on;                   // input_rotation != 0 (:485-491): the projected point is rotated about the frame centre (cos / sin / rotated frame size in `common`)
     int32_t background_mode;          // 0 solid, 1 edge repeat, 2 edge mirror, 3 margin + feather (with extras & 16)

@@ -613,13 +613,20 @@ __device__ __forceinline__ bool px_needs_sat(const float *bg, int n, float limit
     return true;
 #endif
 }
+// remap_colorrange (cpu_undistort.rs:254-260; applied to the finished pixel — sample or background — right before the cast, :619-621): every lane times the plane's
+// scale, then 16 on lanes 0 and 1.  fix: 0 off, 1 luma scale, 2 chroma scale (GfwYuvPlane.fix).
+__device__ __forceinline__ float fix_range1(float v, int fix, int c) {
+    if (fix) { v = v * (fix == 1 ? 0.85882352f : 0.87843137f); if (c < 2) v = v + 16.0f; }
+    return v;
+}
 template <typename T, int N>
-__device__ __forceinline__ void store_px(uint8_t *dst, int off, const float *v, bool sat = true) {
+__device__ __forceinline__ void store_px(uint8_t *dst, int off, const float *v, bool sat = true, int fix = 0) {
     T *d = reinterpret_cast<T *>(dst + (uint32_t)off);          // off >= 0: a zero-extended lane offset on the uniform plane base
     #pragma unroll
     for (int c = 0; c < N; ++c) {
-        if (is_f32<T>::value) d[c] = (T)v[c];                                   // f32 pixels pass through (pixel_formats.rs:247,296)
-        else d[c] = sat ? (T)gfw_f2u_sat(v[c], sizeof(T) == 1 ? 255.0f : 65535.0f) : (T)gfw_f2u_trunc(v[c]);    // `as u8/u16`
+        const float x = fix_range1(v[c], fix, c);
+        if (is_f32<T>::value) d[c] = (T)x;                                      // f32 pixels pass through (pixel_formats.rs:247,296)
+        else d[c] = sat ? (T)gfw_f2u_sat(x, sizeof(T) == 1 ? 255.0f : 65535.0f) : (T)gfw_f2u_trunc(x);    // `as u8/u16`
     }
 }
 // One plane.  32-bit byte offsets from the uniform plane base (planes are < 2 GiB, checked on the host).
@@ -635,7 +642,7 @@ __device__ __forceinline__ void sample_store_bins(int bx, int by, bool ok, const
         else
             taps_edge<T, N, I>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
     }
-    store_px<T, N>(P.dst, row_off(oy, P.dst_stride) + ox * (int)(N * sizeof(T)), out, px_needs_sat<T>(bg, N, limit));
+    store_px<T, N>(P.dst, row_off(oy, P.dst_stride) + ox * (int)(N * sizeof(T)), out, px_needs_sat<T>(bg, N, limit), P.fix);
 }
 template <typename T, int N, int I>
 __device__ __forceinline__ void sample_store(float u, float v, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy, const float *lut) {
@@ -663,7 +670,7 @@ __device__ __forceinline__ void sample_store_shared(float u, float v, bool ok, c
             if (__builtin_expect(inside, 1)) taps_inside<T, 1, I>(pl[pi].src, off0, P0.src_stride, b, pl[pi].limit, &o);
             else taps_edge<T, 1, I>(pl[pi].src, P0.src_stride, b, P0.w, P0.h, pl[pi].bg, pl[pi].limit, &o);
         }
-        store_px<T, 1>(pl[pi].dst, doff, &o);
+        store_px<T, 1>(pl[pi].dst, doff, &o, true, pl[pi].fix);
     }
 }
 // The same over named planes (baked builds: the planes are separate objects, never an array — an array indexed by a loop counter would
@@ -687,7 +694,7 @@ __device__ __forceinline__ void sample_store_shared_refs(float u, float v, bool 
             if (__builtin_expect(inside, 1)) taps_inside<T, 1, I>(P.src, off0, Pa.src_stride, b, P.limit, &o);
             else taps_edge<T, 1, I>(P.src, Pa.src_stride, b, Pa.w, Pa.h, P.bg, P.limit, &o);
         }
-        store_px<T, 1>(P.dst, doff, &o, px_needs_sat<T>(P.bg, 1, P.limit));
+        store_px<T, 1>(P.dst, doff, &o, px_needs_sat<T>(P.bg, 1, P.limit), P.fix);
     };
     one(Pa);
     if (n > 1) one(Pb);
@@ -804,7 +811,7 @@ __device__ __forceinline__ void sample_store2_bins(int bx, int by, bool ok, cons
         if (__builtin_expect((unsigned)b.sx < (unsigned)(P.w - 1) && (unsigned)b.sy < (unsigned)(P.h - 1), 1)) {
             const int off0 = row_off(b.sy, P.src_stride) + b.sx * (int)(N * sizeof(T));
             if (range_ok(aud, off0, 2 * N * sizeof(T), P.src_len) && range_ok(aud, (int64_t)off0 + P.src_stride, 2 * N * sizeof(T), P.src_len)) {
-                if constexpr (!is_f32<T>::value && (N == 1 || N == 2) && sizeof(T) == 1) {
+                if constexpr (!is_f32<T>::value && (N == 1 || N == 2) && sizeof(T) == 1) { if (!P.fix) {      // (the range fix sits between the blend and the cast: the float path below)
                     // integer-dot taps: the pixel value comes out as an integer; store it and leave
                     const uint32_t doff = (uint32_t)oy * (uint32_t)P.dst_stride + (uint32_t)ox * (uint32_t)(N * sizeof(T));
                     if (!range_ok(aud, doff, N * sizeof(T), P.dst_len)) return;
@@ -824,15 +831,14 @@ __device__ __forceinline__ void sample_store2_bins(int bx, int by, bool ok, cons
                         d[0] = (T)ou; d[1] = (T)ov;
                     }
                     return;
-                } else {
-                    taps_inside2<T, N>(P.src, off0, P.src_stride, b, limit, out);
-                }
+                } }
+                taps_inside2<T, N>(P.src, off0, P.src_stride, b, limit, out);
             }
         } else
             taps_edge2<T, N>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
     }
     const int doff = row_off(oy, P.dst_stride) + ox * (int)(N * sizeof(T));
-    if (range_ok(aud, doff, N * sizeof(T), P.dst_len)) store_px<T, N>(P.dst, doff, out, px_needs_sat<T>(bg, N, limit));
+    if (range_ok(aud, doff, N * sizeof(T), P.dst_len)) store_px<T, N>(P.dst, doff, out, px_needs_sat<T>(bg, N, limit), P.fix);
 }
 template <typename T, int N>
 __device__ __forceinline__ void sample_store2(float u, float v, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy,
@@ -860,7 +866,7 @@ __device__ __forceinline__ void sample_store_shared2(float u, float v, bool ok, 
             if (__builtin_expect(inside, 1)) taps_inside2<T, 1>(pl[pi].src, off0, P0.src_stride, b, pl[pi].limit, &o);
             else taps_edge2<T, 1>(pl[pi].src, P0.src_stride, b, P0.w, P0.h, pl[pi].bg, pl[pi].limit, &o);
         }
-        store_px<T, 1>(pl[pi].dst, doff, &o);
+        store_px<T, 1>(pl[pi].dst, doff, &o, true, pl[pi].fix);
     }
 }
 template <typename T>
@@ -888,9 +894,9 @@ __device__ __forceinline__ void sample_store_shared2_refs(float u, float v, bool
             if (n > 2) taps_edge2<T, 1>(Pc.src, Pa.src_stride, b, Pa.w, Pa.h, Pc.bg, Pc.limit, &oc);
         }
     }
-    store_px<T, 1>(Pa.dst, doff, &oa, px_needs_sat<T>(Pa.bg, 1, Pa.limit));
-    if (n > 1) store_px<T, 1>(Pb.dst, doff, &ob, px_needs_sat<T>(Pb.bg, 1, Pb.limit));
-    if (n > 2) store_px<T, 1>(Pc.dst, doff, &oc, px_needs_sat<T>(Pc.bg, 1, Pc.limit));
+    store_px<T, 1>(Pa.dst, doff, &oa, px_needs_sat<T>(Pa.bg, 1, Pa.limit), Pa.fix);
+    if (n > 1) store_px<T, 1>(Pb.dst, doff, &ob, px_needs_sat<T>(Pb.bg, 1, Pb.limit), Pb.fix);
+    if (n > 2) store_px<T, 1>(Pc.dst, doff, &oc, px_needs_sat<T>(Pc.bg, 1, Pc.limit), Pc.fix);
 }
 
 // Two planar chroma planes of identical geometry (U, V) — the C2 hot path: one set of bins / weights / offsets,
@@ -905,7 +911,7 @@ __device__ __forceinline__ void sample_store_uv2(float u, float v, bool ok, cons
             const int off0 = row_off(b.sy, PU.src_stride) + b.sx * (int)sizeof(T);
             const int top = PU.src_len < PV.src_len ? PU.src_len : PV.src_len;
             if (range_ok(aud, off0, 2 * sizeof(T), top) && range_ok(aud, (int64_t)off0 + PU.src_stride, 2 * sizeof(T), top)) {
-                if constexpr (!is_f32<T>::value && sizeof(T) == 1) {
+                if constexpr (!is_f32<T>::value && sizeof(T) == 1) { if (!PU.fix && !PV.fix) {
                     typedef HotTap<T, false> Tap;
                     const uint32_t doff = (uint32_t)oy * (uint32_t)PU.dst_stride + (uint32_t)ox * (uint32_t)sizeof(T);
                     if (!range_ok(aud, doff, sizeof(T), PU.dst_len < PV.dst_len ? PU.dst_len : PV.dst_len)) return;
@@ -915,10 +921,9 @@ __device__ __forceinline__ void sample_store_uv2(float u, float v, bool ok, cons
                     *reinterpret_cast<T *>(PU.dst + doff) = (T)hot_blend(Tap::dot(a0, w), Tap::dot(a1, w), b.ky, lim_u);
                     *reinterpret_cast<T *>(PV.dst + doff) = (T)hot_blend(Tap::dot(b0, w), Tap::dot(b1, w), b.ky, lim_v);
                     return;
-                } else {
-                    taps_inside2<T, 1>(PU.src, off0, PU.src_stride, b, lim_u, &ou);
-                    taps_inside2<T, 1>(PV.src, off0, PU.src_stride, b, lim_v, &ov);
-                }
+                } }
+                taps_inside2<T, 1>(PU.src, off0, PU.src_stride, b, lim_u, &ou);
+                taps_inside2<T, 1>(PV.src, off0, PU.src_stride, b, lim_v, &ov);
             }
         } else {
             taps_edge2<T, 1>(PU.src, PU.src_stride, b, PU.w, PU.h, &bg_u, lim_u, &ou);
@@ -927,8 +932,8 @@ __device__ __forceinline__ void sample_store_uv2(float u, float v, bool ok, cons
     }
     const int doff = row_off(oy, PU.dst_stride) + ox * (int)sizeof(T);
     if (!range_ok(aud, doff, sizeof(T), PU.dst_len < PV.dst_len ? PU.dst_len : PV.dst_len)) return;
-    store_px<T, 1>(PU.dst, doff, &ou, px_needs_sat<T>(&bg_u, 1, lim_u));
-    store_px<T, 1>(PV.dst, doff, &ov, px_needs_sat<T>(&bg_v, 1, lim_v));
+    store_px<T, 1>(PU.dst, doff, &ou, px_needs_sat<T>(&bg_u, 1, lim_u), PU.fix);
+    store_px<T, 1>(PV.dst, doff, &ov, px_needs_sat<T>(&bg_v, 1, lim_v), PV.fix);
 }
 
 // ---- branch-free sampling of a lane-row whose every tap is inside (round 4) -------------------------------------------------
@@ -1028,7 +1033,7 @@ __device__ __forceinline__ void feather_store(float ux, float uy, const Feather 
     sample_only<T, N, I>(map_c<INF_SAFE>(f.x2, mul_x, MP.den_x, MP.rcp_x), map_c<INF_SAFE>(f.y2, mul_y, MP.den_y, MP.rcp_y), P, bg, limit, lut, c2);
     #pragma unroll
     for (int c = 0; c < N; ++c) px[c] = c1[c] * f.alpha + c2[c] * (1.0f - f.alpha);
-    store_px<T, N>(P.dst, row_off(oy, P.dst_stride) + ox * (int)(N * sizeof(T)), px);
+    store_px<T, N>(P.dst, row_off(oy, P.dst_stride) + ox * (int)(N * sizeof(T)), px, true, P.fix);
 }
 
 
@@ -1136,7 +1141,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
 #if GFW_BAKE
 #define GFW_PLANE_INIT(i) GfwYuvPlane PL##i; PL##i.src = A_in.pl[i].src; PL##i.dst = A_in.pl[i].dst; PL##i.src_len = A_in.pl[i].src_len; PL##i.dst_len = A_in.pl[i].dst_len; \
     PL##i.src_stride = GFW_BK_pl##i##_src_stride; PL##i.dst_stride = GFW_BK_pl##i##_dst_stride; PL##i.w = GFW_BK_pl##i##_w; PL##i.h = GFW_BK_pl##i##_h; \
-    PL##i.bg[0] = GFW_BK_pl##i##_bg_0; PL##i.bg[1] = GFW_BK_pl##i##_bg_1; PL##i.bg[2] = GFW_BK_pl##i##_bg_2; PL##i.bg[3] = GFW_BK_pl##i##_bg_3; PL##i.limit = GFW_BK_pl##i##_limit; PL##i.pad_ = 0;
+    PL##i.bg[0] = GFW_BK_pl##i##_bg_0; PL##i.bg[1] = GFW_BK_pl##i##_bg_1; PL##i.bg[2] = GFW_BK_pl##i##_bg_2; PL##i.bg[3] = GFW_BK_pl##i##_bg_3; PL##i.limit = GFW_BK_pl##i##_limit; PL##i.fix = GFW_BK_pl##i##_fix;
     GFW_PLANE_INIT(0) GFW_PLANE_INIT(1) GFW_PLANE_INIT(2) GFW_PLANE_INIT(3)
 #undef GFW_PLANE_INIT
 #else
@@ -1521,7 +1526,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                 constexpr bool FASTROW = GFW_FASTROW && MODEL == GFW_MODEL_OPENCV_FISHEYE && N0 == 1 && !AUDIT && !GFW_BAKED_DIGITAL;
                 // (timing ablations, wrong output by design — baked builds only, GFW_ABLATE_FORCE: 1 no first pass, 2 no luma taps (the store stays), 4 no chroma, 8 no projection,
                 //  16 no luma store, 32 every pixel's matrix = the mid row's (no per-lane matrix fetch); the ahead-of-time kernels' ablations (option 16 + bits) take the per-pixel path)
-                const bool fastrow = FASTROW && (GFW_BAKE || !AF(ablate)) && !AF(hstretch_div) && !AF(vstretch_div) && !AF(rot_on);       // (a stretched or rotated clip: the per-pixel path)
+                const bool fastrow = FASTROW && (GFW_BAKE || !AF(ablate)) && !AF(fix_range) && !AF(hstretch_div) && !AF(vstretch_div) && !AF(rot_on);       // (a stretched or rotated clip: the per-pixel path)
                 if (fastrow) {
                     #pragma unroll (NPX <= 2 ? DH : 1)
                     for (int j = 0; j < DH; ++j) {
@@ -1625,6 +1630,24 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                             #pragma unroll
                             for (int i = 0; i < DW; ++i) {
                                 if (GFW_BAKE && (AF(ablate) & 2)) val[i] = (uint32_t)(bx[i] ^ by[i]) & 0xffu;
+                                else if (GFW_BAKE && (AF(ablate) & 64) && I == 2 && sizeof(T) == 2 && i == 1) {
+#if !defined(GFW_HOST_INTERPRETER)
+                                    // ablation 64 (wrong output by design): the upper bound of the north-star's "wavefront-level gather for the bilinear tap" — the pair's
+                                    // SECOND pixel takes its two row dwords from the neighbouring lane's first pixel through DPP (row_shr:1) instead of fetching them; what real
+                                    // sharing could save at most, were the neighbour's rows and columns always the right ones (they are not: DESIGN.md section 4)
+                                    const Bins2 b0 = bins2_of(bx[0], by[0]), b1 = bins2_of(bx[1], by[1]);
+                                    const int o0 = row_off(b0.sy, PL0.src_stride) + b0.sx * 2;
+                                    const uint32_t d0 = *reinterpret_cast<const uint32_t __attribute__((aligned(2))) *>(PL0.src + (uint32_t)o0);
+                                    const uint32_t d1 = *reinterpret_cast<const uint32_t __attribute__((aligned(2))) *>(PL0.src + (uint32_t)o0 + (uint32_t)PL0.src_stride);
+                                    auto blend = [&](uint32_t r0, uint32_t r1, const Bins2 &bb) {
+                                        const float xs0 = __builtin_fmaf((float)(r0 >> 16), bb.cx1, (float)(r0 & 0xffffu) * bb.cx0);
+                                        const float xs1 = __builtin_fmaf((float)(r1 >> 16), bb.cx1, (float)(r1 & 0xffffu) * bb.cx0);
+                                        return gfw_f2u_trunc(min_limit(xs0 * bb.cy0 + xs1 * bb.cy1, lim_y));
+                                    };
+                                    val[0] = blend(d0, d1, b0);
+                                    val[1] = blend((uint32_t)__builtin_amdgcn_update_dpp(0, (int)d0, 0x111, 0xf, 0xf, false), (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d1, 0x111, 0xf, 0xf, false), b1);
+#endif
+                                }
                                 else if constexpr (I == 2) val[i] = inside_value1<T>(PL0.src, PL0.src_stride, bins2_of(bx[i], by[i]), bg_y, lim_y);
                                 else val[i] = inside_value1_lut<T, I>(PL0.src, PL0.src_stride, bx[i], by[i], bg_y, lim_y, s_lut);
                             }

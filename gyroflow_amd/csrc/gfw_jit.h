@@ -9,6 +9,7 @@ enum { GFW_JIT_UNAVAILABLE = 0, GFW_JIT_COMPILING = 1, GFW_JIT_READY = 2, GFW_JI
 struct GfwJitInfo { int state; double compile_ms; std::string log; };
 
 bool gfw_jit_available();
+std::string gfw_jit_source_id();
 std::string gfw_jit_cache_name(const std::string &arch, const std::vector<std::string> &defines, const std::string &bake_header);
 hipFunction_t gfw_jit_get(int device, const std::string &arch, const std::vector<std::string> &defines, const std::string &bake_header,
                           bool wait, GfwJitInfo *info);

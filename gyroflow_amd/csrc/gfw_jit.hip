@@ -215,6 +215,7 @@ void compile_entry(Entry *e, std::string source, std::vector<std::string> opts, 
 
 // a code object to a file, through a temporary name (tools/build_jit_cache.py via gfw_debug_jit_compile: an interrupted build leaves no truncated entry behind)
 bool gfw_jit_write_code_object(const std::string &path, const std::vector<char> &code) { return looks_like_code_object(code) && write_atomically(path, code); }
+std::string gfw_jit_source_id() { return std::to_string(sizeof(GFW_JIT_SOURCE)) + ":" + key_hash(GFW_JIT_SOURCE); }
 bool gfw_jit_available() { return rtc().ok; }      // (kernels cached on disk are served without it: gfw_jit_get)
 // The file name a specialised kernel has in the on-disk caches (tools/build_jit_cache.py fills the shipped one through gfw_debug_jit_key).
 std::string gfw_jit_cache_name(const std::string &arch, const std::vector<std::string> &defines, const std::string &bake_header) {

@@ -34,6 +34,11 @@ int   gfw_debug_jit_key(int nplanes, const gfw_buffers *planes, const gfw_kernel
                         const float *host_matrices, int matrix_count, int matrices_on_device, const char *arch,
                         char *defs_out, size_t defs_cap, char *header_out, size_t header_cap, char *name_out, size_t name_cap);
 
+/* Identity of the fused kernel's source this library was built from (length and 128-bit hash of the text it embeds for run-time specialisation; the ahead-of-time
+ * kernels are compiled from the same files): measurements stored beside the repository (profiles/ *_traffic.json) name the source they were taken on, and bench.py
+ * quotes them only for the library that matches.  Returns the string's length, or a negative GFW_ERR_*. */
+int   gfw_debug_source_id(char *out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

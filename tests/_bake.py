@@ -39,7 +39,7 @@ def bake_header(frame, rb=4):
     d = {"nplanes": n, "width": w, "height": h, "out_w": ow, "out_h": oh, "cw": cw, "ch": ch, "tiles_x": (cw + 63) // 64,
          "tiles_y": (ch + 4 * rb - 1) // (4 * rb), "matrix_count": p0.matrix_count, "hrs": 1 if p0.flags & 16 else 0, "model": frame.model,
          "k_all_zero": 1 if all(p0.k[i] == 0.0 for i in range(4)) else 0, "background_mode": p0.background_mode, "extras": 0, "ablate": 0, "digital": 0,
-         "fill_bg": 1 if p0.flags & 4 else 0, "rot_on": 1 if p0.input_rotation != 0.0 else 0,
+         "fill_bg": 1 if p0.flags & 4 else 0, "rot_on": 1 if p0.input_rotation != 0.0 else 0, "fix_range": 1 if p0.flags & 1 else 0,
          "hstretch_div": 1 if (p0.input_horizontal_stretch > 0.001 and p0.input_horizontal_stretch != 1.0) else 0,
          "vstretch_div": 1 if (p0.input_vertical_stretch > 0.001 and p0.input_vertical_stretch != 1.0) else 0}
     out = ["#define GFW_BK_%s (%d)" % kv for kv in d.items()]
@@ -57,11 +57,12 @@ def bake_header(frame, rb=4):
     for i in range(4):
         if i < n:
             p, pl = pls[i]["params"], pls[i]
-            vals = {"src_stride": p.stride, "dst_stride": pl["out_size"][2], "w": pl["size"][0], "h": pl["size"][1]}
+            vals = {"src_stride": p.stride, "dst_stride": pl["out_size"][2], "w": pl["size"][0], "h": pl["size"][1],
+                    "fix": (1 if p.plane_index == 0 else 2) if p.flags & 1 else 0}
             bg = [float(np.float32(p.background[c]) * np.float32(p.max_pixel_value)) for c in range(4)]
             lim = p.pixel_value_limit
         else:
-            vals, bg, lim = {"src_stride": 0, "dst_stride": 0, "w": 0, "h": 0}, [0.0] * 4, 0.0
+            vals, bg, lim = {"src_stride": 0, "dst_stride": 0, "w": 0, "h": 0, "fix": 0}, [0.0] * 4, 0.0
         out += ["#define GFW_BK_pl%d_%s (%d)" % (i, k, v) for k, v in vals.items()]
         for c in range(4):
             fl["pl%d_bg_%d" % (i, c)] = bg[c]

@@ -296,9 +296,11 @@ def fused_eligible(fr):
             interleaved = True
         elif any(pl["pixel_type"] != pls[0]["pixel_type"] for pl in pls[1:]):
             return False
-    for pl in pls:
+    for idx, pl in enumerate(pls):
         p = pl["params"]
-        if (p.flags & abi.FLAG_FIX_COLOR_RANGE) or p.interpolation not in (2, 4, 8) or p.input_rotation != p0.input_rotation:
+        if p.interpolation not in (2, 4, 8) or p.input_rotation != p0.input_rotation:
+            return False
+        if ((p.flags ^ p0.flags) & abi.FLAG_FIX_COLOR_RANGE) or ((p.flags & abi.FLAG_FIX_COLOR_RANGE) and p.plane_index != idx):
             return False
         if (p.flags ^ p0.flags) & abi.FLAG_FILL_WITH_BACKGROUND:
             return False
@@ -332,7 +334,7 @@ def jit_waves(n0, matrix_count, jit_model, extras, taps, bps, dh):
     """gfw_api.hip jit_waves: the waves per SIMD a specialised build is compiled for (the kernel derives its tap rows in flight from them)"""
     if jit_model < 0 and (extras & (16 | 32)):
         return 6
-    if n0 == 1 and bps <= 2 and taps == 4 and (bps == 1 or dh == 2):
+    if n0 == 1 and bps <= 2 and taps == 4:
         return 6
     if n0 == 1 and bps <= 2 and taps == 8:
         return 5 if bps == 1 else 6

@@ -241,3 +241,12 @@ def test_source_and_output_rects_three_ways(trial):
     assert np.count_nonzero(ref[0] == 0x5A) > 0                                          # the border outside the output rect kept the 0x5A fill
     name = {"Luma16": "luma16", "Luma8": "luma8", "RGBA8": "rgba8", "RGBAf": "rgbaf"}[fr.planes[0]["pixel_type"]] + "_" + {2: "bilinear", 4: "bicubic", 8: "lanczos4"}[interp] + "_fisheye"
     assert np.array_equal(run_reference_cl_host(name, fr.planes[0], fr.matrices), ref[0])
+
+
+@pytest.mark.parametrize("fmt,interp", [("YUV422P16LE", 2), ("NV12", 2), ("YUV420P", 4), ("P010LE", 8), ("RGBA", 2), ("RGBAF32", 2), ("YUV444P16LE", 2)])
+def test_colour_range_fix_through_the_fused_kernel(fmt, interp):
+    """FIX_COLOR_RANGE (cpu_undistort.rs:254-260, :619-621; the render loop raises it for macOS VideoToolbox surfaces, rendering/mod.rs:507-509): the finished pixel —
+    sample or background — times the plane's scale (luma: plane_index 0), plus 16 on lanes 0 and 1, before the cast.  Fused since round 5: both forms of the
+    kernel's source against the oracle, a zoomed-out frame so that background pixels and edge samples take part."""
+    same_as_oracle(S.SyntheticFrame(fmt, 322, 186, seed=84, fov=1.6, interpolation=interp, flags=abi.FLAG_FIX_COLOR_RANGE, limited_range=True,
+                                    background_rgba=(0.3, 0.5, 0.7, 1.0)))

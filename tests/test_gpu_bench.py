@@ -80,6 +80,17 @@ def test_two_self_spawned_ranks_on_one_gpu():
     assert two["config"]["rank_checksums"][1] != two["config"]["rank_checksums"][0]
 
 
+def test_eight_self_spawned_ranks_on_one_gpu():
+    """The launcher path the driver's 8-GPU scaling run takes, with every rank on cuda:0 (small frames, gloo): eight workers rendezvous, broadcast the clip-invariant
+    block, time the same region and all-gather their checksums — the first 8-GPU run is not also the first 8-process run."""
+    out, _ = run_bench(["--gpus", "8", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--resident", "4", "--width", "640", "--height", "360",
+                        "--backend", "gloo", "--same-device"], timeout=900)
+    assert out["n_gpus"] == 8 and out["launcher"]["ranks_spawned"] == 8 and out["launcher"]["failures"] == []
+    assert out["config"]["frames_total"] == 32 and len(out["config"]["rank_checksums"]) == 8
+    assert len(set(out["config"]["rank_checksums"])) == 8              # every rank warped its own frames
+    assert out["config"]["parity_vs_oracle"] == "bit-exact"
+
+
 def test_c5_clip_checksums_do_not_depend_on_the_rank_count():
     base = ["--c5", "--frames", "70", "--resident", "8", "--warmup", "3", "--no-cpu-baseline"]
     one, _ = run_bench(base + ["--gpus", "1"])

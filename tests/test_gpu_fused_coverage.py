@@ -127,3 +127,17 @@ def test_fill_with_background_takes_the_fused_kernel(fmt, jit):
     assert warp.last_backend().startswith("yuv_fused"), warp.last_backend()
     for i, (a, b) in enumerate(zip(ref, got)):
         assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "fill, plane %d" % i)
+
+
+@pytest.mark.parametrize("fmt", ["YUV422P16LE", "NV12", "YUV420P", "P010LE", "RGBA", "GBRAPF32LE"])
+@pytest.mark.parametrize("jit", [0, 2])
+@pytest.mark.parametrize("interp", [2, 8])
+def test_colour_range_fix_takes_the_fused_kernel(fmt, jit, interp):
+    """FIX_COLOR_RANGE (cpu_undistort.rs:254-260, :619-621; rendering/mod.rs:507-509 raises it for macOS VideoToolbox) — fused since round 5: the pixel is scaled and
+    offset between the sample and the cast, background pixels included"""
+    fr = S.SyntheticFrame(fmt, 322, 186, seed=84, fov=1.6, interpolation=interp, flags=abi.FLAG_FIX_COLOR_RANGE, limited_range=True, background_rgba=(0.3, 0.5, 0.7, 1.0))
+    ref = O.run_frame(fr)
+    got = warp.run_frame(fr, jit=jit)
+    assert warp.last_backend().startswith("yuv_fused"), warp.last_backend()
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "colour-range fix, plane %d" % i)

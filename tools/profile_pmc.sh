@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/profile_r04.sh <tag> — rocprofv3 kernel-trace stats + PMC passes of the SHIPPED library under bench.py's default workload (C2, clip calls of 8 frames through the
+# tools/profile_pmc.sh <tag> — rocprofv3 kernel-trace stats + PMC passes of the SHIPPED library under bench.py's default workload (C2, clip calls of 8 frames through the
 # run-time specialised kernel: one dispatch of gfw_jit_kernel = 8 frames).  Counters in their own runs (no trace domains with --pmc).
 set -u
 cd $GRAFT_REPO_ROOT
