@@ -410,6 +410,11 @@ __device__ __forceinline__ GfwPt rd_row(float px, float py, int idx, const float
 __device__ __forceinline__ int round_i32(float x) {
     return gfw_f2i(x + copysignf(0x1.fffffep-2f, x));
 }
+// round_i32(u * 32): the product is exact (a power of two; coordinates this large or small — beyond 2^122, below 2^-120 — are not finite pixel positions and land in
+// the same saturated / zero bin either way), so the multiply and the add are ONE fused operation with the same single rounding (round 5: an instruction per coordinate)
+__device__ __forceinline__ int round32_i32(float u) {
+    return gfw_f2i(__builtin_fmaf(u, 32.0f, copysignf(0x1.fffffep-2f, u)));
+}
 // f32::min(v, limit) with the hardware's IEEE-mode v_min_f32 (non-NaN operand wins, as Rust's does): spares the
 // canonicalising v_max the compiler puts in front of fminf for a uniform operand.
 __device__ __forceinline__ float min_limit(float v, float limit) {
@@ -434,7 +439,7 @@ __device__ __forceinline__ uint32_t gfw_f2u_trunc(float v) { uint32_t r; asm("v_
 template <int I> struct Bins { int sx, sy; const float *tx, *ty; };
 template <int I> __device__ __forceinline__ int raw_bin(float u) {           // round((u - offset) * 32): the sample's column / row and its 1/32 phase (:374, :380-381)
     constexpr float OFFSET = (I == 2) ? 0.0f : (I == 4 ? 1.0f : 3.0f);
-    return round_i32((u - OFFSET) * 32.0f);
+    return round32_i32(u - OFFSET);
 }
 template <int I>
 __device__ __forceinline__ Bins<I> bins_of(int sx0, int sy0, const float *lut) {
@@ -742,7 +747,7 @@ __device__ __forceinline__ Bins2 bins2_of(int sx0, int sy0) {             // fro
     b.cy1 = (float)(sy0 & 31) * 0.03125f; b.cy0 = 1.0f - b.cy1;
     return b;
 }
-__device__ __forceinline__ Bins2 make_bins2(float u, float v) { return bins2_of(round_i32(u * 32.0f), round_i32(v * 32.0f)); }
+__device__ __forceinline__ Bins2 make_bins2(float u, float v) { return bins2_of(round32_i32(u), round32_i32(v)); }
 // Taps that straddle the source rect: out-of-rect taps read `bg`, out-of-rect rows contribute bg*cy
 // (cpu_undistort.rs:392-409), in the reference's exact operation order.
 template <typename T, int N>
@@ -765,7 +770,7 @@ __device__ __forceinline__ void taps_edge2(const uint8_t *src, int stride, const
 }
 // All four taps inside.  For the integer pixel types every tap is >= +0, so the reference's leading zero-adds
 // (xsum = 0 + p*c, sum = 0 + xs*cy) are exact identities and are dropped; for f32 pixels (-0, negative values) they stay.
-template <typename T, int N>
+template <typename T, int N, bool CAST_FOLLOWS = false>     // CAST_FOLLOWS: the caller truncates the value to the integer type next (no colour-range fix in between)
 __device__ __forceinline__ void taps_inside2(const uint8_t *src, int off0, int stride, const Bins2 &b, float limit, float *out) {
     // all four taps inside: off0 >= 0 and the plane is < 2 GiB (host-checked), so both rows are zero-extended 32-bit lane offsets on the
     // uniform plane base — the saddr + voffset form of global_load, one address instruction per row instead of a 64-bit add chain
@@ -787,7 +792,11 @@ __device__ __forceinline__ void taps_inside2(const uint8_t *src, int off0, int s
             // fused form rounds nowhere the reference's separate multiply and add would
             const float xs0 = __builtin_fmaf((float)row0[N + c], b.cx1, (float)row0[c] * b.cx0);
             const float xs1 = __builtin_fmaf((float)row1[N + c], b.cx1, (float)row1[c] * b.cx0);
-            out[c] = min_limit(xs0 * b.cy0 + xs1 * b.cy1, limit);
+            // min(sum, pixel_value_limit) ahead of a truncating cast is idle when the limit is the type's maximum: the weights of a row and of the two rows sum to 1 exactly
+            // (k/32 and 1 - k/32), so the real sum is <= 65535 (255), each product and the sum round up by at most one part in 2^24: sum <= 65535.004 < 65536, and the cast
+            // truncates.  Known at compile time in a baked build only.
+            const float sum = xs0 * b.cy0 + xs1 * b.cy1;
+            out[c] = (GFW_BAKE && CAST_FOLLOWS && limit >= (sizeof(T) == 1 ? 255.0f : 65535.0f)) ? sum : min_limit(sum, limit);
         }
     }
 }
@@ -843,7 +852,7 @@ __device__ __forceinline__ void sample_store2_bins(int bx, int by, bool ok, cons
 template <typename T, int N>
 __device__ __forceinline__ void sample_store2(float u, float v, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy,
                                               unsigned long long *aud = nullptr) {
-    sample_store2_bins<T, N>(round_i32(u * 32.0f), round_i32(v * 32.0f), ok, P, bg, limit, ox, oy, aud);       // (garbage bins of a point that is not ok are never used)
+    sample_store2_bins<T, N>(round32_i32(u), round32_i32(v), ok, P, bg, limit, ox, oy, aud);       // (garbage bins of a point that is not ok are never used)
 }
 // Planar planes of identical geometry (U and V; or G,B,R,A of a planar float frame): one set of bins / weights /
 // offsets, one gather pair per plane.
@@ -954,7 +963,7 @@ __device__ __forceinline__ uint32_t inside_value1(const uint8_t *src, int stride
         return hot_blend(Tap::dot(r0, w), Tap::dot(r1, w), b.ky, limit);
     } else {
         float o;
-        taps_inside2<T, 1>(src, off0, stride, b, limit, &o);
+        taps_inside2<T, 1, true>(src, off0, stride, b, limit, &o);
         if constexpr (is_f32<T>::value) return gfw_f2u(o);
         else return px_needs_sat<T>(bg, 1, limit) ? gfw_f2u_sat(o, 65535.0f) : gfw_f2u_trunc(o);
     }
@@ -1427,7 +1436,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                         v_fast[i] = __builtin_fmaf(ty, Dn[i], Tn[i]);
                         const float n = rintf(v_fast[i]);
                         good[i] = gfw_lanes(fabsf(v_fast[i] - n) < Q.gap);           // (NaN: not certified)
-                        sy[i] = max(min(gfw_f2i(n), (int)Q.lim), 0);
+                        sy[i] = max(min(gfw_f2i(n), min((int)Q.lim, AF(matrix_count) - 1)), 0);      // (both upper clamps at once: :469 and :482)
                     }
                 } else {
                     #pragma unroll
@@ -1442,7 +1451,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     const int lx = cx * DW + i;
                     const bool live = WHOLE || (lane_ok && lx < AF(out_w) && ly < AF(out_h));
                     if (!WHOLE) good[i] = good[i] | gfw_lanes(!live);
-                    sy[i] = live ? min(sy[i], AF(matrix_count) - 1) : 0;
+                    sy[i] = live ? ((LAT && lat) ? sy[i] : min(sy[i], AF(matrix_count) - 1)) : 0;
                     if constexpr (DW != 2) s_rows[q][tid][i] = (unsigned short)sy[i];
                     if (AUDIT && gfw_vote_lane(good[i], lane) && live) {           // audit: every certificate is checked
                         const float ox = (float)lx + L.t2x;
@@ -1523,7 +1532,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                 // The branch-free row (round 4; specialised fisheye, bilinear, single-channel luma): a lane's DW pixels of one line are projected with
                 // rd_lean_nobranch, mapped and binned without a divergent branch; the wave is asked ONCE per stage — `__any(rare)` sends the odd lanes
                 // through rd<> itself, `__all(interior)` picks between the branch-free taps (pair stored as one word) and sample_store2.
-                constexpr bool FASTROW = GFW_FASTROW && MODEL == GFW_MODEL_OPENCV_FISHEYE && N0 == 1 && !AUDIT && !GFW_BAKED_DIGITAL;
+                constexpr bool FASTROW = GFW_FASTROW && MODEL == GFW_MODEL_OPENCV_FISHEYE && N0 == 1 && !AUDIT && !GFW_BAKED_DIGITAL;      // (packed RGBAf through this row measured 69.8 against 64.0 us per C4 frame: profiles/r05_ab_c4_fastrow.txt)
                 // (timing ablations, wrong output by design — baked builds only, GFW_ABLATE_FORCE: 1 no first pass, 2 no luma taps (the store stays), 4 no chroma, 8 no projection,
                 //  16 no luma store, 32 every pixel's matrix = the mid row's (no per-lane matrix fetch); the ahead-of-time kernels' ablations (option 16 + bits) take the per-pixel path)
                 const bool fastrow = FASTROW && (GFW_BAKE || !AF(ablate)) && !AF(fix_range) && !AF(hstretch_div) && !AF(vstretch_div) && !AF(rot_on);       // (a stretched or rotated clip: the per-pixel path)
@@ -1541,7 +1550,9 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                             #pragma unroll
                             for (int i = 0; i < DW; ++i) {
                                 const int lx = cx * DW + i;
-                                ox[i] = (float)lx + L.t2x; oy[i] = (float)ly + L.t2y;
+                                // (translation2d == +0 in a baked build: x + (+0) is x for every x >= +0, and (float)(lx + 1) is (float)lx + 1 below 2^24 — a conversion and three adds per pair)
+                                if (GFW_BAKE && gfw_f2u(L.t2x) == 0u) ox[i] = (i == 0) ? (float)lx : ox[0] + (float)i; else ox[i] = (float)lx + L.t2x;
+                                if (GFW_BAKE && gfw_f2u(L.t2y) == 0u) oy[i] = (i == 0) ? (float)ly : oy[0]; else oy[i] = (float)ly + L.t2y;
                                 row[i] = two_pass ? (DW == 2 ? (int)(i == 0 ? (rows2 & 0xffffu) : (rows2 >> 16)) : (int)s_rows[r * DH + j][tid][i])
                                                   : min(default_row<MODEL>(ox[i], oy[i], A), AF(matrix_count) - 1);
                             }
@@ -1763,6 +1774,20 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                                 const int doff = row_off(cy, PL1.dst_stride) + cx * (int)sizeof(T);
                                 store_value1<T>(PL1.dst, doff, vu); store_value1<T>(PL2.dst, doff, vv);
                             }
+                            chroma_done = true;
+                        }
+                    }
+                    if constexpr (FASTROW && I == 2 && is_f32<T>::value && N0 == 1 && !INTERLEAVED_UV) if (fastrow && AF(nplanes) >= 2) {
+                        // planar float frames (the EXR route: G, B, R, A planes of one geometry — round 5): one vote, then every further plane's interior taps with one set of bins
+                        const Bins2 bc = make_bins2(cu, cv);
+                        if (__builtin_expect(gfw_all_lanes(okm0 & gfw_lanes((unsigned)bc.sx < (unsigned)(PL1.w - 1)) & gfw_lanes((unsigned)bc.sy < (unsigned)(PL1.h - 1))), 1)) {
+                            const uint32_t va = inside_value1<T>(PL1.src, PL1.src_stride, bc, PL1.bg, PL1.limit);
+                            const uint32_t vb = AF(nplanes) > 2 ? inside_value1<T>(PL2.src, PL1.src_stride, bc, PL2.bg, PL2.limit) : 0u;
+                            const uint32_t vc = AF(nplanes) > 3 ? inside_value1<T>(PL3.src, PL1.src_stride, bc, PL3.bg, PL3.limit) : 0u;
+                            const int doff = row_off(cy, PL1.dst_stride) + cx * (int)sizeof(T);
+                            store_value1<T>(PL1.dst, doff, va);
+                            if (AF(nplanes) > 2) store_value1<T>(PL2.dst, doff, vb);
+                            if (AF(nplanes) > 3) store_value1<T>(PL3.dst, doff, vc);
                             chroma_done = true;
                         }
                     }

@@ -96,3 +96,50 @@ def test_every_certificate_with_an_r_limit_and_shifted_coordinates(seed):
     if a["certified"]:
         assert a["gap_px"] < a["eps_px"], a
     assert all(np.array_equal(x, y) for x, y in zip(O.run_frame(fr), outs[0]))
+
+
+# ---- adversarial clips for the derived certificate (round 5) ---------------------------------------------------------------------------------------------------
+# Each case aims at one premise of DESIGN.md section 2c: theta_d's polynomial P nearly vanishing inside the table's range (the exact path's relative error explodes: no
+# certificate may be issued), a very long and a very short focal length (rho tiny / the table at its 64 cap), a strong roll with a long readout (the lattice's curvature term
+# beyond its limit: the frame must fall back to the per-pixel form, not certify wrongly), large coefficients of either sign, a principal point far off centre.  Frames are
+# large enough (1280 x 720) that the lattice form is what an ordinary lens gets there, so the adversarial ones are compared with it on its own ground.
+def adversarial_clip(case):
+    w, h = 1280, 720
+    lens = S.gopro_style_lens(w, h)
+    kw = dict(seed=900 + case, fov=1.0, readout_ms=16.0)
+    if case == 0:      # P(theta) = 1 + k0 t^2 crosses zero near t = 0.95: inside the frame's range
+        lens["k"] = [-1.1, 0.0, 0.0, 0.0] + [0.0] * 8
+    elif case == 1:    # P with a deep minimum (0.11) inside the range: the exact path's error amplification kappa grows ninefold, E with it; whatever is certified must hold
+        lens["k"] = [-1.6, 0.72, 0.0, 0.0] + [0.0] * 8
+    elif case == 2:    # very long lens: every ray within a few degrees, rho ~ 1e-3
+        lens["f"] = (20.0 * w,) * 2
+    elif case == 3:    # very short lens: the corner ray beyond 80 degrees, the table at its cap
+        lens["f"] = (0.12 * w,) * 2
+        kw["fov"] = 0.5
+    elif case == 4:    # strong roll over a long readout: rows of a wave's span far apart, large curvature of v
+        kw.update(readout_ms=60.0, constant_quat=None, timestamp_ms=3210.0, fov=2.0)
+    elif case == 5:    # large coefficients, alternating signs
+        lens["k"] = [0.6, -0.9, 0.7, -0.25] + [0.0] * 8
+    elif case == 6:    # principal point far off centre: rho's range lopsided, linear forms with large constant terms
+        lens["c"] = (0.1 * w, 0.92 * h)
+    elif case == 7:    # horizontal shutter with a zoomed-out frame
+        kw.update(horizontal_rs=True, fov=2.5)
+    return S.SyntheticFrame("YUV422P16LE", w, h, lens=lens, **kw)
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_adversarial_clips_never_get_a_wrong_certificate(case):
+    fr = adversarial_clip(case)
+    p0 = fr.planes[0]["params"]
+    served = _emu.p1_table(p0, fr.matrices, p0.matrix_count)
+    if case == 0:
+        assert served is None, "a lens whose theta_d polynomial vanishes inside the range must not be certified"
+    if served is None:
+        outs = _emu.run_frames([fr])                      # the exact first pass: still the oracle's frame
+        assert all(np.array_equal(x, y) for x, y in zip(O.run_frame(fr), outs[0]))
+        return
+    outs, a = _emu.run_frames([fr], audit=True)
+    assert a["wrong"] == 0 and a["queue_overflow"] == 0 and a["out_of_range"] == 0, a
+    if a["certified"]:
+        assert a["gap_px"] < a["eps_px"], a
+    assert all(np.array_equal(x, y) for x, y in zip(O.run_frame(fr), outs[0]))
