@@ -628,6 +628,8 @@ static void timeline_dump(gfw_ctx *c, hipFunction_t fn) {
         (void)hipStreamSynchronize(c->stream);
         if (gfw_jit_read_symbol(fn, "gfw_tl", host.data(), host.size() * 8))
             if (FILE *f = fopen(tl_file, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+        if (gfw_jit_read_symbol(fn, "gfw_tl_blocks", host.data(), host.size() * 8))       // GFW_TIMELINE = 2 builds: the clocks of the branch-free row's blocks
+            if (FILE *f = fopen((std::string(tl_file) + ".blocks").c_str(), "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
     }
 }
 static int clip_flush(gfw_ctx *c, ClipBatch *b) {

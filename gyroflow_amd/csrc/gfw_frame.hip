@@ -105,6 +105,10 @@
 #ifndef GFW_BAKE
 #define GFW_BAKE 0               // 1: the clip-invariant arguments are the literals GFW_BK_<field> of the bake header in front of this file (read through AF())
 #endif
+#ifndef GFW_TLB
+#define GFW_TLB(k) do {} while (0)
+#define GFW_TLB_START() do {} while (0)
+#endif
 #ifndef GFW_TIMELINE
 #define GFW_TIMELINE 0           // diagnosis builds only: per-wave start / end / phase clocks and HW_ID into a device array that the 60th launch
                                  // dumps to $GFW_TIMELINE_FILE (tools/analyze_timeline.py)
@@ -578,19 +582,31 @@ __device__ __forceinline__ void taps_inside(const uint8_t *src, int off0, int st
     float sum[N];
     #pragma unroll
     for (int c = 0; c < N; ++c) sum[c] = 0.0f;
+    // multi-channel and float pixels: the rows in groups too — a group's fetches first, then its arithmetic (left to one unrolled loop the shipped compiler issued
+    // `fetch, wait` row by row for the interleaved chroma of NV12 / P010: tests/test_kernel_fetch_clusters.py).  Integer pixels only: 16-byte float4 taps would hold I * 4 registers per row.
+    constexpr int RG = is_f32<T>::value ? 1 : (I * N * (int)sizeof(T) <= 16 ? (I < 4 ? I : 4) : 2);
     #pragma unroll
-    for (int yp = 0; yp < I; ++yp) {
-        const T *row = reinterpret_cast<const T *>(src + (uint32_t)(off0 + yp * stride));
-        float xs[N];
+    for (int y0 = 0; y0 < I; y0 += RG) {
+        T v[RG][I * N];
         #pragma unroll
-        for (int c = 0; c < N; ++c) xs[c] = 0.0f;
-        #pragma unroll
-        for (int xp = 0; xp < I; ++xp) {
+        for (int r = 0; r < RG; ++r) {
+            const T *row = reinterpret_cast<const T *>(src + (uint32_t)(off0 + (y0 + r) * stride));
             #pragma unroll
-            for (int c = 0; c < N; ++c) xs[c] = xs[c] + (float)row[xp * N + c] * cx[xp];
+            for (int e = 0; e < I * N; ++e) v[r][e] = row[e];
         }
         #pragma unroll
-        for (int c = 0; c < N; ++c) sum[c] = sum[c] + xs[c] * b.ty[yp];
+        for (int r = 0; r < RG; ++r) {
+            float xs[N];
+            #pragma unroll
+            for (int c = 0; c < N; ++c) xs[c] = 0.0f;
+            #pragma unroll
+            for (int xp = 0; xp < I; ++xp) {
+                #pragma unroll
+                for (int c = 0; c < N; ++c) xs[c] = xs[c] + (float)v[r][xp * N + c] * cx[xp];
+            }
+            #pragma unroll
+            for (int c = 0; c < N; ++c) sum[c] = sum[c] + xs[c] * b.ty[y0 + r];
+        }
     }
     #pragma unroll
     for (int c = 0; c < N; ++c) out[c] = fminf(sum[c], limit);
@@ -1126,6 +1142,13 @@ __device__ __forceinline__ float pass1_node(float ox, float oy, const Mid &M, co
 #if GFW_TIMELINE
 }  // namespace
 extern "C" { __device__ unsigned long long gfw_tl[8192 * 8]; }      // external name: the host reads it by symbol (hipModuleGetGlobal in a run-time build)
+#if GFW_TIMELINE >= 2
+// GFW_TIMELINE = 2: where a wave's life goes INSIDE the branch-free row (round 5): per wave, accumulated shader clocks of [row start .. matrix rows arrived],
+// [.. projection done], [.. luma taps issued and stored], [.. chroma done]; [4] rows counted.  A forced `s_waitcnt vmcnt(0)` separates the first two (diagnosis only).
+extern "C" { __device__ unsigned long long gfw_tl_blocks[8192 * 8]; }
+#define GFW_TLB(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long tlb_now_ = __builtin_readcyclecounter(); tl_blk[k] += tlb_now_ - tl_mark; tl_mark = tlb_now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define GFW_TLB_START() do { __builtin_amdgcn_sched_barrier(0); tl_mark = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
 namespace {
 #endif
 // The kernel body.  `clip` (baked builds only): the per-frame pointers of the frames of one launch — the frames of a clip share every
@@ -1310,6 +1333,9 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
 #if GFW_TIMELINE
     const unsigned long long tl_ready = wall_clock64();           // set-up done (LDS tables, the frames' certificates, uniforms): the tile walk starts
     unsigned long long tl_p1 = 0, tl_p3 = 0, tl_units = 0;
+#if GFW_TIMELINE >= 2
+    unsigned long long tl_blk[5] = {0, 0, 0, 0, 0}, tl_mark = 0;
+#endif
 #endif
 #if GFW_PRIO_MODE
     int prio_step = 1;                                // lane-rows per priority level (a GFW_PRIO_SPAN-th of this wave's work)
@@ -1540,6 +1566,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     #pragma unroll (NPX <= 2 ? DH : 1)
                     for (int j = 0; j < DH; ++j) {
                         const int ly = cy * DH + j;
+                        GFW_TLB_START();
                         float pu[DW], pv[DW]; bool odd[DW]; bool any_odd = false;
                         GfwVote okp[DW];                 // which lanes hold a valid point: a wave mask in scalar registers (a per-lane bool would live in a VGPR across the vote below)
                         {
@@ -1567,7 +1594,12 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                                 #pragma unroll
                                 for (int i = 0; i < DW; ++i) { ma[i] = float4{M.m0, M.m1, M.m2, M.m3}; mb[i] = float4{M.m4, M.m5, M.m6, M.m7}; m8[i] = M.m8; }
                             }
+#if GFW_TIMELINE >= 2
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            GFW_TLB(0);
+#endif
                             rd_lean_nobranch<DW>(ox, oy, ma, mb, m8, L, A, pu, pv, odd);         // (the pair side by side or one after the other: 46.2 = 46.4 us)
+                            GFW_TLB(1);
                             if (GFW_BAKE && (AF(ablate) & 8)) {
                                 #pragma unroll
                                 for (int i = 0; i < DW; ++i) { pu[i] = ox[i] * 0.5f; pv[i] = oy[i] * 0.5f; odd[i] = false; }
@@ -1676,6 +1708,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                                 }
                             }
                         }
+                        GFW_TLB(2);
                     }
                 } else {
                 #pragma unroll (NPX <= 2 ? NPX : 1)
@@ -1815,6 +1848,9 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                         else sample_store_shared<T, I>(cu, cv, ok0, A_in.pl, 1, AF(nplanes) - 1, cx, cy, s_lut);
                     }
                 }
+#if GFW_TIMELINE >= 2
+                if (fastrow) { GFW_TLB(3); tl_blk[4] += 1; }
+#endif
             }
         }
         if (FAST1 && two_pass) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // s_rows is rewritten by the next tile
@@ -1830,6 +1866,11 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         unsigned long long *o = gfw_tl + ((size_t)blockIdx.x * 4 + wave) * 8;
         o[0] = tl_start; o[1] = wall_clock64(); o[2] = tl_p1; o[3] = tl_p3; o[4] = tl_units;
         o[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); o[6] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); o[7] = blockIdx.x | ((tl_ready - tl_start) << 32);
+#if GFW_TIMELINE >= 2
+        unsigned long long *ob = gfw_tl_blocks + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int k = 0; k < 5; ++k) ob[k] = tl_blk[k];
+        ob[5] = tl_p1; ob[6] = tl_p3; ob[7] = tl_units;
+#endif
     }
 #endif
 }
