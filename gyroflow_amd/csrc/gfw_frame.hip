@@ -33,7 +33,7 @@
 // compiled once per tap count and sample type), background_mode 0-3, input rotation and the fill flag (round 4; not the colour-range fix), translation3d == 0 (other lens models, refraction, digital lens, IBIS/OIS terms, the lens-correction
 // blend, background mode 3 and the Sony mesh are served by the generic-model instantiations with the exact first pass), any stretch (round 4),
 // full-plane rects; Luma8/Luma16 (+UV8/UV16) planes with chroma planes of identical geometry, one
-// packed RGB(A)8/16 / BGRA8 / AYUV16 / RGBAf plane, or planar R32f planes.
+// packed RGB(A)8/16 / BGRA8 / AYUV16 / RGBAf / RGBAf16 plane, or planar R32f planes.
 #ifndef GFW_JIT
 #define GFW_JIT 0                // 1: this file is being compiled at run time by hiprtc (gfw_jit.hip) into ONE baked instantiation: device code only
 #endif
@@ -455,8 +455,12 @@ __device__ __forceinline__ Bins<I> bins_of(int sx0, int sy0, const float *lut) {
 }
 template <int I>
 __device__ __forceinline__ Bins<I> make_bins(float u, float v, const float *lut) { return bins_of<I>(raw_bin<I>(u), raw_bin<I>(v), lut); }
+// float samples — f32, and since round 5 the f16 of packed RGBAf16 (pixel_formats.rs:227-246: half::f16 to_f32 on load, from_f32 = IEEE round-to-nearest-even on store:
+// the hardware's v_cvt_f32_f16 / v_cvt_f16_f32): every tap is converted to f32 first, so the float arithmetic of a sample (leading zero adds kept: signed zeros, no
+// saturation) is the same for both; only the load and the store know the width.
 template <typename T> struct is_f32 { static constexpr bool value = false; };
 template <> struct is_f32<float> { static constexpr bool value = true; };
+template <> struct is_f32<_Float16> { static constexpr bool value = true; };
 // Taps that straddle the source rect: out-of-rect taps read `bg`, out-of-rect rows contribute bg*cy
 // (cpu_undistort.rs:391-411), in the reference's exact operation order.
 template <typename T, int N, int I>
@@ -1001,7 +1005,8 @@ __device__ __forceinline__ GfwVote lut_interior(int bx, int by, int w, int h) { 
 }
 template <typename T>
 __device__ __forceinline__ void store_value1(uint8_t *dst, int off, uint32_t v) {
-    if constexpr (is_f32<T>::value) *reinterpret_cast<uint32_t *>(dst + (uint32_t)off) = v;
+    if constexpr (is_f32<T>::value && sizeof(T) == 4) *reinterpret_cast<uint32_t *>(dst + (uint32_t)off) = v;
+    else if constexpr (is_f32<T>::value) *reinterpret_cast<T *>(dst + (uint32_t)off) = (T)__builtin_bit_cast(float, v);      // (f16 planes: the f32 bit pattern, narrowed)
     else *reinterpret_cast<T *>(dst + (uint32_t)off) = (T)v;
 }
 // two horizontally adjacent samples of an integer plane leave as ONE store (the pair's address need not be aligned to the pair: global memory takes it)
@@ -1934,11 +1939,11 @@ static hipError_t launch_tn(const GfwYuvArgs &A, int dw, int dh, bool interleave
     }
     return launch_mt<MODEL, T, N0, I, GFW_YUV_RB_EXACT, false, false>(A, dw, dh, interleaved, s);
 }
-// This translation unit is compiled once per (sample kind, tap count): -DGFW_FRAME_KIND=1|2|4 (u8, u16, f32) and
+// This translation unit is compiled once per (sample kind, tap count): -DGFW_FRAME_KIND=1|2|3|4 (u8, u16, f16, f32) and
 // -DGFW_FRAME_TAPS=2|4|8 (bilinear, bicubic, Lanczos4), so that the nine families of instantiations build in parallel;
 // gfw_kernels.hip dispatches on both.
 #if !defined(GFW_FRAME_KIND) || !defined(GFW_FRAME_TAPS)
-#error "compile with -DGFW_FRAME_KIND=1|2|4 -DGFW_FRAME_TAPS=2|4|8"
+#error "compile with -DGFW_FRAME_KIND=1|2|3|4 -DGFW_FRAME_TAPS=2|4|8"
 #endif
 template <int MODEL>
 static hipError_t launch_m(const GfwYuvArgs &A, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s) {
@@ -1950,6 +1955,8 @@ static hipError_t launch_m(const GfwYuvArgs &A, int n0, int dw, int dh, bool int
     if (n0 == 1) return launch_tn<MODEL, uint16_t, 1>(A, dw, dh, interleaved, fast1, s);
     if (n0 == 3) return launch_tn<MODEL, uint16_t, 3>(A, dw, dh, interleaved, fast1, s);
     if (n0 == 4) return launch_tn<MODEL, uint16_t, 4>(A, dw, dh, interleaved, fast1, s);
+#elif GFW_FRAME_KIND == 3
+    if (n0 == 4) return launch_tn<MODEL, _Float16, 4>(A, dw, dh, interleaved, fast1, s);      // packed RGBAf16
 #else
     if (n0 == 1) return launch_tn<MODEL, float, 1>(A, dw, dh, interleaved, fast1, s);
     if (n0 == 4) return launch_tn<MODEL, float, 4>(A, dw, dh, interleaved, fast1, s);

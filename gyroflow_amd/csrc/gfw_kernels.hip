@@ -19,14 +19,14 @@ hipError_t gfw_launch_plane(const GfwPlane &A, const GfwCommon &C, hipStream_t s
 
 // ---------------------------------------------------------------------------- fused frame kernel dispatch
 #define GFW_DECL_YUV(K, I) hipError_t gfw_launch_yuv_kind##K##_taps##I(const GfwYuvArgs &A, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s);
-GFW_DECL_YUV(1, 2) GFW_DECL_YUV(1, 4) GFW_DECL_YUV(1, 8) GFW_DECL_YUV(2, 2) GFW_DECL_YUV(2, 4) GFW_DECL_YUV(2, 8) GFW_DECL_YUV(4, 2) GFW_DECL_YUV(4, 4) GFW_DECL_YUV(4, 8)
+GFW_DECL_YUV(1, 2) GFW_DECL_YUV(1, 4) GFW_DECL_YUV(1, 8) GFW_DECL_YUV(2, 2) GFW_DECL_YUV(2, 4) GFW_DECL_YUV(2, 8) GFW_DECL_YUV(4, 2) GFW_DECL_YUV(4, 4) GFW_DECL_YUV(4, 8) GFW_DECL_YUV(3, 2) GFW_DECL_YUV(3, 4) GFW_DECL_YUV(3, 8)
 int gfw_yuv_rows_per_lane(bool fast1, int tune_rb) {
     (void)tune_rb;
     return fast1 ? GFW_YUV_RB_FAST : GFW_YUV_RB_EXACT;
 }
 hipError_t gfw_launch_yuv(const GfwYuvArgs &A, int sample_kind, int taps, int n0, int dw, int dh, bool interleaved, bool fast1, hipStream_t s) {
 #define GFW_CASE_YUV(K, I) if (sample_kind == K && taps == I) return gfw_launch_yuv_kind##K##_taps##I(A, n0, dw, dh, interleaved, fast1, s);
-    GFW_CASE_YUV(1, 2) GFW_CASE_YUV(1, 4) GFW_CASE_YUV(1, 8) GFW_CASE_YUV(2, 2) GFW_CASE_YUV(2, 4) GFW_CASE_YUV(2, 8) GFW_CASE_YUV(4, 2) GFW_CASE_YUV(4, 4) GFW_CASE_YUV(4, 8)
+    GFW_CASE_YUV(1, 2) GFW_CASE_YUV(1, 4) GFW_CASE_YUV(1, 8) GFW_CASE_YUV(2, 2) GFW_CASE_YUV(2, 4) GFW_CASE_YUV(2, 8) GFW_CASE_YUV(4, 2) GFW_CASE_YUV(4, 4) GFW_CASE_YUV(4, 8) GFW_CASE_YUV(3, 2) GFW_CASE_YUV(3, 4) GFW_CASE_YUV(3, 8)
     return hipErrorInvalidValue;
 }
 

@@ -226,7 +226,7 @@ def p1_table(p0, matrices, matrix_count):
 
 
 SAMPLE_KIND = {"Luma8": (1, 1), "Luma16": (2, 1), "RGB8": (1, 3), "RGBA8": (1, 4), "BGRA8": (1, 4), "RGB16": (2, 3), "RGBA16": (2, 4), "AYUV16": (2, 4),
-               "RGBAf": (4, 4), "R32f": (4, 1)}          # plane 0's sample bytes and channel count (build_yuv_args); RGBAf16 / UV planes first: per-plane kernel
+               "RGBAf": (4, 4), "R32f": (4, 1), "RGBAf16": (3, 4)}          # plane 0's sample kind (bytes; 3 = two-byte float) and channel count (build_yuv_args); UV planes first: per-plane kernel
 
 
 def launch_shape(fr):
@@ -309,7 +309,7 @@ def fused_eligible(fr):
         for st in (p.input_horizontal_stretch, p.input_vertical_stretch):
             if st > 0.001 and st != 1.0 and p.lens_correction_amount < 1.0:
                 return False
-        if bps == 2 and ((p.stride | pl["out_size"][2]) & 1):
+        if bps in (2, 3) and ((p.stride | pl["out_size"][2]) & 1):
             return False
         if bps == 4 and ((p.stride | pl["out_size"][2]) & 3):
             return False
@@ -366,7 +366,7 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=F
     fast1 = p1 is not None
     rb = 4 if fast1 else 1
     defs = {"GFW_FRAME_KIND": bps, "GFW_FRAME_TAPS": p0.interpolation, "GFW_JIT_WAVES": jit_waves(n0, p0.matrix_count, jit_model, extras, p0.interpolation, bps, dh), "GFW_JIT_MODEL": jit_model,
-            "GFW_JIT_T": {1: "uint8_t", 2: "uint16_t", 4: "float"}[bps], "GFW_JIT_N0": n0, "GFW_JIT_DW": dw, "GFW_JIT_DH": dh,
+            "GFW_JIT_T": {1: "uint8_t", 2: "uint16_t", 3: "_Float16", 4: "float"}[bps], "GFW_JIT_N0": n0, "GFW_JIT_DW": dw, "GFW_JIT_DH": dh,
             "GFW_JIT_IL": 1 if il else 0, "GFW_JIT_RB": rb, "GFW_JIT_FAST1": 1 if fast1 else 0}
     header = _bake.bake_header(fr0, rb=rb)
     header, n1 = re.subn(r"#define GFW_BK_extras \(0\)", "#define GFW_BK_extras (%d)" % extras, header)

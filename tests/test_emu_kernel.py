@@ -250,3 +250,11 @@ def test_colour_range_fix_through_the_fused_kernel(fmt, interp):
     kernel's source against the oracle, a zoomed-out frame so that background pixels and edge samples take part."""
     same_as_oracle(S.SyntheticFrame(fmt, 322, 186, seed=84, fov=1.6, interpolation=interp, flags=abi.FLAG_FIX_COLOR_RANGE, limited_range=True,
                                     background_rgba=(0.3, 0.5, 0.7, 1.0)))
+
+
+@pytest.mark.parametrize("interp", [2, 4, 8])
+@pytest.mark.parametrize("fov", [1.0, 1.7])
+def test_packed_half_float_pixels_through_the_fused_kernel(interp, fov):
+    """RGBAf16 (pixel_formats.rs:227-246: half::f16 to_f32 on load, from_f32 — round to nearest even — on store) on the fused kernel since round 5: the f32 packed path
+    with the conversions at the fetch and the store; both kernel forms against the oracle, interior and zoomed-out (background, edge taps)."""
+    same_as_oracle(S.SyntheticFrame("RGBAF16", 322, 186, seed=61, fov=fov, interpolation=interp, background_rgba=(0.2, 0.4, 0.6, 0.8)))

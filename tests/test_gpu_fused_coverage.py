@@ -141,3 +141,16 @@ def test_colour_range_fix_takes_the_fused_kernel(fmt, jit, interp):
     assert warp.last_backend().startswith("yuv_fused"), warp.last_backend()
     for i, (a, b) in enumerate(zip(ref, got)):
         assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "colour-range fix, plane %d" % i)
+
+
+@pytest.mark.parametrize("jit", [0, 2])
+@pytest.mark.parametrize("interp", [2, 4, 8])
+@pytest.mark.parametrize("fov", [1.0, 1.7])
+def test_packed_half_float_takes_the_fused_kernel(jit, interp, fov):
+    """RGBAf16 (pixel_formats.rs:227-246) — fused since round 5: the f32 packed path with v_cvt_f32_f16 / v_cvt_f16_f32 at the fetch and the store"""
+    fr = S.SyntheticFrame("RGBAF16", 322, 186, seed=61, fov=fov, interpolation=interp, background_rgba=(0.2, 0.4, 0.6, 0.8))
+    ref = O.run_frame(fr)
+    got = warp.run_frame(fr, jit=jit)
+    assert warp.last_backend().startswith("yuv_fused"), warp.last_backend()
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "RGBAf16, plane %d" % i)
