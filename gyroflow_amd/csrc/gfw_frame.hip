@@ -33,7 +33,7 @@
 // compiled once per tap count and sample type), background_mode 0-3, input rotation and the fill flag (round 4; not the colour-range fix), translation3d == 0 (other lens models, refraction, digital lens, IBIS/OIS terms, the lens-correction
 // blend, background mode 3 and the Sony mesh are served by the generic-model instantiations with the exact first pass), any stretch (round 4),
 // full-plane rects; Luma8/Luma16 (+UV8/UV16) planes with chroma planes of identical geometry, one
-// packed RGB(A)8/16 / BGRA8 / AYUV16 / RGBAf / RGBAf16 plane, or planar R32f planes.
+// packed RGB(A)8/16 / BGRA8 / AYUV16 / RGBAf plane, or planar R32f planes.
 #ifndef GFW_JIT
 #define GFW_JIT 0                // 1: this file is being compiled at run time by hiprtc (gfw_jit.hip) into ONE baked instantiation: device code only
 #endif
