@@ -764,8 +764,8 @@ extern "C" {
 
 int gfw_flush(gfw_ctx *c) {
     if (!c) return GFW_ERR_INVALID_ARGUMENT;
-    std::lock_guard<std::mutex> lk(g_group_mu);
-    return flush_context_locked(c);
+    GroupLock lk(g_group_mu);
+    return flush_context_locked(c, lk);
 }
 }  // extern "C"
 // Entry points other than gfw_undistort_image keep their place in the order of calls: whatever is being held leaves first (no lock when nothing is)
@@ -796,7 +796,7 @@ int gfw_undistort_image(gfw_ctx *c, const gfw_buffers *buffers, const gfw_kernel
     // (a context that never took part in a held frame, called by a thread that holds nothing: the round-3 path, no lock)
     if (!holdable && !(t_group && t_group->n > 0) && !(c->held && c->held->n > 0) && !c->needs_order)
         return run_planes(c, 1, buffers, params, &pt, matrices, matrix_count, mesh, mesh_len);
-    std::lock_guard<std::mutex> lk(g_group_mu);
+    GroupLock lk(g_group_mu);
     PlaneGroup *g = t_group;
     if (!g && holdable) { g = t_group = new PlaneGroup(); g->thread = std::this_thread::get_id(); g_groups.push_back(g); }
     bool cont = false;
@@ -805,18 +805,20 @@ int gfw_undistort_image(gfw_ctx *c, const gfw_buffers *buffers, const gfw_kernel
         cont = holdable && params->plane_index == g->n && g->pl[0].c->device == c->device && g->pl[0].c->model == c->model && g->pl[0].c->digital == c->digital &&
                g->matrix_count == matrix_count && g->matrices_on_device == c->matrices_on_device;
         if (cont) cont = g->matrices_on_device ? (matrices == g->d_matrices) : (memcmp(matrices, g->h_matrices.data(), (size_t)matrix_count * 14 * sizeof(float)) == 0);
-        if (!cont) { const int frc = group_launch(g); if (frc != GFW_OK) return frc; }
+        if (!cont) { const int frc = group_launch(g, lk); if (frc != GFW_OK) return frc; }
     }
     const bool starts = holdable && !cont && params->plane_index == 0;
     // whatever else involves this context leaves first, unless the call is the next plane of the frame or opens the next frame of the clip its context holds
-    if (!cont && !(starts && c->coalesce_frames > 1)) { const int frc = flush_context_locked(c); if (frc != GFW_OK) return frc; }
-    if (!cont && !starts)
+    if (!cont && !(starts && c->coalesce_frames > 1)) { const int frc = flush_context_locked(c, lk); if (frc != GFW_OK) return frc; }
+    if (!cont && !starts) {
+        lk.unlock();
         return run_planes(c, 1, buffers, params, &pt, matrices, matrix_count, mesh, mesh_len);
+    }
     {   // the errors of this plane belong to this call
         const int vrc = validate_plane(buffers, params, pt);
-        if (vrc != GFW_OK) { (void)group_launch(g); return vrc; }
-        if (params->matrix_count != matrix_count) { (void)group_launch(g); set_error("plane %d: matrix_count %d != %d", g->n, params->matrix_count, matrix_count); return GFW_ERR_INVALID_ARGUMENT; }
-        if (matrix_count > c->max_matrix_rows) { (void)group_launch(g); set_error("Buffer size mismatch matrices! %d vs %d", c->max_matrix_rows, matrix_count); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
+        if (vrc != GFW_OK) { (void)group_launch(g, lk); return vrc; }
+        if (params->matrix_count != matrix_count) { (void)group_launch(g, lk); set_error("plane %d: matrix_count %d != %d", g->n, params->matrix_count, matrix_count); return GFW_ERR_INVALID_ARGUMENT; }
+        if (matrix_count > c->max_matrix_rows) { (void)group_launch(g, lk); set_error("Buffer size mismatch matrices! %d vs %d", c->max_matrix_rows, matrix_count); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
     }
     if (g->n == 0) {
         g->matrix_count = matrix_count; g->matrices_on_device = c->matrices_on_device;
@@ -831,7 +833,8 @@ int gfw_undistort_image(gfw_ctx *c, const gfw_buffers *buffers, const gfw_kernel
     const bool complete = pt == GFW_PIX_UV8 || pt == GFW_PIX_UV16 || ((pt == GFW_PIX_LUMA8 || pt == GFW_PIX_LUMA16) && g->n == 3) || g->n == 4;
     if (complete) {
         gfw_ctx *owner = g->pl[0].c;
-        const int rc = group_launch(g);
+        const int rc = group_launch(g, lk);
+        lk.unlock();
         // GFW_OPT_FRAME_SYNC on a synchronous member of an asynchronous owner: the frame is complete when this call returns (a synchronous owner waited in run_planes)
         if (rc == GFW_OK && c->synchronous && c != owner) HIP_TRY(hipStreamSynchronize(owner->stream), GFW_ERR_HIP);
         return rc;

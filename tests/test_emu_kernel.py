@@ -138,11 +138,11 @@ def test_clip_launch_of_the_feature_bodies(fmt, kw):
 
 PER_PLANE = sorted(n for n in G.CASES if n not in FUSED) + ["yuv422p16_stretch", "yuv422p16_fill_background", "input_rotation_90_nv12", "input_rotation_180_640x360", "c2_yuv422p16_480x270_rs", "c1_nv12_1920x1080_constquat", "p010_lanczos4_640x360", "yuv420p_bilinear_642x362",
                                                             "rgba64_bicubic_640x360", "gbrapf32_bicubic_640x360", "yuv422p16_mirror", "gopro_640x360", "hyperview_lca06_640x360",
-                                                            "ibis_terms_640x360"]
+                                                            "ibis_terms_640x360", "rgbaf16_bilinear_640x360"]
 
 
 def test_per_plane_cases_cover_what_the_fused_kernel_leaves():
-    assert {"yuv422p16_stretch", "yuv422p16_fill_background", "input_rotation_90_nv12", "input_rotation_180_640x360"} <= set(FUSED)     # the fused kernel's since round 4 (and still the per-plane kernel's when asked)
+    assert {"yuv422p16_stretch", "yuv422p16_fill_background", "input_rotation_90_nv12", "input_rotation_180_640x360", "rgbaf16_bilinear_640x360"} <= set(FUSED)     # the fused kernel's since round 4 / 5 (and still the per-plane kernel's when asked)
     assert {"yuv422p16_stretch", "yuv422p16_fill_background", "input_rotation_90_nv12", "input_rotation_180_640x360", "rgbaf16_bilinear_640x360"} <= set(PER_PLANE)
 
 

@@ -301,3 +301,43 @@ def test_get_stream_sends_held_planes_on_their_way():
             assert_plane_equal(ref[p], out[p], fr.planes[p]["pixel_type"], "after gfw_get_stream, plane %d" % p)
     finally:
         loop.close()
+
+
+def test_threads_assembling_frames_side_by_side_do_not_wait_for_each_others_launches():
+    """Round 5: the process-wide lock covers the book-keeping of held planes, not the launches.  Four render threads, each with the plane contexts
+    of its own clip — one of them behind a blocking run-time build (GFW_OPT_JIT = 2, ~1 s) — assemble their frames concurrently; every frame is bit-exact,
+    and the threads without a build are done long before the one with it (they used to queue behind the lock it held)."""
+    import threading, time
+    fmts = ["YUV422P16LE", "NV12", "YUV420P", "P010LE"]
+    loops = [PlaneLoop(clip(f, 640, 360, 4), jit=2 if i == 0 else 0, frames_per_launch=2 if i == 3 else 1) for i, f in enumerate(fmts)]
+    done, errors = [None] * len(loops), []
+    gate = threading.Barrier(len(loops))
+
+    def work(i):
+        try:
+            gate.wait()
+            for j in range(4):
+                loops[i].frame(j)
+            loops[i].be[-1].synchronize()
+            done[i] = time.perf_counter()
+        except Exception as e:                     # noqa: BLE001 — reported below, in the main thread
+            errors.append((i, repr(e)))
+
+    try:
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(len(loops))]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(120)
+        assert not errors, errors
+        assert all(d is not None for d in done)
+        for i, loop in enumerate(loops):
+            for j in range(4):
+                loop.check(j, "thread %d %s" % (i, fmts[i]))
+        build = done[0] - t0
+        if build > 0.3:                            # (a cached code object makes the build instantaneous: nothing to compare then)
+            assert max(done[1:]) - t0 < 0.5 * build, [d - t0 for d in done]
+    finally:
+        for loop in loops:
+            loop.close()
