@@ -95,6 +95,9 @@ def parse_args(argv):
     ap.add_argument("--c5", action="store_true", help="C5: a --frames long 4K clip dealt round-robin to the ranks (strong scaling); per-row "
                                                       "matrices built on the device per frame; per-frame checksums all-gathered")
     ap.add_argument("--frames", type=int, default=10000, help="--c5: frames in the clip")
+    ap.add_argument("--sum-pass", action="store_true",
+                    help="--c5: take each frame's checksum with a gfw_checksum64 pass over its destination buffer (33 MB read back per C2 frame) instead of where the pixels "
+                         "leave (gfw_set_frame_checksums, the default: the specialised kernel adds what it stores, no second pass)")
     ap.add_argument("--sum-stream", type=int, default=0, choices=(0, 1),
                     help="--c5: 0 (default) the per-frame checksums in order on the warp's stream; 1: on a stream of their own, beside the warp of the next launch (two groups of "
                          "destination sets ordered by events, one wave slot per SIMD left free for them) — built in round 5 to take the verification off the critical path and "
@@ -275,6 +278,7 @@ def worker(args):
     # the frames of a clip launch write one destination set each; clip launches dealt to S streams: a group of sets per stream
     N_DST = max(8, min(args.clip, CLIP_FRAMES)) * (args.streams if args.clip > 1 else 1)
     sum_stream_on = bool(args.c5 and args.sum_stream and args.clip > 1)
+    sums_in_kernel = bool(args.c5 and not args.sum_pass and not sum_stream_on and args.streams == 1)
     if sum_stream_on:
         N_DST = 2 * min(args.clip, CLIP_FRAMES)         # two groups of destination sets: launch c + 1 writes one while the checksums of launch c read the other
     W, H = args.width, args.height
@@ -512,7 +516,7 @@ def worker(args):
             sums_done[par].record(sum_stream)
             return
         call()
-        if args.c5:
+        if args.c5 and not sums_in_kernel:
             for i in range(ln):                         # each frame's checksum, in order on the same stream
                 sum_fn(ctxp, dst_ptrs[i], dst_total, sum_base + 8 * (k0 + i))
 
@@ -538,7 +542,7 @@ def worker(args):
                     be._check(rc)
                 call.mp = tbl.value
             call()
-            if args.c5:
+            if args.c5 and not sums_in_kernel:
                 sum_fn(ctxp, dst_ptrs[d], dst_total, sum_base + 8 * k)           # the frame's checksum, in order on the same stream
         elif n_streams > 1:
             calls_by_stream[k % n_streams][j]()
@@ -552,6 +556,8 @@ def worker(args):
         """steps 0 .. n-1 of the workload, as clip calls or frame by frame; every bracket_every-th launch has its kernel time taken"""
         set_opt, ctxps = be.lib.gfw_set_option, [b.ctx for b in all_bes]
         enq_mark[0], enq_mark[1] = None, 0
+        if sums_in_kernel:
+            be.set_frame_checksums(sum_base, max(1, n_steps))            # step k's frame adds the checksum of what it writes to word k (the count restarts here)
         if clip_n > 1:
             for c, k0 in enumerate(range(0, n, clip_n)):
                 ln = min(clip_n, n - k0)
@@ -651,7 +657,8 @@ def worker(args):
     workload = workload.replace("LENS", (args.lens_model or "opencv_fisheye") + (" + " + args.digital if args.digital else "") +
                                 ("" if args.lca == 1.0 else " (lens correction %g)" % args.lca))
     if args.c5:
-        workload += "; %d-frame clip dealt round-robin to %d rank(s), one 64-bit checksum per frame" % (total, world)
+        workload += "; %d-frame clip dealt round-robin to %d rank(s), one 64-bit checksum per frame (%s)" % (
+            total, world, "taken by the warp kernel where the pixels leave: gfw_set_frame_checksums" if sums_in_kernel else "a gfw_checksum64 pass over each destination buffer")
     if clip_n > 1:
         workload += "; steps handed to the library as gfw_undistort_clip calls of %d frames" % clip_n
     if args.per_plane:
@@ -721,7 +728,19 @@ def worker(args):
                 refs[k] = O.run_frame(view)
                 if not all(np.array_equal(refs[k][p], got[d][p]) for p in range(nplanes)):
                     bad.append(k)
-                if args.c5:
+                if args.c5 and sums_in_kernel:
+                    # the checksum of the bytes WRITTEN (the pixels: stride padding and the gaps between planes stay out), each at its place in its 64-bit word
+                    want = 0
+                    for p, pl in enumerate(frames[0].planes):
+                        ow, oh, ostride = pl["out_size"]
+                        body = np.zeros(S.align(sizes[p], 8), np.uint8)
+                        rows_v = body[:oh * ostride].reshape(oh, ostride)
+                        rows_v[:, :ow * pl["params"].bytes_per_pixel] = refs[k][p][:oh * ostride].reshape(oh, ostride)[:, :ow * pl["params"].bytes_per_pixel]
+                        want += int(body.view(np.int64).sum(dtype=np.int64))
+                    want = int(np.array([want & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64).view(np.int64)[0])
+                    if want != int(mine[k]):
+                        bad.append(("checksum", k))
+                elif args.c5:
                     want = int(np.concatenate([np.pad(refs[k][p], (0, offs[p + 1] - offs[p] - sizes[p]), constant_values=0x5A) for p in range(nplanes)]
                                               + [np.full(dst_total - offs[-1], 0x5A, np.uint8)]).view(np.int64).sum(dtype=np.int64))
                     if want != int(mine[k]):

@@ -139,6 +139,9 @@ struct gfw_ctx {
     std::atomic<int> pending_planes{0};            // planes of this context held in some thread's group (flush_if_pending looks here: the holder may be another thread)
     bool multi_plane = false;                      // this context has been seen as one plane of a multi-plane frame (its calls may be held: GFW_OPT_COALESCE_PLANES = 1)
     int frame_sync = 0;                            // GFW_OPT_FRAME_SYNC
+    // gfw_set_frame_checksums: the caller's ring of device words, the frames submitted since, the table of partial sums the checksum build of the fused kernel fills
+    unsigned long long *sums = nullptr; size_t sum_n = 0, sum_k = 0;
+    DevBuf d_ck_part;
     struct ClipBatch *held = nullptr;              // frames assembled from per-plane calls, waiting for their launch (owner context only)
     gfw_ctx *frame_owner = nullptr; bool needs_order = false;   // a member context: whose stream its planes were launched on, and whether its own stream has been ordered behind that yet
     std::vector<gfw_buffers> held_planes;          // ... and the descriptions those frames were validated with
@@ -303,7 +306,7 @@ void gfw_destroy(gfw_ctx *c) {
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &b : c->stage_src) b.release();
     for (auto &b : c->stage_dst) b.release();
-    c->d_mesh.release(); c->d_p1_table.release(); c->d_audit.release(); c->d_tracks.release(); c->d_offsets.release(); for (auto &ss : c->sslots) { ss.d.release(); if (ss.h) (void)hipHostFree(ss.h); if (ss.done) (void)hipEventDestroy(ss.done); } c->d_prefix.release(); c->d_timings.release(); c->d_batch[0].release(); c->d_batch[1].release();
+    c->d_mesh.release(); c->d_ck_part.release(); c->d_p1_table.release(); c->d_audit.release(); c->d_tracks.release(); c->d_offsets.release(); for (auto &ss : c->sslots) { ss.d.release(); if (ss.h) (void)hipHostFree(ss.h); if (ss.done) (void)hipEventDestroy(ss.done); } c->d_prefix.release(); c->d_timings.release(); c->d_batch[0].release(); c->d_batch[1].release();
     if (c->h_timings) (void)hipHostFree(c->h_timings);
     for (auto &e : c->timing_copied) if (e) (void)hipEventDestroy(e);
     for (auto &b : c->bslots) { b.buf.release(); if (b.built) (void)hipEventDestroy(b.built); if (b.consumed) (void)hipEventDestroy(b.consumed); }
@@ -573,7 +576,25 @@ struct ClipBatch {
     int grid = 0, n = 0;
     const gfw_buffers *first = nullptr;          // planes of the frame that opened the pending launch (fully validated by run_planes)
     const char *backend = "";
+    unsigned long long *sums[GFW_CLIP_MAX] = {};   // gfw_set_frame_checksums: where each frame's checksum goes (the launch's kernel takes it: CA.Y.checksum)
 };
+// gfw_set_frame_checksums: the word of the next frame submitted on the context (nullptr: off)
+static unsigned long long *next_sum(gfw_ctx *c) { return (c->sums && c->sum_n) ? c->sums + (c->sum_k++ % c->sum_n) : nullptr; }
+// the launch's table of partial sums: one word per frame, workgroup and wave (gfw_frame.hip ck_flush)
+static int clip_flush(gfw_ctx *c, ClipBatch *b);
+static int ck_table(gfw_ctx *c, int grid, GfwYuvArgs &Y, ClipBatch *pending) {
+    const size_t need = (size_t)GFW_CLIP_MAX * (size_t)(grid > 4096 ? grid : 4096) * 4 * sizeof(unsigned long long);      // (2 MB: every grid the launcher picks on 256 CUs)
+    if (need > c->d_ck_part.cap && pending && pending->n > 0) { const int frc = clip_flush(c, pending); if (frc != GFW_OK) return frc; }     // (a pending launch names the table that is about to move)
+    HIP_TRY(c->d_ck_part.ensure(need), GFW_ERR_HIP);
+    Y.ck_part = (unsigned long long *)c->d_ck_part.ptr;
+    return GFW_OK;
+}
+static int ck_finish(gfw_ctx *c, const GfwClipArgs &CA, int grid, unsigned long long *const *sums) {
+    GfwCkSums S;
+    for (int i = 0; i < 16; ++i) S.sum[i] = i < CA.n_frames ? sums[i] : nullptr;
+    HIP_TRY(gfw_launch_ck_finish(CA.Y.ck_part, grid * 4, CA.n_frames, S, c->stream), GFW_ERR_HIP);
+    return GFW_OK;
+}
 static bool clip_same_shape(const gfw_buffers *a, const gfw_buffers *b, int nplanes) {
     for (int i = 0; i < nplanes; ++i) {
         const gfw_buffer_desc *x[2] = {&a[i].input, &a[i].output}, *y[2] = {&b[i].input, &b[i].output};
@@ -637,14 +658,40 @@ static int clip_flush(gfw_ctx *c, ClipBatch *b) {
     b->CA.n_frames = b->n; b->CA.pad_ = 0;
     prof_begin(c);
     const hipError_t e = gfw_jit_launch(b->fn, b->CA, b->grid, c->stream);
+    int crc = GFW_OK;
+    if (e == hipSuccess && b->CA.Y.checksum) crc = ck_finish(c, b->CA, b->grid, b->sums);
     prof_end(c, b->n);
     timeline_dump(c, b->fn);
     b->n = 0;
     if (e != hipSuccess) { set_error("clip launch failed: %s", hipGetErrorString(e)); return GFW_ERR_HIP; }
-    return GFW_OK;
+    return crc;
 }
 
 #include "gfw_api_bake.inc"
+// gfw_set_frame_checksums behind a kernel that does not take the sum itself: a pass over what the frame's kernels wrote — the pixels of each plane's output rect
+// (cpu_undistort.rs:546-551: nothing outside it is touched), whole pixels inside the declared length
+static int checksum_written(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params, unsigned long long *sum) {
+    for (int i = 0; i < nplanes; ++i) {
+        const gfw_kernel_params &P = params[i];
+        const gfw_buffer_desc &o = planes[i].output;
+        const long long bpp = P.bytes_per_pixel, stride = o.stride;
+        if (bpp <= 0 || stride <= 0) continue;
+        const long long cols = stride / bpp, rows_all = ((long long)o.len + stride - 1) / stride;
+        long long x0 = P.output_rect[0] > 0 ? P.output_rect[0] : 0, y0 = P.output_rect[1] > 0 ? P.output_rect[1] : 0;
+        long long x1 = (long long)P.output_rect[0] + P.output_rect[2], y1 = (long long)P.output_rect[1] + P.output_rect[3];
+        if (x1 > cols) x1 = cols;
+        if (y1 > rows_all) y1 = rows_all;
+        if (x1 <= x0 || y1 <= y0) continue;
+        // (the last row may be cut short by the declared length: the kernels write only whole pixels inside it)
+        while (y1 > y0 && (y1 - 1) * stride + x1 * bpp > (long long)o.len) {
+            const long long fit = ((long long)o.len - (y1 - 1) * stride) / bpp;
+            if (fit > x0) { HIP_TRY(gfw_launch_ck_region((const uint8_t *)o.data, (y1 - 1) * stride + x0 * bpp, stride, (int)((fit - x0) * bpp), 1, sum, c->stream), GFW_ERR_HIP); }
+            --y1;
+        }
+        HIP_TRY(gfw_launch_ck_region((const uint8_t *)o.data, y0 * stride + x0 * bpp, stride, (int)((x1 - x0) * bpp), (int)(y1 - y0), sum, c->stream), GFW_ERR_HIP);
+    }
+    return GFW_OK;
+}
 static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params, const int *pixel_types,
                       const float *matrices, int matrix_count, const float *mesh, size_t mesh_len, ClipBatch *batch = nullptr) {
     if (!c) { set_error("null context"); return GFW_ERR_INVALID_ARGUMENT; }
@@ -698,11 +745,26 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
     int bps = 0, n0 = 1, dw = 1, dh = 1; bool interleaved = false, fast1 = false;
     const bool fused = build_yuv_args(c, nplanes, planes, params, pixel_types, launches, c->matrices_on_device ? nullptr : matrices,
                                       matrix_count, mesh_len, Y, bps, n0, dw, dh, interleaved, fast1);
+    // gfw_set_frame_checksums: this frame's word.  The specialised fused kernel takes the checksum in its store path when every plane starts on a 64-bit word and
+    // every element it stores lies inside one (strides aligned to the element: always, but for a caller's odd sub-buffer); everything else is followed by a pass
+    // over what it wrote.  In a clip launch the alignment is the first frame's to answer for the kernel choice and every frame's to meet (checked where frames join).
+    unsigned long long *const sum = c->dry ? nullptr : next_sum(c);
+    if (sum) for (int i = 0; i < nplanes; ++i) if (planes[i].output.kind == GFW_BUF_HOST) { set_error("gfw_set_frame_checksums: plane %d writes a host buffer", i); return GFW_ERR_INVALID_ARGUMENT; }
+    bool sum_taken = false;
     if (fused) {
         fill_common(c, &params[0], d_mat, (Y.extras & 32) ? d_mesh : nullptr, (Y.extras & 32) ? (int)mesh_len : 0, Y.common);
         Y.matrices = d_mat;
+        if (sum) {
+            const int el = bps == 3 ? 2 : bps;        // bytes per element (sample kind 3: half floats)
+            bool aligned = true;
+            for (int i = 0; i < Y.nplanes; ++i) aligned = aligned && ((uintptr_t)Y.pl[i].dst & 7) == 0 && (Y.pl[i].dst_stride % el) == 0;    // (the kernel places an element in its word by its OFFSET)
+            // (the lane-row adds a frame's 8/16-bit samples up in 32-bit registers: fewer than 2^15 lane-rows per lane and frame even if eight workgroups shared the frame)
+            const long long lane_rows = (long long)Y.tiles_x * Y.tiles_y * gfw_yuv_rows_per_lane(fast1, 0) * dh;
+            Y.checksum = (aligned && lane_rows < 8 * 32768ll) ? 1 : 0;
+        }
         int jgrid = 0;
         hipFunction_t jf = jit_for(c, Y, bps, params[0].interpolation, n0, dw, dh, interleaved, fast1, &jgrid);
+        if (jf && Y.checksum) { const int krc = ck_table(c, jgrid, Y, batch); if (krc != GFW_OK) return krc; sum_taken = true; }
         bool all_device = c->matrices_on_device != 0;
         for (int i = 0; i < nplanes; ++i) all_device = all_device && planes[i].input.kind != GFW_BUF_HOST && planes[i].output.kind != GFW_BUF_HOST;
         if (jf && batch && all_device && c->bslot_cur < 0 && c->mslot_cur < 0) {      // (a table of the cross-stream ring is ordered by events: frame by frame)
@@ -713,11 +775,16 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
                 const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc;
             }
             if (batch->n == 0) { batch->CA.Y = Y; batch->fn = jf; batch->grid = jgrid; batch->first = planes; batch->backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit"; }
+            batch->sums[batch->n] = sum;
             GfwFrameDyn &F = batch->CA.fr[batch->n++];
             for (int i = 0; i < 4; ++i) { F.src[i] = Y.pl[i].src; F.dst[i] = Y.pl[i].dst; }
             F.matrices = Y.matrices;
             c->last_backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit";
             if (batch->n == GFW_CLIP_MAX) { const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc; }
+            if (sum && !sum_taken) {                  // (a frame of a launch whose kernel does not take sums: behind the launch it has just joined)
+                const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc;
+                const int src_ = checksum_written(c, nplanes, planes, params, sum); if (src_ != GFW_OK) return src_;
+            }
             return GFW_OK;
         }
         if (batch) { const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc; }
@@ -728,6 +795,7 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
             for (int i = 0; i < 4; ++i) { CA.fr[0].src[i] = Y.pl[i].src; CA.fr[0].dst[i] = Y.pl[i].dst; }
             CA.fr[0].matrices = Y.matrices;
             HIP_TRY(gfw_jit_launch(jf, CA, jgrid, c->stream), GFW_ERR_HIP);
+            if (sum_taken) { const int krc = ck_finish(c, CA, jgrid, &sum); if (krc != GFW_OK) return krc; }
             timeline_dump(c, jf);
             c->last_backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit";
         } else {
@@ -743,6 +811,7 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
         }
         c->last_backend = "plane_generic";
     }
+    if (sum && !sum_taken) { const int src_ = checksum_written(c, nplanes, planes, params, sum); if (src_ != GFW_OK) return src_; }
     prof_end(c);
     { const int mrc = matrices_consumed(c); if (mrc != GFW_OK) return mrc; }
     if (c->ev_used > 4096) { (void)hipStreamSynchronize(c->stream); prof_harvest(c); }
@@ -865,8 +934,11 @@ int gfw_undistort_clip(gfw_ctx *c, int n_frames, int nplanes, const gfw_buffers 
     for (int f = 0; f < n_frames; ++f) {
         // A frame shaped exactly like the one that opened the pending launch (same descriptions but for the pointers; the parameters are
         // shared by construction) needs none of the per-frame validation again: its pointers join the launch.  ~10 us -> < 1 us of host time.
-        if (batch.n > 0 && batch.n < GFW_CLIP_MAX && c->matrices_on_device == 2 && matrices[f] && clip_same_shape(batch.first, planes + (size_t)f * nplanes, nplanes) &&
+        bool words = true;                            // (the checksum build places an element by its offset: every plane on a 64-bit word, as run_planes checked for the launch's first frame)
+        if (c->sums) for (int i = 0; i < nplanes; ++i) words = words && ((uintptr_t)planes[(size_t)f * nplanes + i].output.data & 7) == 0;
+        if (batch.n > 0 && batch.n < GFW_CLIP_MAX && (!c->sums || (batch.CA.Y.checksum && words)) && c->matrices_on_device == 2 && matrices[f] && clip_same_shape(batch.first, planes + (size_t)f * nplanes, nplanes) &&
             !clip_ring_table(c, matrices[f]) && !clip_overlaps(&batch, planes + (size_t)f * nplanes, nplanes)) {
+            batch.sums[batch.n] = next_sum(c);
             GfwFrameDyn &F = batch.CA.fr[batch.n++];
             for (int i = 0; i < 4; ++i) {
                 F.src[i] = i < nplanes ? (const uint8_t *)planes[(size_t)f * nplanes + i].input.data : nullptr;
@@ -986,6 +1058,13 @@ extern "C" int gfw_checksum64(gfw_ctx *c, const void *d_buf, size_t bytes, unsig
     { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }
 
     HIP_TRY(gfw_launch_checksum64(d_buf, bytes, d_out, c->stream), GFW_ERR_HIP);
+    return GFW_OK;
+}
+
+extern "C" int gfw_set_frame_checksums(gfw_ctx *c, unsigned long long *d_sums, size_t count) {
+    if (!c) { set_error("null context"); return GFW_ERR_INVALID_ARGUMENT; }
+    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }          // frames being held were submitted under the previous setting
+    c->sums = (d_sums && count) ? d_sums : nullptr; c->sum_n = c->sums ? count : 0; c->sum_k = 0;
     return GFW_OK;
 }
 

@@ -35,6 +35,7 @@ struct GfwYuvArgs {
     int32_t k_all_zero;               // k[0..3] all zero (opencv_fisheye.rs:75)
     int32_t hstretch_div, vstretch_div;
     int32_t fix_range;                // some plane has `fix` set: the frame takes the per-pixel path (the range fix sits between the sample and the store)
+    int32_t checksum;                 // specialised builds only (GFW_BK_checksum): the kernel takes the checksum of what it writes (gfw_set_frame_checksums) into ck_part
     int32_t fill_bg;                  // FILL_WITH_BACKGROUND (flags & 4, cpu_undistort.rs:558-561): every pixel of the output rect is the background
     int32_t rot_on;                   // input_rotation != 0 (:485-491): the projected point is rotated about the frame centre (cos / sin / rotated frame size in `common`)
     int32_t background_mode;          // 0 solid, 1 edge repeat, 2 edge mirror, 3 margin + feather (with extras & 16)
@@ -58,6 +59,7 @@ struct GfwYuvArgs {
     float p1_f, p1_c;                 // f[1], c[1] (f[0], c[0] for horizontal rolling shutter)
     float p1_lat[6];                  // lattice form of the first pass: bounds max |s|, max sqrt(rho) |s'|, max rho |s'|, max rho^1.5 |s''| over the table's range
                                       // (gfw_api.hip p1_prepare_table), the interpolation's own rounding allowance in pixels, [5] != 0: per-pixel form on request
+    unsigned long long *ck_part;      // checksum builds: partial sums of the launch, [frame][workgroup][wave] (one word each; gfw_ck_finish adds a frame's words to its sum)
     unsigned long long *audit;        // nullptr, or 8 words: certified, certified-but-wrong, queued, queue-overflow, max |approx-exact| (f32 bits),
                                       // [5] global addresses outside their buffer (audit mode range-checks every tap, store, matrix row and table entry)
     gfw_kernel_params kp;             // plane-0 params, for the non-specialised lens models

@@ -138,6 +138,62 @@
 #undef GFW_BK_ablate                 // timing ablations of a SPECIALISED kernel (GFW_JIT_DEFS=GFW_ABLATE_FORCE=<bits>; the option's 16 + bits reach only the ahead-of-time kernels): wrong output by design
 #define GFW_BK_ablate (GFW_ABLATE_FORCE)
 #endif
+
+// ---- the frame's checksum, taken where the pixels leave (specialised builds with GFW_BK_checksum: gfw_set_frame_checksums) -----------------------------
+// gfw_checksum64 of a destination buffer is the sum of its little-endian 64-bit words modulo 2^64, i.e. every byte times 256^(address mod 8): additive, so the kernel
+// that writes the bytes can take it on the way out instead of a second pass reading 33 MB per C2 frame back (C5: 53 -> 43 us per frame).  Every lane adds the
+// elements it stores, shifted to their place in the word, into an LDS slot of its own (one ds_add_u64, no return); at a frame change and at the end a wave folds
+// its 64 slots together and writes ONE word of the launch's table of partial sums (GfwYuvArgs.ck_part), which gfw_ck_finish adds up.  Builds without the option carry none of this.
+#ifndef GFW_LDS_ADD
+#define GFW_LDS_ADD(p, v) ((void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT))      // ds_add_u64: nothing comes back, nothing to wait for
+#endif
+#if GFW_BAKE && GFW_BK_checksum
+#define GFW_CK 1
+__shared__ unsigned long long gfw_ck_slot[256];       // a lane's stores outside the branch-free lane-row
+__shared__ unsigned long long gfw_ck_wave[4];         // a wave's sum while it is being folded
+#else
+#define GFW_CK 0
+#endif
+#define GFW_CK_ELSEWHERE ((unsigned long long *)8)
+template <typename T>
+__device__ __forceinline__ void gfw_ck(uint32_t off, T v, unsigned long long *acc = nullptr) {
+#if GFW_CK
+    static_assert(sizeof(T) <= 4, "one element of a plane");
+    unsigned long long bits;
+    if constexpr (sizeof(T) == 1) bits = __builtin_bit_cast(uint8_t, v);
+    else if constexpr (sizeof(T) == 2) bits = __builtin_bit_cast(uint16_t, v);
+    else bits = __builtin_bit_cast(uint32_t, v);
+    // the element's place in its word: from the offset alone — the host sends only frames whose planes start on a word (8-byte) boundary here, and whose planes and
+    // strides are element-aligned, so that an element never straddles a word
+    if (acc == GFW_CK_ELSEWHERE) return;            // (the caller accounts for this store itself)
+#ifdef GFW_CK_ABLATE_COLD
+    if (!acc) return;                               // timing ablation (wrong sums): the stores outside the branch-free lane-row leave unaccounted
+#endif
+    const unsigned sh = (off & 7u) * 8u;
+    if (acc) *acc += bits << sh;                    // the branch-free lane-row: a register pair of the lane (folded into the slot before the wave's fold)
+    else {
+        unsigned slot = threadIdx.y * 64 + threadIdx.x;
+        asm("" : "+v"(slot));                       // opaque: the slot's address is worked out at the (rare) store, not kept — in scratch — across the kernel
+        GFW_LDS_ADD(&gfw_ck_slot[slot], bits << sh);
+    }
+#else
+    (void)off; (void)v; (void)acc;
+#endif
+}
+// two adjacent elements that left as one store: one addition when the pair sits inside a word (its offset a multiple of its size), else element by element
+// (`inside`: the caller knows it does — a pair at an even pixel of a plane whose stride is a multiple of the pair, a literal in a baked build: no test per store)
+template <typename E>
+__device__ __forceinline__ void gfw_ck_pair(uint32_t off, uint32_t v0, uint32_t v1, unsigned long long *acc = nullptr, bool inside = false) {
+#if GFW_CK
+    if constexpr (sizeof(E) == 4) { gfw_ck<uint32_t>(off, v0, acc); gfw_ck<uint32_t>(off + 4u, v1, acc); }
+    else if (inside || (off & (2u * (unsigned)sizeof(E) - 1u)) == 0u) {
+        if constexpr (sizeof(E) == 1) gfw_ck<uint16_t>(off, (uint16_t)((v0 & 0xffu) | (v1 << 8)), acc);
+        else gfw_ck<uint32_t>(off, (v0 & 0xffffu) | (v1 << 16), acc);
+    } else { gfw_ck<E>(off, (E)v0, acc); gfw_ck<E>(off + (unsigned)sizeof(E), (E)v1, acc); }
+#else
+    (void)off; (void)v0; (void)v1; (void)acc; (void)inside;
+#endif
+}
 namespace {
 
 // Wave votes as one compare into a scalar pair and one scalar compare with EXEC: the library's __all / __any go through a 0/1 select and a second
@@ -650,8 +706,11 @@ __device__ __forceinline__ void store_px(uint8_t *dst, int off, const float *v, 
     #pragma unroll
     for (int c = 0; c < N; ++c) {
         const float x = fix_range1(v[c], fix, c);
-        if (is_f32<T>::value) d[c] = (T)x;                                      // f32 pixels pass through (pixel_formats.rs:247,296)
-        else d[c] = sat ? (T)gfw_f2u_sat(x, sizeof(T) == 1 ? 255.0f : 65535.0f) : (T)gfw_f2u_trunc(x);    // `as u8/u16`
+        T t;
+        if (is_f32<T>::value) t = (T)x;                                         // f32 pixels pass through (pixel_formats.rs:247,296)
+        else t = sat ? (T)gfw_f2u_sat(x, sizeof(T) == 1 ? 255.0f : 65535.0f) : (T)gfw_f2u_trunc(x);       // `as u8/u16`
+        d[c] = t;
+        gfw_ck<T>((uint32_t)off + (uint32_t)(c * sizeof(T)), t);
     }
 }
 // One plane.  32-bit byte offsets from the uniform plane base (planes are < 2 GiB, checked on the host).
@@ -848,7 +907,9 @@ __device__ __forceinline__ void sample_store2_bins(int bx, int by, bool ok, cons
                         typedef HotTap<T, false> Tap;
                         const uint32_t r0 = Tap::load(P.src, (uint32_t)off0), r1 = Tap::load(P.src, (uint32_t)off0 + (uint32_t)P.src_stride);
                         const uint32_t w = Tap::wpack(b.kx);
-                        *reinterpret_cast<T *>(P.dst + doff) = (T)hot_blend(Tap::dot(r0, w), Tap::dot(r1, w), b.ky, limit);
+                        const T o1 = (T)hot_blend(Tap::dot(r0, w), Tap::dot(r1, w), b.ky, limit);
+                        *reinterpret_cast<T *>(P.dst + doff) = o1;
+                        gfw_ck<T>(doff, o1);
                     } else {
                         typedef HotTap<T, true> Tap;
                         const auto r0 = Tap::load(P.src, (uint32_t)off0), r1 = Tap::load(P.src, (uint32_t)off0 + (uint32_t)P.src_stride);
@@ -858,6 +919,7 @@ __device__ __forceinline__ void sample_store2_bins(int bx, int by, bool ok, cons
                         const uint32_t ou = hot_blend(u0, u1, b.ky, limit), ov = hot_blend(v0, v1, b.ky, limit);
                         T *d = reinterpret_cast<T *>(P.dst + doff);
                         d[0] = (T)ou; d[1] = (T)ov;
+                        gfw_ck_pair<T>(doff, ou, ov);
                     }
                     return;
                 } }
@@ -947,8 +1009,10 @@ __device__ __forceinline__ void sample_store_uv2(float u, float v, bool ok, cons
                     const uint32_t a0 = Tap::load(PU.src, (uint32_t)off0), a1 = Tap::load(PU.src, (uint32_t)off0 + (uint32_t)PU.src_stride);
                     const uint32_t b0 = Tap::load(PV.src, (uint32_t)off0), b1 = Tap::load(PV.src, (uint32_t)off0 + (uint32_t)PU.src_stride);
                     const uint32_t w = Tap::wpack(b.kx);
-                    *reinterpret_cast<T *>(PU.dst + doff) = (T)hot_blend(Tap::dot(a0, w), Tap::dot(a1, w), b.ky, lim_u);
-                    *reinterpret_cast<T *>(PV.dst + doff) = (T)hot_blend(Tap::dot(b0, w), Tap::dot(b1, w), b.ky, lim_v);
+                    const T o_u = (T)hot_blend(Tap::dot(a0, w), Tap::dot(a1, w), b.ky, lim_u), o_v = (T)hot_blend(Tap::dot(b0, w), Tap::dot(b1, w), b.ky, lim_v);
+                    *reinterpret_cast<T *>(PU.dst + doff) = o_u;
+                    *reinterpret_cast<T *>(PV.dst + doff) = o_v;
+                    gfw_ck<T>(doff, o_u); gfw_ck<T>(doff, o_v);
                     return;
                 } }
                 taps_inside2<T, 1>(PU.src, off0, PU.src_stride, b, lim_u, &ou);
@@ -1004,17 +1068,20 @@ __device__ __forceinline__ GfwVote lut_interior(int bx, int by, int w, int h) { 
     return gfw_lanes((unsigned)(bx >> 5) <= (unsigned)(w - I - TAP_MARGIN)) & gfw_lanes((unsigned)(by >> 5) <= (unsigned)(h - I));
 }
 template <typename T>
-__device__ __forceinline__ void store_value1(uint8_t *dst, int off, uint32_t v) {
-    if constexpr (is_f32<T>::value && sizeof(T) == 4) *reinterpret_cast<uint32_t *>(dst + (uint32_t)off) = v;
-    else if constexpr (is_f32<T>::value) *reinterpret_cast<T *>(dst + (uint32_t)off) = (T)__builtin_bit_cast(float, v);      // (f16 planes: the f32 bit pattern, narrowed)
-    else *reinterpret_cast<T *>(dst + (uint32_t)off) = (T)v;
+__device__ __forceinline__ void store_value1(uint8_t *dst, int off, uint32_t v, unsigned long long *ck = nullptr) {
+    if constexpr (is_f32<T>::value && sizeof(T) == 4) { *reinterpret_cast<uint32_t *>(dst + (uint32_t)off) = v; gfw_ck<uint32_t>((uint32_t)off, v, ck); }
+    else if constexpr (is_f32<T>::value) { const T h = (T)__builtin_bit_cast(float, v); *reinterpret_cast<T *>(dst + (uint32_t)off) = h; gfw_ck<T>((uint32_t)off, h, ck); }      // (f16 planes: the f32 bit pattern, narrowed)
+    else { *reinterpret_cast<T *>(dst + (uint32_t)off) = (T)v; gfw_ck<T>((uint32_t)off, (T)v, ck); }
 }
 // two horizontally adjacent samples of an integer plane leave as ONE store (the pair's address need not be aligned to the pair: global memory takes it)
 template <typename T>
-__device__ __forceinline__ void store_pair1(uint8_t *dst, int off, uint32_t v0, uint32_t v1) {
+__device__ __forceinline__ void store_pair1(uint8_t *dst, int off, uint32_t v0, uint32_t v1, unsigned long long *ck = nullptr, bool ck_inside = false) {
     if constexpr (sizeof(T) == 1) { typedef uint16_t u16u __attribute__((aligned(1))); *reinterpret_cast<u16u *>(dst + (uint32_t)off) = (uint16_t)(v0 | (v1 << 8)); }
     else if constexpr (sizeof(T) == 2) { typedef uint32_t u32u __attribute__((aligned(2))); *reinterpret_cast<u32u *>(dst + (uint32_t)off) = v0 | (v1 << 16); }
     else { typedef uint2 u2u __attribute__((aligned(4))); *reinterpret_cast<u2u *>(dst + (uint32_t)off) = uint2{v0, v1}; }
+    if constexpr (sizeof(T) == 1) gfw_ck_pair<uint8_t>((uint32_t)off, v0, v1, ck, ck_inside);
+    else if constexpr (sizeof(T) == 2) gfw_ck_pair<uint16_t>((uint32_t)off, v0, v1, ck, ck_inside);
+    else gfw_ck_pair<uint32_t>((uint32_t)off, v0, v1, ck, ck_inside);
 }
 
 // ---- background mode 3 ("margin with feather", cpu_undistort.rs:576-613) ----------------------------------------------------
@@ -1207,6 +1274,72 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     constexpr int NXN = (64 * DW) / 8 + 1, HYR = RB * DH - 1;
     __shared__ float s_node[LAT ? 4 : 1][LAT ? 64 : 1];
     const int wave = threadIdx.y, lane = threadIdx.x, tid = wave * 64 + lane;
+#if GFW_CK
+    unsigned long long ck_acc;                       // the branch-free lane-row's stores: a register pair (an LDS atomic per store cost the kernel 18 %)
+#define CKA (&ck_acc)
+    // a pair store of the branch-free row sits at an even pixel (luma: pixel cx * DW of its row; interleaved chroma: site cx): inside a word whenever the rows are
+    const bool CK_PAIR0 = GFW_BAKE && (PL0.dst_stride % (int)(2 * sizeof(T))) == 0, CK_PAIR1 = GFW_BAKE && (PL1.dst_stride % (int)(2 * sizeof(T))) == 0;
+    // ... and where the rows of a plane are whole words apart, a lane's store at a site lands at the SAME place of its word in every row of every tile (its column is
+    // tile * 64 + lane): the lane adds the raw values up and shifts each sum once, at the fold.  8- and 16-bit planes: three 32-bit sums — the luma pair's two
+    // pixels (ck_l0, ck_l1) and the chroma site's samples (ck_c) — i.e. three v_add_u32 per lane-row of C2 and three registers; a frame's worth of 16-bit samples
+    // of one lane cannot overflow them (< 2^15 lane-rows per lane and frame even on the smallest grid: the host sends larger frames through the pass instead).  Float planes: 64-bit sums (ck_l, ck_c64).
+#ifdef GFW_CK_ABLATE_HOT
+    const bool CK_HOT = false;                      // timing ablation (wrong sums): the branch-free lane-row's stores leave unaccounted
+#else
+    const bool CK_HOT = true;
+#endif
+    const bool CK_INV0 = GFW_BAKE && (PL0.dst_stride & 7) == 0;
+    const bool CK_INVC = GFW_BAKE && (PL1.dst_stride & 7) == 0 && (INTERLEAVED_UV || AF(nplanes) < 3 || (PL2.dst_stride & 7) == 0) && (AF(nplanes) < 4 || (PL3.dst_stride & 7) == 0);
+    constexpr bool CK_WIDE = sizeof(T) == 4;
+    uint32_t ck_l0, ck_l1, ck_c;                     // (zeroed where the tile walk starts: not alive during the set-up above it, whose registers are the kernel's scarcest)
+    unsigned long long ck_l, ck_c64;
+    auto ck_bits1 = [](uint32_t v) -> uint32_t {         // what a store_value1<T> writes
+        if constexpr (is_f32<T>::value && sizeof(T) == 2) return __builtin_bit_cast(uint16_t, (T)__builtin_bit_cast(float, v));
+        else return v;
+    };
+    auto ck_luma = [&](const uint32_t *val) {           // the DW luma values a lane has just stored side by side
+        if constexpr (CK_WIDE) { ck_l += (unsigned long long)val[0] + (DW == 2 ? (unsigned long long)val[DW - 1] << 32 : 0ull); }
+        else { ck_l0 += ck_bits1(val[0]); if constexpr (DW == 2) ck_l1 += ck_bits1(val[DW - 1]); }
+    };
+#define CKL (CK_INV0 ? GFW_CK_ELSEWHERE : &ck_acc)
+#define CKC (CK_INVC ? GFW_CK_ELSEWHERE : &ck_acc)
+    gfw_ck_slot[tid] = 0;                            // (a lane's own slot: nobody else touches it)
+    if (lane == 0) gfw_ck_wave[wave] = 0;            // (the wave's own word: ordered before the first fold by that fold's own LDS traffic — one wave, in-order LDS)
+    // The wave leaves frame `from` for frame `to` (n_frames at the end) — uniform control flow: it folds its 64 slots (a butterfly through LDS) and lane 0 writes the
+    // wave's word of every frame in [from, to) — the sum, then zeros for frames it had no tile of — into the launch's table of partial sums, [frame][workgroup][wave].
+    // No atomics: thousands of them on one word serialise across the XCDs (gfw_kernels.hip, gfw_checksum64); gfw_ck_finish adds the table up behind the launch.
+    auto ck_flush = [&](int from, int to) {
+        unsigned ln = (unsigned)lane, sl = (unsigned)tid, wv = (unsigned)wave;
+        asm("" : "+v"(wv));
+        asm("" : "+v"(sl));
+        asm("" : "+v"(ln));                          // opaque: what the fold derives from the lane — its shifts, its slot — is worked out HERE (hoisted to the top of the
+                                                     // kernel these values lived in scratch across all of it, and a kernel that touches scratch starts its 8192 waves
+                                                     // slowly enough to cost 8 % of a launch: profiles/r05_c5_checksum.txt)
+        const unsigned sh_l = ((ln * (unsigned)(DW * sizeof(T))) & 7u) * 8u;
+        const unsigned sh_c = ((ln * (unsigned)((INTERLEAVED_UV ? 2 : 1) * sizeof(T))) & 7u) * 8u;
+        const unsigned long long luma = CK_WIDE ? ck_l : (unsigned long long)ck_l0 + ((unsigned long long)ck_l1 << (8 * sizeof(T)));
+        const unsigned long long v = gfw_ck_slot[sl] + ck_acc + (luma << sh_l) + ((ck_c64 + ck_c) << sh_c);
+        ck_acc = 0; ck_l = 0; ck_c64 = 0; ck_l0 = 0; ck_l1 = 0; ck_c = 0;
+        gfw_ck_slot[sl] = 0;
+        // the wave's 64 sums into ONE word: 64 LDS additions on the same address — the hardware takes them one after the other, eight times per wave and launch; a
+        // butterfly through the lanes' slots needed a dozen registers at a point of the tile walk that has none to spare (they went to scratch: see above)
+        GFW_LDS_ADD(&gfw_ck_wave[wv], v);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (ln == 0) {
+            const size_t per_frame = (size_t)gridDim.x * 4;
+            unsigned long long *o = A.ck_part + (size_t)blockIdx.x * 4 + wv;
+            o[(size_t)from * per_frame] = gfw_ck_wave[wv];
+            for (int f = from + 1; f < to; ++f) o[(size_t)f * per_frame] = 0;
+            gfw_ck_wave[wv] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // (the word is lane 0's until here)
+    };
+#else
+#define CKA ((unsigned long long *)nullptr)
+#define CKL ((unsigned long long *)nullptr)
+#define CKC ((unsigned long long *)nullptr)
+    const bool CK_PAIR0 = false, CK_PAIR1 = false;
+#endif
     if (MODEL == GFW_MODEL_OPENCV_FISHEYE) { gfw_atan_lds_init(tid); gfw_atan_key_lds_init(tid); }
     if (I != 2) {
         for (int i = tid; i < 448; i += 256) s_lut[i] = GFW_COEFFS[i];
@@ -1356,12 +1489,18 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     // a launch's tiles out dynamically, wave by wave from per-XCD counters, levelled the waves' end times — idle wave-slot time 6.3 % -> 3.2 % —
     // and gained nothing: the SIMDs were busy either way, profiles/r03_ab_scheduling.txt.)
     int cur_frame = 0;
+#if GFW_CK
+    ck_acc = 0; ck_l = 0; ck_c64 = 0; ck_l0 = 0; ck_l1 = 0; ck_c = 0;
+#endif
     for (int slot = (int)blockIdx.x >> 3; slot < n_slots; slot += wg_per_xcd) {
         const int fi = n_frames > 1 ? slot / per_xcd : 0;
         const int t = xcd_tile(fi, slot - fi * per_xcd);
         if (t >= n_tiles) continue;                  // the last sub-bands are the short ones
 #if GFW_BAKE
         if (fi != cur_frame) {                       // next frame of the launch: its planes and its matrices
+#if GFW_CK
+            ck_flush(cur_frame, fi);
+#endif
             cur_frame = fi;
             PL0.src = clip->fr[fi].src[0]; PL0.dst = clip->fr[fi].dst[0]; PL1.src = clip->fr[fi].src[1]; PL1.dst = clip->fr[fi].dst[1];
             PL2.src = clip->fr[fi].src[2]; PL2.dst = clip->fr[fi].dst[2]; PL3.src = clip->fr[fi].src[3]; PL3.dst = clip->fr[fi].dst[3];
@@ -1664,10 +1803,10 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                                     const uint32_t vu = inside_value1<T>(PL1.src, PL1.src_stride, bc, &bg_c[0], lim_u);
                                     const uint32_t vv = inside_value1<T>(PL2.src, PL1.src_stride, bc, &bg_v, lim_v);
                                     const int doff = row_off(ly, PL0.dst_stride) + (cx * DW) * (int)sizeof(T);
-                                    if constexpr (DW == 2) store_pair1<T>(PL0.dst, doff, val[0], val[1]);
-                                    else store_value1<T>(PL0.dst, doff, val[0]);
+                                    if constexpr (DW == 2) store_pair1<T>(PL0.dst, doff, val[0], val[1], CKA, CK_PAIR0);
+                                    else store_value1<T>(PL0.dst, doff, val[0], CKA);
                                     const int cdoff = row_off(cy, PL1.dst_stride) + cx * (int)sizeof(T);
-                                    store_value1<T>(PL1.dst, cdoff, vu); store_value1<T>(PL2.dst, cdoff, vv);
+                                    store_value1<T>(PL1.dst, cdoff, vu, CKA); store_value1<T>(PL2.dst, cdoff, vv, CKA);
                                     row_done = true;
                                 }
                             }
@@ -1701,8 +1840,11 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                             }
                             const int doff = row_off(ly, PL0.dst_stride) + (cx * DW) * (int)sizeof(T);
                             if (GFW_BAKE && (AF(ablate) & 16)) { if (lane == 99 && val[0] == 0x12345u) PL0.dst[0] = 1; }
-                            else if constexpr (DW == 2) store_pair1<T>(PL0.dst, doff, val[0], val[1]);
-                            else store_value1<T>(PL0.dst, doff, val[0]);
+                            else if constexpr (DW == 2) store_pair1<T>(PL0.dst, doff, val[0], val[1], CKL, CK_PAIR0);
+                            else store_value1<T>(PL0.dst, doff, val[0], CKL);
+#if GFW_CK
+                            if (CK_INV0 && CK_HOT) ck_luma(val);
+#endif
                         } else {
                             #pragma unroll
                             for (int i = 0; i < DW; ++i) {
@@ -1799,18 +1941,25 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                                     const uint32_t w = Tap::wpack(bc.kx);
                                     uint32_t ua, va, ub, vb;
                                     Tap::dot(r0, w, ua, va); Tap::dot(r1, w, ub, vb);
-                                    store_pair1<T>(PL1.dst, doff, hot_blend(ua, ub, bc.ky, lim_u), hot_blend(va, vb, bc.ky, lim_u));
+                                    store_pair1<T>(PL1.dst, doff, hot_blend(ua, ub, bc.ky, lim_u), hot_blend(va, vb, bc.ky, lim_u), CKA, CK_PAIR1);      // (8-bit pairs: through the lane's general sum)
                                 } else {
                                     float o[2];
                                     taps_inside2<T, 2>(PL1.src, off0, PL1.src_stride, bc, lim_u, o);
                                     const bool sat = px_needs_sat<T>(bg_c, 2, lim_u);
-                                    store_pair1<T>(PL1.dst, doff, sat ? gfw_f2u_sat(o[0], 65535.0f) : gfw_f2u_trunc(o[0]), sat ? gfw_f2u_sat(o[1], 65535.0f) : gfw_f2u_trunc(o[1]));
+                                    const uint32_t p0 = sat ? gfw_f2u_sat(o[0], 65535.0f) : gfw_f2u_trunc(o[0]), p1 = sat ? gfw_f2u_sat(o[1], 65535.0f) : gfw_f2u_trunc(o[1]);
+                                    store_pair1<T>(PL1.dst, doff, p0, p1, CKC, CK_PAIR1);
+#if GFW_CK
+                                    if (CK_INVC) ck_c64 += (unsigned long long)p0 + ((unsigned long long)p1 << (8 * sizeof(T)));      // (interleaved 16-bit chroma: one 64-bit sum)
+#endif
                                 }
                             } else {
                                 const uint32_t vu = inside_value1<T>(PL1.src, PL1.src_stride, bc, &bg_c[0], lim_u);
                                 const uint32_t vv = inside_value1<T>(PL2.src, PL1.src_stride, bc, &bg_v, lim_v);
                                 const int doff = row_off(cy, PL1.dst_stride) + cx * (int)sizeof(T);
-                                store_value1<T>(PL1.dst, doff, vu); store_value1<T>(PL2.dst, doff, vv);
+                                store_value1<T>(PL1.dst, doff, vu, CKC); store_value1<T>(PL2.dst, doff, vv, CKC);
+#if GFW_CK
+                                if (CK_INVC && CK_HOT) { if constexpr (CK_WIDE) ck_c64 += (unsigned long long)vu + vv; else ck_c += ck_bits1(vu) + ck_bits1(vv); }
+#endif
                             }
                             chroma_done = true;
                         }
@@ -1823,9 +1972,12 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                             const uint32_t vb = AF(nplanes) > 2 ? inside_value1<T>(PL2.src, PL1.src_stride, bc, PL2.bg, PL2.limit) : 0u;
                             const uint32_t vc = AF(nplanes) > 3 ? inside_value1<T>(PL3.src, PL1.src_stride, bc, PL3.bg, PL3.limit) : 0u;
                             const int doff = row_off(cy, PL1.dst_stride) + cx * (int)sizeof(T);
-                            store_value1<T>(PL1.dst, doff, va);
-                            if (AF(nplanes) > 2) store_value1<T>(PL2.dst, doff, vb);
-                            if (AF(nplanes) > 3) store_value1<T>(PL3.dst, doff, vc);
+                            store_value1<T>(PL1.dst, doff, va, CKC);
+                            if (AF(nplanes) > 2) store_value1<T>(PL2.dst, doff, vb, CKC);
+                            if (AF(nplanes) > 3) store_value1<T>(PL3.dst, doff, vc, CKC);
+#if GFW_CK
+                            if (CK_INVC) ck_c64 += (unsigned long long)ck_bits1(va) + (AF(nplanes) > 2 ? ck_bits1(vb) : 0u) + (unsigned long long)(AF(nplanes) > 3 ? ck_bits1(vc) : 0u);
+#endif
                             chroma_done = true;
                         }
                     }
@@ -1836,7 +1988,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                             const uint32_t vu = inside_value1_lut<T, I>(PL1.src, PL1.src_stride, cbx, cby, &bg_c[0], lim_u, s_lut);
                             const uint32_t vv = inside_value1_lut<T, I>(PL2.src, PL1.src_stride, cbx, cby, &bg_v, lim_v, s_lut);
                             const int doff = row_off(cy, PL1.dst_stride) + cx * (int)sizeof(T);
-                            store_value1<T>(PL1.dst, doff, vu); store_value1<T>(PL2.dst, doff, vv);
+                            store_value1<T>(PL1.dst, doff, vu, CKA); store_value1<T>(PL2.dst, doff, vv, CKA);
                             chroma_done = true;
                         }
                     }
@@ -1866,6 +2018,9 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
         { const unsigned long long tl_c = __builtin_readcyclecounter(); tl_p1 += tl_b - tl_a; tl_p3 += tl_c - tl_b; tl_units += (unsigned long long)RB; }
 #endif
     }
+#if GFW_CK
+    ck_flush(cur_frame, n_frames);
+#endif
 #if GFW_TIMELINE
     if (lane == 0) {       // per wave: start, end (100 MHz device clock), phase clocks, lane-rows, HW_ID, XCC_ID, workgroup
         unsigned long long *o = gfw_tl + ((size_t)blockIdx.x * 4 + wave) * 8;

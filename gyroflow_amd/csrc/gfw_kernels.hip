@@ -272,6 +272,58 @@ hipError_t gfw_launch_checksum64(const void *buf, size_t bytes, unsigned long lo
     return hipGetLastError();
 }
 
+// gfw_set_frame_checksums, behind a launch of the checksum build of the fused kernel: the words of frame f in the launch's table of partial sums
+// ([frame][workgroup][wave], every word written by its wave) added to the frame's sum.  GFW_CK_SPLIT workgroups per frame, one word per lane and pass, one atomic per
+// workgroup — the first version (ONE workgroup per frame walking 8192 words, 32 dependent passes) took longer than the checksum pass it replaces: C5 50.0 us per
+// frame against 53.2, with 42.0 of warp (profiles/r05_c5_checksum.txt).
+#define GFW_CK_SPLIT 16
+__global__ __launch_bounds__(256) void gfw_ck_finish_kernel(const unsigned long long *part, int per_frame, GfwCkSums S) {
+    __shared__ unsigned long long w[4];
+    const int f = blockIdx.x / GFW_CK_SPLIT, k = blockIdx.x % GFW_CK_SPLIT;
+    const unsigned long long *p = part + (size_t)f * per_frame;
+    unsigned long long a0 = 0, a1 = 0;
+    int i = k * 256 + threadIdx.x;
+    for (; i + GFW_CK_SPLIT * 256 < per_frame; i += 2 * GFW_CK_SPLIT * 256) { a0 += p[i]; a1 += p[i + GFW_CK_SPLIT * 256]; }      // (two loads in flight)
+    if (i < per_frame) a0 += p[i];
+    unsigned long long acc = a0 + a1;
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && S.sum[f]) atomicAdd(S.sum[f], w[0] + w[1] + w[2] + w[3]);
+}
+hipError_t gfw_launch_ck_finish(const unsigned long long *part, int per_frame, int n_frames, const GfwCkSums &sums, hipStream_t s) {
+    if (n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gfw_ck_finish_kernel, dim3((unsigned)n_frames * GFW_CK_SPLIT), dim3(256), 0, s, part, per_frame, sums);
+    return hipGetLastError();
+}
+// ... and behind every other kernel: the checksum of a written region, byte times 256^(address mod 8).  A lane takes the aligned words of a row in turn: a word
+// that lies inside the row whole IS its own contribution; the row's two ends go byte by byte.
+__global__ __launch_bounds__(256) void gfw_ck_region_kernel(const uint8_t *dst, long long first_byte, long long stride, int row_bytes, int rows, unsigned long long *out) {
+    __shared__ unsigned long long w[4];
+    unsigned long long acc = 0;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        const uint8_t *a = dst + first_byte + (long long)r * stride, *e = a + row_bytes;
+        const uintptr_t w0 = (uintptr_t)a & ~(uintptr_t)7;
+        const int n_words = (int)(((uintptr_t)e + 7 - w0) >> 3);
+        for (int j = threadIdx.x; j < n_words; j += 256) {
+            const uint8_t *q = (const uint8_t *)(w0 + (uintptr_t)8 * j);
+            if (q >= a && q + 8 <= e) acc += *reinterpret_cast<const unsigned long long *>(q);
+            else for (int b = 0; b < 8; ++b) if (q + b >= a && q + b < e) acc += (unsigned long long)q[b] << (8 * b);
+        }
+    }
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, w[0] + w[1] + w[2] + w[3]);
+}
+hipError_t gfw_launch_ck_region(const uint8_t *dst, long long first_byte, long long stride, int row_bytes, int rows, unsigned long long *out, hipStream_t s) {
+    if (rows <= 0 || row_bytes <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gfw_ck_region_kernel, dim3((unsigned)(rows < 256 ? rows : 256)), dim3(256), 0, s, dst, first_byte, stride, row_bytes, rows, out);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------- test hooks (gfw_debug_*)
 __global__ void gfw_debug_math_kernel(int op, const float *a, const float *b, float *out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

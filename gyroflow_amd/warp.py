@@ -91,6 +91,11 @@ class Backend:
         """hipStream_t the context enqueues on (an int), after whatever it holds for a frame or a launch has been enqueued (gfw_get_stream flushes)."""
         return self.lib.gfw_get_stream(self.ctx)
 
+    def set_frame_checksums(self, d_sums_ptr, count):
+        """From now on frame k submitted on the context adds the checksum of the bytes it writes to the device word d_sums_ptr[k % count] (gfw_set_frame_checksums);
+        (0, 0) turns it off."""
+        self._check(self.lib.gfw_set_frame_checksums(self.ctx, d_sums_ptr, count))
+
     def jit_status(self):
         """(state, compile milliseconds, compiler log) of the context's run-time specialised kernel; state 0 none / unavailable,
         1 compiling, 2 ready, 3 failed (gfw_jit_status)."""

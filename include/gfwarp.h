@@ -361,6 +361,13 @@ int   gfw_release_external(gfw_external *handle);
  * all-gathered across ranks): adds the sum of the u64 words of a device buffer (mod 2^64) to *d_out, enqueued in order
  * on the context's stream.  `bytes` a multiple of 8, `d_buf` 16-byte aligned, `d_out` a zero-initialised device word. */
 int   gfw_checksum64(gfw_ctx *ctx, const void *d_buf, size_t bytes, unsigned long long *d_out);
+/* The same checksum taken WHERE THE PIXELS LEAVE: from this call on, frame k submitted on the context (k = 0, 1, ...: a gfw_undistort_frame call, a frame of
+ * gfw_undistort_clip, a frame assembled from coalesced gfw_undistort_image calls, a lone gfw_undistort_image call) adds the checksum of every byte it WRITES —
+ * the byte times 256^(its address mod 8), modulo 2^64: what gfw_checksum64 of a zero-initialised destination holds afterwards — to d_sums[k mod count], in
+ * order on the context's stream.  `d_sums`: `count` device words the caller zeroed; NULL or count = 0 turns it off.  A specialised fused kernel takes the sum in
+ * its store path (no second pass over the output: 33 MB per C2 frame, 11 us); every other kernel is followed by a pass over the written region — same value.
+ * HIP_DEVICE outputs only (GFW_ERR_INVALID_ARGUMENT from the frame's call otherwise). */
+int   gfw_set_frame_checksums(gfw_ctx *ctx, unsigned long long *d_sums, size_t count);
 
 /* ---- per-row matrices on the device ("next" row: FrameTransform::at_timestamp, frame_transform.rs:221-308) ----
  * gfw_set_quaternion_tracks uploads the clip's original and smoothed orientation tracks once

@@ -25,7 +25,7 @@ def rotated_frame_size(p0):
     return libm.roundf(abs(float(fx))), libm.roundf(abs(float(fy)))
 
 
-def bake_header(frame, rb=4):
+def bake_header(frame, rb=4, checksum=0):
     pls = frame.planes
     p0 = pls[0]["params"]
     w, h = p0.width, p0.height
@@ -39,7 +39,7 @@ def bake_header(frame, rb=4):
     d = {"nplanes": n, "width": w, "height": h, "out_w": ow, "out_h": oh, "cw": cw, "ch": ch, "tiles_x": (cw + 63) // 64,
          "tiles_y": (ch + 4 * rb - 1) // (4 * rb), "matrix_count": p0.matrix_count, "hrs": 1 if p0.flags & 16 else 0, "model": frame.model,
          "k_all_zero": 1 if all(p0.k[i] == 0.0 for i in range(4)) else 0, "background_mode": p0.background_mode, "extras": 0, "ablate": 0, "digital": 0,
-         "fill_bg": 1 if p0.flags & 4 else 0, "rot_on": 1 if p0.input_rotation != 0.0 else 0, "fix_range": 1 if p0.flags & 1 else 0,
+         "fill_bg": 1 if p0.flags & 4 else 0, "rot_on": 1 if p0.input_rotation != 0.0 else 0, "fix_range": 1 if p0.flags & 1 else 0, "checksum": checksum,
          "hstretch_div": 1 if (p0.input_horizontal_stretch > 0.001 and p0.input_horizontal_stretch != 1.0) else 0,
          "vstretch_div": 1 if (p0.input_vertical_stretch > 0.001 and p0.input_vertical_stretch != 1.0) else 0}
     out = ["#define GFW_BK_%s (%d)" % kv for kv in d.items()]

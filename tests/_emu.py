@@ -56,7 +56,7 @@ def guarded(data, at_end):
     return arr
 
 
-def kernel_source(top="gfw_frame.hip", n_asm=9):
+def kernel_source(top="gfw_frame.hip", n_asm=13):
     """`top` + the project headers it includes as one text (gen_jit_source.expand, without its typedef prelude: the host has <stdint.h>), asm -> emu_*()."""
     out = []
     G.expand(os.path.join(G.CSRC, top), set(), out)
@@ -74,7 +74,7 @@ def kernel_source(top="gfw_frame.hip", n_asm=9):
     return src
 
 
-def build(defs, header, top="gfw_frame.hip", n_asm=9, driver="emu_driver.inc", extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=1"), opt="-O1"):
+def build(defs, header, top="gfw_frame.hip", n_asm=13, driver="emu_driver.inc", extra_flags=("-DGFW_JIT=1", "-DGFW_BAKE=1"), opt="-O1"):
     """-> path of the host library for these template arguments (+ bake header) (cached under build/emu/ by content)."""
     if not CXX.endswith("clang++"):
         import pytest
@@ -341,13 +341,14 @@ def jit_waves(n0, matrix_count, jit_model, extras, taps, bps, dh):
     return 8 if (n0 == 1 and matrix_count > 1) else 7
 
 
-def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=False):
+def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=False, checksums=False):
     """One clip launch of the host-interpreted kernel over `frames` (same shape and constants, <= 16) -> [[plane outputs] per frame].
     `votes`: 0 = a wave vote answers with the lane's own predicate, 1 = as if another lane of the wave failed it (every lane takes the general route).
     `audit`: the audit instantiation (ahead-of-time form, bilinear): -> (outputs, dict of the audit words: certificates issued / wrong, queued pixels,
     largest |approximate - exact| first-pass coordinate, addresses outside the declared buffers).
     `hw_ulp`: the stand-ins for v_rcp_f32 / v_sqrt_f32 return the correctly rounded value moved by this many ulps (the hardware's are 1-ulp approximations).
     `grid`: persistent workgroups of the launch (a multiple of 8; the library launches num_cus x waves, capped at the tile count).
+    `checksums`: the build that takes each frame's checksum where the pixels leave (GFW_BK_checksum, gfw_set_frame_checksums) -> (outputs, [checksum per frame]).
     baked=False: the ahead-of-time form of the same body (every clip-invariant field read from the argument block instead of a literal; one frame)."""
     fr0 = frames[0]
     p0 = fr0.planes[0]["params"]
@@ -368,7 +369,8 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=F
     defs = {"GFW_FRAME_KIND": bps, "GFW_FRAME_TAPS": p0.interpolation, "GFW_JIT_WAVES": jit_waves(n0, p0.matrix_count, jit_model, extras, p0.interpolation, bps, dh), "GFW_JIT_MODEL": jit_model,
             "GFW_JIT_T": {1: "uint8_t", 2: "uint16_t", 3: "_Float16", 4: "float"}[bps], "GFW_JIT_N0": n0, "GFW_JIT_DW": dw, "GFW_JIT_DH": dh,
             "GFW_JIT_IL": 1 if il else 0, "GFW_JIT_RB": rb, "GFW_JIT_FAST1": 1 if fast1 else 0}
-    header = _bake.bake_header(fr0, rb=rb)
+    assert not checksums or (baked and not audit)
+    header = _bake.bake_header(fr0, rb=rb, checksum=1 if checksums else 0)
     header, n1 = re.subn(r"#define GFW_BK_extras \(0\)", "#define GFW_BK_extras (%d)" % extras, header)
     header, n2 = re.subn(r"#define GFW_BK_digital \(0\)", "#define GFW_BK_digital (%d)" % (fr0.digital if extras & 2 else 0), header)
     assert n1 == 1 and n2 == 1
@@ -412,6 +414,9 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=F
         mesh = np.ascontiguousarray(mesh, dtype=np.float32)
         com.mesh, com.mesh_len = mesh.ctypes.data, mesh.size
     kp = fr0.planes[0]["params"]
+    sums = (C.c_ulonglong * n)()
+    lib.gfw_emu_set_sums.argtypes = [C.c_void_p]
+    lib.gfw_emu_set_sums(C.cast(sums, C.c_void_p) if checksums else None)
     rc = lib.gfw_emu_launch(n, srcs, dsts, mats, tab.ctypes.data, p1[1] if fast1 else 0.0, p1[2] if fast1 else 0.0, *(p1[3][:3] if fast1 else (0.0, 0.0, 0.0)),
                             C.cast(C.byref(kp), C.c_void_p), C.cast(C.byref(com), C.c_void_p), grid, pints.ctypes.data, pfloats.ctypes.data,
                             p1[4].ctypes.data if fast1 else None)
@@ -423,6 +428,8 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=F
         return outs, {"certified": int(words[0]), "wrong": int(words[1]), "queued": int(words[2]), "queue_overflow": int(words[3]), "gap_px": gap,
                       "out_of_range": int(words[5]), "eps_px": float(np.array([int(words[6]) & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0]) if fast1 else None,
                       "eps_host_px": p1[3][3] if fast1 else None}
+    if checksums:
+        return outs, [int(v) for v in sums]
     return outs
 
 

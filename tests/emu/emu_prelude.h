@@ -77,6 +77,8 @@ static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned m, unsigned base) { co
 // queue length right after a fence, then lanes push new entries).
 void emu_wave_atomic_point();
 template <typename T> static inline T atomicAdd(T *p, T v) { emu_wave_atomic_point(); const T old = *p; *p = (T)(old + v); return old; }
+// a lane's add into an LDS word of its own (the checksum slots of gfw_frame.hip): nobody else reads it before a fence
+#define GFW_LDS_ADD(p, v) ((void)(*(p) += (v)))
 
 // ---- hardware instructions and builtins --------------------------------------------------------------------------------
 static inline float emu_sat_i32(float v) { return v; }

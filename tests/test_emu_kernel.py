@@ -258,3 +258,48 @@ def test_packed_half_float_pixels_through_the_fused_kernel(interp, fov):
     """RGBAf16 (pixel_formats.rs:227-246: half::f16 to_f32 on load, from_f32 — round to nearest even — on store) on the fused kernel since round 5: the f32 packed path
     with the conversions at the fetch and the store; both kernel forms against the oracle, interior and zoomed-out (background, edge taps)."""
     same_as_oracle(S.SyntheticFrame("RGBAF16", 322, 186, seed=61, fov=fov, interpolation=interp, background_rgba=(0.2, 0.4, 0.6, 0.8)))
+
+
+# ---- the frame's checksum taken where the pixels leave (GFW_BK_checksum builds: gfw_set_frame_checksums) ----------------------------------
+
+def written_checksum(fr, outs):
+    """What gfw_checksum64 of a zero-initialised destination would hold after the frame: every byte the kernel writes (the output pixels: stride padding and the
+    planes' untouched tails stay out) times 256^(its address mod 8), summed modulo 2^64 — computed from the planes the interpreter wrote, at THEIR addresses."""
+    total = 0
+    for pl, arr in zip(fr.planes, outs):
+        ow, oh, stride = pl["out_size"]
+        row_bytes = ow * pl["params"].bytes_per_pixel
+        rows = np.frombuffer(arr, np.uint8)[:oh * stride].reshape(oh, stride)[:, :row_bytes]
+        pos = (arr.ctypes.data + np.arange(oh, dtype=np.int64)[:, None] * stride + np.arange(row_bytes, dtype=np.int64)[None, :]) & 7
+        for k in range(8):
+            total += int(rows[pos == k].astype(np.uint64).sum()) << (8 * k)
+    return total & 0xFFFFFFFFFFFFFFFF
+
+
+@pytest.mark.parametrize("fmt,kw,n,grid", [
+    ("YUV422P16LE", dict(), 3, 8),                                   # the branch-free lane-row: pair stores of luma, single chroma values; three frames = two frame changes per wave
+    ("YUV422P16LE", dict(interpolation=4), 1, 8),
+    ("NV12", dict(), 2, 16),                                         # interleaved 8-bit chroma pairs (a pair may sit anywhere in a word)
+    ("YUV420P", dict(interpolation=8), 1, 8),
+    ("P010LE", dict(fov=1.6), 2, 8),                                 # out-of-frame pixels: the background goes through the same stores
+    ("RGBAF32", dict(), 1, 8),
+    ("GBRAPF32LE", dict(), 2, 8),
+    ("RGBAF16", dict(), 1, 8),
+    ("YUV444P16LE", dict(base_overrides={"lens_correction_amount": 0.5}), 1, 8),      # a generic-model body
+])
+def test_checksum_taken_at_the_stores_is_the_checksum_of_what_was_written(fmt, kw, n, grid):
+    frames = [S.SyntheticFrame(fmt, 200, 120, seed=0xC5 + j, timestamp_ms=1000.0 + 33.3 * j, **kw) for j in range(n)]
+    outs, sums = _emu.run_frames(frames, grid=grid, checksums=True)
+    for j, (fr, got, s) in enumerate(zip(frames, outs, sums)):
+        for p, (a, b) in enumerate(zip(O.run_frame(fr), got)):
+            assert np.array_equal(a, b), "frame %d plane %d" % (j, p)
+        assert s == written_checksum(fr, got), "frame %d: %016x" % (j, s)
+
+
+def test_checksum_words_of_frames_a_wave_has_no_tile_of_are_written_too():
+    """64 workgroups for a frame of 4 tiles: most waves never see a tile of most frames, and still own a word of every frame in the launch's table of partial
+    sums — the interpreter's table starts poisoned, so a word left unwritten shows."""
+    frames = [S.SyntheticFrame("YUV422P16LE", 192, 48, seed=0x5C + j, timestamp_ms=1000.0 + 33.3 * j) for j in range(5)]
+    outs, sums = _emu.run_frames(frames, grid=64, checksums=True)
+    for fr, got, s in zip(frames, outs, sums):
+        assert s == written_checksum(fr, got)
