@@ -121,3 +121,36 @@ def test_bytes_the_frame_does_not_write_stay_out_of_its_checksum():
     _, sums_z, ref_z, _, _ = run_clip(frames, 2, True, zero=True)
     _, sums_d, _, _, _ = run_clip(frames, 2, True, zero=False)
     assert sums_z == ref_z and sums_d == sums_z
+
+
+def test_frames_assembled_from_per_plane_calls_take_their_checksum_on_the_owner_context():
+    """The render loop's call sequence (one gfw_undistort_image per plane, each plane a context of its own, coalesced into one fused launch): the frame runs on the
+    context that took plane 0 — the option is that context's."""
+    import torch
+    from test_gpu_coalesce import PlaneLoop, clip
+    frames = clip("YUV422P16LE", 320, 192, 5)
+    loop = PlaneLoop(frames, jit=2, frames_per_launch=2)
+    try:
+        dev = loop.dev
+        for planes in loop.d_dst:
+            for t in planes:
+                t.zero_()
+        d_sums = torch.zeros(5, dtype=torch.int64, device=dev)
+        d_ref = torch.zeros(5, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        loop.be[0].set_frame_checksums(d_sums.data_ptr(), 5)
+        for j in range(5):
+            loop.frame(j)
+        loop.be[-1].synchronize()
+        names = [warp.Backend.last_backend_of(be) for be in loop.be]
+        assert all(n.startswith("yuv_fused") for n in names), names
+        loop.be[0].set_frame_checksums(0, 0)
+        for j in range(5):
+            for t in loop.d_dst[j]:
+                assert loop.be[0].lib.gfw_checksum64(loop.be[0].ctx, t.data_ptr(), t.numel(), d_ref.data_ptr() + 8 * j) == 0
+        loop.be[0].synchronize()
+        torch.cuda.synchronize(dev)
+        got, ref = d_sums.cpu().numpy().tolist(), d_ref.cpu().numpy().tolist()
+        assert got == ref and len(set(got)) == 5, (got, ref)
+    finally:
+        loop.close()
