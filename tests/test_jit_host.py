@@ -130,3 +130,25 @@ def test_a_compiler_option_travels_through_the_definition_list(tmp_path):
         if tag == "default":
             assert k[".vgpr_count"] <= 64 and k[".private_segment_fixed_size"] == 0, k
     assert counts["default"] <= 8 and counts["slp"] > 50, counts
+
+
+def test_the_checksum_build_takes_its_sums_without_a_private_segment(tmp_path):
+    """gfw_set_frame_checksums: the checksum build of C2's kernel (GFW_BK_checksum = 1) as jit_waves budgets it — seven waves per SIMD.  What the option costs is
+    registers, not instructions: builds whose fold left lane-derived values in scratch across the kernel ran 8-10 % slower on the MI355X (a kernel with ANY private
+    segment starts its 8192 waves slowly: profiles/r05_c5_checksum.txt), so the shipped form must have none; its LDS grows by the 256 lane slots and the four wave words."""
+    lib = abi.load_library()
+    plain = open(os.path.join(ROOT, "tools", "bake_c2.h")).read()
+    assert "#define GFW_BK_checksum (0)" in plain
+    got = {}
+    for name, header in (("plain", plain), ("checksum", plain.replace("#define GFW_BK_checksum (0)", "#define GFW_BK_checksum (1)"))):
+        out = str(tmp_path / (name + ".co"))
+        log = C.create_string_buffer(1 << 16)
+        n = lib.gfw_debug_jit_compile(b"gfx950", (C2_DEFS % (2, 7)).encode(), header.encode(), out.encode(), log, len(log))
+        if n == -2:
+            pytest.skip("libhiprtc.so not available")
+        assert n > 0, log.value.decode(errors="replace")[-3000:]
+        got[name] = [k for k in KR.report(out) if k[".name"] == "gfw_jit_kernel"][0]
+    k, kp = got["checksum"], got["plain"]
+    assert k[".private_segment_fixed_size"] == 0 and k[".vgpr_count"] <= 72, (k[".vgpr_count"], k[".private_segment_fixed_size"])
+    assert KR.workgroups_per_cu(k) >= 7, KR.workgroups_per_cu(k)
+    assert k[".group_segment_fixed_size"] - kp[".group_segment_fixed_size"] in range(2048, 2048 + 128), (k[".group_segment_fixed_size"], kp[".group_segment_fixed_size"])
