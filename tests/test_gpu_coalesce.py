@@ -337,7 +337,7 @@ def test_threads_assembling_frames_side_by_side_do_not_wait_for_each_others_laun
                 loop.check(j, "thread %d %s" % (i, fmts[i]))
         build = done[0] - t0
         if build > 0.3:                            # (a cached code object makes the build instantaneous: nothing to compare then)
-            assert max(done[1:]) - t0 < 0.5 * build, [d - t0 for d in done]
+            assert max(done[1:]) - t0 < 0.8 * build, [d - t0 for d in done]      # (behind the lock they would end AFTER the build; measured: 0.02-0.05 s against ~1 s)
     finally:
         for loop in loops:
             loop.close()
