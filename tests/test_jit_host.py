@@ -134,8 +134,8 @@ def test_a_compiler_option_travels_through_the_definition_list(tmp_path):
 
 def test_the_checksum_build_takes_its_sums_without_a_private_segment(tmp_path):
     """gfw_set_frame_checksums: the checksum build of C2's kernel (GFW_BK_checksum = 1) as jit_waves budgets it — seven waves per SIMD.  What the option costs is
-    registers, not instructions: builds whose fold left lane-derived values in scratch across the kernel ran 8-10 % slower on the MI355X (a kernel with ANY private
-    segment starts its 8192 waves slowly: profiles/r05_c5_checksum.txt), so the shipped form must have none; its LDS grows by the 256 lane slots and the four wave words."""
+    registers, not instructions: builds whose fold left lane-derived values in scratch across the kernel ran 4-10 % slower on the MI355X than their scratch-free twins
+    (same instruction count, all waves resident: profiles/r05_c5_checksum.txt), so the shipped form must have none; its LDS grows by the 256 lane slots and the four wave words."""
     lib = abi.load_library()
     plain = open(os.path.join(ROOT, "tools", "bake_c2.h")).read()
     assert "#define GFW_BK_checksum (0)" in plain
