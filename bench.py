@@ -20,7 +20,8 @@ all-gather of output checksums.
 
 Modes: default = weak scaling (every rank warps its own K frames of C2); `--c5` = BASELINE.json configs[4]: a
 10 000-frame clip whose frames are dealt round-robin to the ranks (strong scaling), each frame's per-row matrices built
-on the device from the clip's quaternion tracks, a 64-bit checksum per frame all-gathered at the end.
+on the device from the clip's quaternion tracks, a 64-bit checksum per frame — taken by the warp kernel where the pixels
+leave (gfw_set_frame_checksums; `--sum-pass`: a gfw_checksum64 pass over each destination instead) — all-gathered at the end.
 
 Prints ONE JSON line (rank 0) with
   roofline     — algorithmic HBM bytes/launch (sum over planes of w*h*bpp read + written) over the
