@@ -154,3 +154,55 @@ def test_frames_assembled_from_per_plane_calls_take_their_checksum_on_the_owner_
         assert got == ref and len(set(got)) == 5, (got, ref)
     finally:
         loop.close()
+
+
+@pytest.mark.parametrize("fmt,interp", [("YUV422P16LE", 2), ("NV12", 4), ("RGBAF32", 2)])
+def test_output_rects_only_the_rect_is_written_and_only_the_rect_is_summed(fmt, interp):
+    """HAS_OUTPUT_RECT / HAS_SOURCE_RECT frames (the per-plane kernel's: plugins' sub-windows): pixels outside the output rect keep the caller's bytes (0x5A here) and
+    stay out of the frame's word, which is computed HERE from the oracle's planes at the device addresses of the destinations."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(0x4EC7 + interp)
+    fr = S.SyntheticFrame(fmt, 322, 190, seed=0x77, fov=0.85, interpolation=interp)
+    for pl in fr.planes:
+        p = pl["params"]
+        (pw, ph), (ow, oh) = pl["size"][:2], pl["out_size"][:2]
+        x0, y0 = int(rng.integers(1, pw // 5)), int(rng.integers(1, ph // 5))
+        p.source_rect[0], p.source_rect[1], p.source_rect[2], p.source_rect[3] = x0, y0, pw - x0 - int(rng.integers(1, pw // 5)), ph - y0 - int(rng.integers(1, ph // 5))
+        x0, y0 = int(rng.integers(1, ow // 5)), int(rng.integers(1, oh // 5))
+        p.output_rect[0], p.output_rect[1], p.output_rect[2], p.output_rect[3] = x0, y0, ow - x0 - int(rng.integers(1, ow // 5)), oh - y0 - int(rng.integers(1, oh // 5))
+        p.flags |= abi.FLAG_HAS_SOURCE_RECT | abi.FLAG_HAS_OUTPUT_RECT
+    d_src, d_dst = fr.device_planes(dev), fr.device_outputs(dev)                   # destinations pre-filled with 0x5A
+    d_mat = torch.from_numpy(warp.pack_matrices(fr.matrices)).to(dev)
+    d_sum = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+    types, params = [pl["pixel_type"] for pl in fr.planes], [pl["params"] for pl in fr.planes]
+    bufs = [warp.device_buffers(d_src[p].data_ptr(), d_src[p].numel(), pl["size"], d_dst[p].data_ptr(), d_dst[p].numel(), pl["out_size"]) for p, pl in enumerate(fr.planes)]
+    be = warp.Backend(params[0], types[0], fr.model, fr.digital, bufs[0])
+    try:
+        be.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        be.set_option(abi.OPT_SYNCHRONOUS, 0)
+        be.set_option(abi.OPT_MATRICES_ON_DEVICE, 2)
+        be.set_frame_checksums(d_sum.data_ptr(), 1)
+        warp.FrameCall(be, bufs, params, types, d_mat.data_ptr(), fr.matrices.shape[0])()
+        be.synchronize()
+        assert warp.last_backend() == "plane_generic", warp.last_backend()
+    finally:
+        be.close()
+    torch.cuda.synchronize(dev)
+    got = [t.cpu().numpy() for t in d_dst]
+    ref = O.run_frame(_View(fr, [t.cpu().numpy() for t in d_src]))
+    want = 0
+    for p, pl in enumerate(fr.planes):
+        assert_plane_equal(ref[p], got[p], pl["pixel_type"], "plane %d" % p)
+        assert np.count_nonzero(got[p] == 0x5A) > 0
+        q = pl["params"]
+        ow, oh, stride = pl["out_size"]
+        bpp = q.bytes_per_pixel
+        rows = np.frombuffer(ref[p], np.uint8)[:oh * stride].reshape(oh, stride)
+        x0, y0, rw, rh = (int(v) for v in q.output_rect)
+        sub = rows[y0:y0 + rh, x0 * bpp:(x0 + rw) * bpp]
+        pos = (d_dst[p].data_ptr() + (np.arange(y0, y0 + rh, dtype=np.int64)[:, None] * stride) + np.arange(x0 * bpp, (x0 + rw) * bpp, dtype=np.int64)[None, :]) & 7
+        for k in range(8):
+            want += int(sub[pos == k].astype(np.uint64).sum()) << (8 * k)
+    assert (int(d_sum.cpu().numpy()[0]) & 0xFFFFFFFFFFFFFFFF) == (want & 0xFFFFFFFFFFFFFFFF)
