@@ -45,7 +45,7 @@ struct GfwYuvArgs {
                                       // 8 lens-correction blend (lens_correction_amount < 1, :429-460),
                                       // 16 background mode 3: margin with feather (:576-613),
                                       // 32 Sony lens-distortion mesh / focal-plane distortion in `common.mesh` (:169-214)
-    int32_t ablate;                   // benchmark-only ablation bits (0 in production): 1 no first pass, 2 no luma taps, 4 no chroma, 8 no projection
+    int32_t ablate;                   // always 0 from the library; read only by GFW_TESTING builds of the kernel (the timing ablations of tools/ A/B runs: gfw_frame.hip)
     float hstretch, vstretch;
     float f[2], c[2], k[12];
     float t2[2];

