@@ -116,7 +116,6 @@ ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP = -9, -10, -11
 POINT_INDEX_SINGLE, POINT_INDEX_PER_POINT, POINT_INDEX_PER_ROW, POINT_INDEX_PER_COLUMN = 0, 1, 2, 3
 OPT_SYNCHRONOUS, OPT_MATRICES_ON_DEVICE, OPT_KERNEL_VARIANT, OPT_PROFILE, OPT_TUNE_ROWS, OPT_TUNE_GRID, OPT_JIT, OPT_COALESCE_PLANES, OPT_COALESCE_FRAMES = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OPT_FRAME_SYNC = 10
-OPT_PIN_HOST = 11
 CLIP_MAX = 16                    # GFW_CLIP_FRAMES_MAX: frames gfw_undistort_clip puts into one launch
 
 _lib = None

@@ -145,10 +145,6 @@ struct gfw_ctx {
     struct ClipBatch *held = nullptr;              // frames assembled from per-plane calls, waiting for their launch (owner context only)
     gfw_ctx *frame_owner = nullptr; bool needs_order = false;   // a member context: whose stream its planes were launched on, and whether its own stream has been ordered behind that yet
     std::vector<gfw_buffers> held_planes;          // ... and the descriptions those frames were validated with
-    // HOST buffers (BufferSource::Cpu, gpu/mod.rs:34 — what the render loop passes, rendering/mod.rs:522-525): the caller's ranges are page-locked on first sight and
-    // remembered (FFmpeg hands the same frame pool round and round), so that the copies of a frame are DMA at the link's rate instead of the runtime's pageable path
-    struct PinEntry { void *p; size_t len; unsigned long long tick; };
-    std::vector<PinEntry> pins; unsigned long long pin_tick = 0; size_t pin_bytes = 0; bool pin_host = true;      // GFW_OPT_PIN_HOST
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;   // recorded, not yet harvested
     size_t ev_used = 0;
@@ -310,8 +306,6 @@ void gfw_destroy(gfw_ctx *c) {
     for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &b : c->stage_src) b.release();
     for (auto &b : c->stage_dst) b.release();
-    for (auto &e : c->pins) (void)hipHostUnregister(e.p);
-    c->pins.clear(); (void)hipGetLastError();
     c->d_mesh.release(); c->d_ck_part.release(); c->d_p1_table.release(); c->d_audit.release(); c->d_tracks.release(); c->d_offsets.release(); for (auto &ss : c->sslots) { ss.d.release(); if (ss.h) (void)hipHostFree(ss.h); if (ss.done) (void)hipEventDestroy(ss.done); } c->d_prefix.release(); c->d_timings.release(); c->d_batch[0].release(); c->d_batch[1].release();
     if (c->h_timings) (void)hipHostFree(c->h_timings);
     for (auto &e : c->timing_copied) if (e) (void)hipEventDestroy(e);
@@ -343,9 +337,6 @@ int gfw_set_option(gfw_ctx *c, int option, int64_t value) {
                       c->jit_info = GfwJitInfo{GFW_JIT_UNAVAILABLE, 0.0, std::string()}; return GFW_OK;
     case GFW_OPT_COALESCE_PLANES: if (value < 0 || value > 2) { set_error("GFW_OPT_COALESCE_PLANES %lld (0..2)", (long long)value); return GFW_ERR_INVALID_ARGUMENT; }
                                   { const int frc = gfw_flush(c); if (frc != GFW_OK) return frc; c->coalesce_planes = (int)value; return GFW_OK; }
-    case GFW_OPT_PIN_HOST: c->pin_host = value != 0;
-                           if (!c->pin_host) { (void)hipStreamSynchronize(c->stream); for (auto &e : c->pins) (void)hipHostUnregister(e.p); c->pins.clear(); c->pin_bytes = 0; (void)hipGetLastError(); }
-                           return GFW_OK;
     case GFW_OPT_FRAME_SYNC: { const int frc = gfw_flush(c); if (frc != GFW_OK) return frc; c->frame_sync = value != 0; return GFW_OK; }
     case GFW_OPT_COALESCE_FRAMES: if (value < 1 || value > GFW_CLIP_FRAMES_MAX) { set_error("GFW_OPT_COALESCE_FRAMES %lld (1..%d)", (long long)value, GFW_CLIP_FRAMES_MAX); return GFW_ERR_INVALID_ARGUMENT; }
                                   { const int frc = gfw_flush(c); if (frc != GFW_OK) return frc; } c->coalesce_frames = (int)value; return GFW_OK;
@@ -691,27 +682,6 @@ static int clip_flush(gfw_ctx *c, ClipBatch *b) {
 // gfw_set_frame_checksums behind a kernel that does not take the sum itself: a pass over what the frame's kernels wrote — the pixels of each plane's output rect
 // (cpu_undistort.rs:546-551: nothing outside it is touched), whole pixels inside the declared length
 static int checksum_written(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params, unsigned long long *sum);
-// Page-locks a caller's host range (best effort: a range that cannot be registered — overlapping another registration, a read-only mapping, the limit of locked
-// memory — simply keeps the pageable path).  Per context, least recently used out: at most kPinEntries ranges / kPinBytes bytes stay locked.
-static void host_pin(gfw_ctx *c, const void *p, size_t len) {
-    static const bool off = [] { const char *e = getenv("GFW_PIN_HOST"); return e && e[0] == '0' && e[1] == 0; }();
-    constexpr size_t kPinEntries = 64, kPinBytes = (size_t)4 << 30;
-    if (off || !c->pin_host || !p || len < ((size_t)1 << 16)) return;                         // (small planes: the pageable path's latency is what they pay either way)
-    ++c->pin_tick;
-    for (auto &e : c->pins) if (e.p == p && e.len >= len) { e.tick = c->pin_tick; return; }
-    for (size_t i = 0; i < c->pins.size(); ) {                               // the same address with another length: the allocation changed hands
-        if (c->pins[i].p == p) { (void)hipHostUnregister(c->pins[i].p); c->pin_bytes -= c->pins[i].len; c->pins[i] = c->pins.back(); c->pins.pop_back(); } else ++i;
-    }
-    while (!c->pins.empty() && (c->pins.size() >= kPinEntries || c->pin_bytes + len > kPinBytes)) {
-        size_t lru = 0;
-        for (size_t i = 1; i < c->pins.size(); ++i) if (c->pins[i].tick < c->pins[lru].tick) lru = i;
-        (void)hipStreamSynchronize(c->stream);                                // (a copy from that range may still be in flight on an asynchronous context)
-        (void)hipHostUnregister(c->pins[lru].p); c->pin_bytes -= c->pins[lru].len;
-        c->pins[lru] = c->pins.back(); c->pins.pop_back();
-    }
-    if (hipHostRegister(const_cast<void *>(p), len, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return; }
-    c->pins.push_back({const_cast<void *>(p), len, c->pin_tick}); c->pin_bytes += len;
-}
 // What a plane's kernels WRITE: the pixels of its output rect (cpu_undistort.rs:546-551: nothing outside it is touched), whole pixels inside the declared length,
 // as runs of rows: fn(byte offset of the run's first pixel, bytes per row, rows).  The last row may be cut short by the declared length.
 template <typename F>
@@ -778,16 +748,16 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
         A.pix = pixel_types[i];
         if (b.input.kind == GFW_BUF_HOST) {
             HIP_TRY(c->stage_src[i].ensure(b.input.len), GFW_ERR_HIP);
-            host_pin(c, b.input.data, b.input.len);
             HIP_TRY(hipMemcpyAsync(c->stage_src[i].ptr, b.input.data, b.input.len, hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);  // opencl.rs:359
             A.src = (const uint8_t *)c->stage_src[i].ptr;
         } else A.src = (const uint8_t *)b.input.data;
         if (b.output.kind == GFW_BUF_HOST) {
             // Bytes the kernel never writes (stride padding, pixels outside output_rect) must keep the caller's content, as they do on the CPU path.  Rounds 1-5
             // uploaded the destination first and copied all of it back (33 MB more over the link per C2 frame than opencl.rs:408-413 moves); since round 6 nothing is
-            // uploaded and only what the kernels WRITE comes back (for_written_region below): the staging buffer's other bytes are never looked at.
+            // uploaded and only what the kernels WRITE comes back (for_written_region below): the staging buffer's other bytes are never looked at.  (Page-locking
+            // the caller's ranges — hipHostRegister, least recently used out — was built and measured in the same call: 1.291 ms per C2 frame with it, 1.298 without;
+            // the runtime's pageable path already runs at the link's rate, and a registration that outlives the caller's allocation is a hazard.  Not kept.)
             HIP_TRY(c->stage_dst[i].ensure(b.output.len), GFW_ERR_HIP);
-            host_pin(c, b.output.data, b.output.len);
             A.dst = (uint8_t *)c->stage_dst[i].ptr;
         } else A.dst = (uint8_t *)b.output.data;
         A.dst_len = (int64_t)b.output.len;
@@ -1004,14 +974,17 @@ int gfw_undistort_clip(gfw_ctx *c, int n_frames, int nplanes, const gfw_buffers 
         // A frame shaped exactly like the one that opened the pending launch (same descriptions but for the pointers; the parameters are
         // shared by construction) needs none of the per-frame validation again: its pointers join the launch.  ~10 us -> < 1 us of host time.
         bool words = true;                            // (the checksum build places an element by its offset: every plane on a 64-bit word, as run_planes checked for the launch's first frame)
-        if (c->sums) for (int i = 0; i < nplanes; ++i) words = words && ((uintptr_t)planes[(size_t)f * nplanes + i].output.data & 7) == 0;
+        if (c->sums && batch.n > 0) for (int i = 0; i < nplanes && i < 4; ++i) words = words && (((uintptr_t)planes[(size_t)f * nplanes + i].output.data + (uintptr_t)(batch.CA.fr[0].dst[i] - (uint8_t *)batch.first[i].output.data)) & 7) == 0;
         if (batch.n > 0 && batch.n < GFW_CLIP_MAX && (!c->sums || (batch.CA.Y.checksum && words)) && c->matrices_on_device == 2 && matrices[f] && clip_same_shape(batch.first, planes + (size_t)f * nplanes, nplanes) &&
             !clip_ring_table(c, matrices[f]) && !clip_overlaps(&batch, planes + (size_t)f * nplanes, nplanes)) {
             batch.sums[batch.n] = next_sum(c);
+            sum_commit(c, batch.sums[batch.n]);
             GfwFrameDyn &F = batch.CA.fr[batch.n++];
             for (int i = 0; i < 4; ++i) {
-                F.src[i] = i < nplanes ? (const uint8_t *)planes[(size_t)f * nplanes + i].input.data : nullptr;
-                F.dst[i] = i < nplanes ? (uint8_t *)planes[(size_t)f * nplanes + i].output.data : nullptr;
+                // (the kernel's planes begin at their rects' first pixels: the same offsets the launch's first frame was given — clip_same_shape compared the rects)
+                const ptrdiff_t so = i < nplanes ? batch.CA.fr[0].src[i] - (const uint8_t *)batch.first[i].input.data : 0, dof = i < nplanes ? batch.CA.fr[0].dst[i] - (uint8_t *)batch.first[i].output.data : 0;
+                F.src[i] = i < nplanes ? (const uint8_t *)planes[(size_t)f * nplanes + i].input.data + so : nullptr;
+                F.dst[i] = i < nplanes ? (uint8_t *)planes[(size_t)f * nplanes + i].output.data + dof : nullptr;
             }
             F.matrices = matrices[f];
             c->last_backend = batch.backend;

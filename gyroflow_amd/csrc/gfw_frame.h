@@ -15,6 +15,8 @@ struct GfwYuvPlane {
     float limit;                      // pixel_value_limit
     int32_t src_len, dst_len;         // bytes the caller declared for the two buffers (< 2 GiB on this path): audit mode range-checks against them
     int32_t fix;                      // FIX_COLOR_RANGE (flags & 1, cpu_undistort.rs:254-260, :619-621): 0 off, 1 the luma scale (plane_index 0), 2 the chroma scale
+    float org_x, org_y;               // source_rect origin (mod.rs:322: a BufferDescription's rect): added to the mapped coordinate as map_coord adds it (cpu_undistort.rs:510-515) ...
+    int32_t ox32, oy32;               // ... and 32 * origin, which comes off the 1/32-pixel bins again: src / dst point at the rects' first pixels, w / h are the rects'
 };
 
 #define GFW_P1_TABLE_N 8192      // intervals of the s(rho) table of the certified first pass (64 KB)

@@ -512,6 +512,12 @@ template <int I> __device__ __forceinline__ int raw_bin(float u) {           // 
     constexpr float OFFSET = (I == 2) ? 0.0f : (I == 4 ? 1.0f : 3.0f);
     return round32_i32(u - OFFSET);
 }
+// The bins of a source coordinate of plane P.  The kernel's planes begin at the first pixel of their source rect (the host rebases the pointers); the reference maps
+// a coordinate INTO the rect — map_coord's `+ out_min`, cpu_undistort.rs:510-515: `u * srw / W + srx`, one more rounding — and bins that sum.  So the origin is added
+// as the reference adds it and 32 * origin comes off the bins again (exact integer arithmetic).  A buffer without rects has origin 0: ox32 / oy32 are literals of a
+// baked build, a uniform branch ahead of time, and the coordinate is binned as before (u + (+0) differs from u only for u = -0, which bins to 0 either way).
+template <int I> __device__ __forceinline__ int bin_x(float u, const GfwYuvPlane &P) { return P.ox32 ? raw_bin<I>(u + P.org_x) - P.ox32 : raw_bin<I>(u); }
+template <int I> __device__ __forceinline__ int bin_y(float v, const GfwYuvPlane &P) { return P.oy32 ? raw_bin<I>(v + P.org_y) - P.oy32 : raw_bin<I>(v); }
 template <int I>
 __device__ __forceinline__ Bins<I> bins_of(int sx0, int sy0, const float *lut) {
     Bins<I> b;
@@ -741,7 +747,7 @@ __device__ __forceinline__ void sample_store_bins(int bx, int by, bool ok, const
 }
 template <typename T, int N, int I>
 __device__ __forceinline__ void sample_store(float u, float v, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy, const float *lut) {
-    sample_store_bins<T, N, I>(raw_bin<I>(u), raw_bin<I>(v), ok, P, bg, limit, ox, oy, lut);       // (garbage bins of a point that is not ok are never used)
+    sample_store_bins<T, N, I>(bin_x<I>(u, P), bin_y<I>(v, P), ok, P, bg, limit, ox, oy, lut);       // (garbage bins of a point that is not ok are never used)
 }
 // Planar planes of identical geometry (U and V; or G,B,R,A of a planar float frame): one set of bins / weights /
 // offsets, one gather set per plane.
@@ -753,7 +759,7 @@ __device__ __forceinline__ void sample_store_shared(float u, float v, bool ok, c
     bool inside = false;
     int off0 = 0;
     if (ok) {
-        b = make_bins<I>(u, v, lut);
+        b = bins_of<I>(bin_x<I>(u, P0), bin_y<I>(v, P0), lut);
         inside = bins_inside<T, 1, I>(b, P0.w, P0.h);
         off0 = row_off(b.sy, P0.src_stride) + b.sx * (int)sizeof(T);
     }
@@ -778,7 +784,7 @@ __device__ __forceinline__ void sample_store_shared_refs(float u, float v, bool 
     bool inside = false;
     int off0 = 0;
     if (ok) {
-        b = make_bins<I>(u, v, lut);
+        b = bins_of<I>(bin_x<I>(u, Pa), bin_y<I>(v, Pa), lut);
         inside = bins_inside<T, 1, I>(b, Pa.w, Pa.h);
         off0 = row_off(b.sy, Pa.src_stride) + b.sx * (int)sizeof(T);
     }
@@ -945,7 +951,7 @@ __device__ __forceinline__ void sample_store2_bins(int bx, int by, bool ok, cons
 template <typename T, int N>
 __device__ __forceinline__ void sample_store2(float u, float v, bool ok, const GfwYuvPlane &P, const float *bg, float limit, int ox, int oy,
                                               unsigned long long *aud = nullptr) {
-    sample_store2_bins<T, N>(round32_i32(u), round32_i32(v), ok, P, bg, limit, ox, oy, aud);       // (garbage bins of a point that is not ok are never used)
+    sample_store2_bins<T, N>(bin_x<2>(u, P), bin_y<2>(v, P), ok, P, bg, limit, ox, oy, aud);       // (garbage bins of a point that is not ok are never used)
 }
 // Planar planes of identical geometry (U and V; or G,B,R,A of a planar float frame): one set of bins / weights /
 // offsets, one gather pair per plane.
@@ -956,7 +962,7 @@ __device__ __forceinline__ void sample_store_shared2(float u, float v, bool ok, 
     bool inside = false;
     int off0 = 0;
     if (ok) {
-        b = make_bins2(u, v);
+        b = bins2_of(bin_x<2>(u, P0), bin_y<2>(v, P0));
         inside = (unsigned)b.sx < (unsigned)(P0.w - 1) && (unsigned)b.sy < (unsigned)(P0.h - 1);
         off0 = row_off(b.sy, P0.src_stride) + b.sx * (int)sizeof(T);
     }
@@ -977,7 +983,7 @@ __device__ __forceinline__ void sample_store_shared2_refs(float u, float v, bool
     bool inside = false;
     int off0 = 0;
     if (ok) {
-        b = make_bins2(u, v);
+        b = bins2_of(bin_x<2>(u, Pa), bin_y<2>(v, Pa));
         inside = (unsigned)b.sx < (unsigned)(Pa.w - 1) && (unsigned)b.sy < (unsigned)(Pa.h - 1);
         off0 = row_off(b.sy, Pa.src_stride) + b.sx * (int)sizeof(T);
     }
@@ -1008,7 +1014,7 @@ __device__ __forceinline__ void sample_store_uv2(float u, float v, bool ok, cons
                                                  float bg_u, float bg_v, float lim_u, float lim_v, int ox, int oy, unsigned long long *aud = nullptr) {
     float ou = bg_u, ov = bg_v;
     if (ok) {
-        const Bins2 b = make_bins2(u, v);
+        const Bins2 b = bins2_of(bin_x<2>(u, PU), bin_y<2>(v, PU));
         if (__builtin_expect((unsigned)b.sx < (unsigned)(PU.w - 1) && (unsigned)b.sy < (unsigned)(PU.h - 1), 1)) {
             const int off0 = row_off(b.sy, PU.src_stride) + b.sx * (int)sizeof(T);
             const int top = PU.src_len < PV.src_len ? PU.src_len : PV.src_len;
@@ -1119,13 +1125,13 @@ __device__ __forceinline__ Feather feather_of(float ux, float uy, const GfwYuvAr
 template <typename T, int N, int I>
 __device__ __forceinline__ void sample_only(float u, float v, const GfwYuvPlane &P, const float *bg, float limit, const float *lut, float *out) {
     if (I == 2) {
-        const Bins2 b = make_bins2(u, v);
+        const Bins2 b = bins2_of(bin_x<2>(u, P), bin_y<2>(v, P));
         if ((unsigned)b.sx < (unsigned)(P.w - 1) && (unsigned)b.sy < (unsigned)(P.h - 1))
             taps_inside2<T, N>(P.src, row_off(b.sy, P.src_stride) + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
         else
             taps_edge2<T, N>(P.src, P.src_stride, b, P.w, P.h, bg, limit, out);
     } else {
-        const Bins<I> b = make_bins<I>(u, v, lut);
+        const Bins<I> b = bins_of<I>(bin_x<I>(u, P), bin_y<I>(v, P), lut);
         if (bins_inside<T, N, I>(b, P.w, P.h))
             taps_inside<T, N, I>(P.src, row_off(b.sy, P.src_stride) + b.sx * (int)(N * sizeof(T)), P.src_stride, b, limit, out);
         else
@@ -1256,7 +1262,8 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
 #if GFW_BAKE
 #define GFW_PLANE_INIT(i) GfwYuvPlane PL##i; PL##i.src = A_in.pl[i].src; PL##i.dst = A_in.pl[i].dst; PL##i.src_len = A_in.pl[i].src_len; PL##i.dst_len = A_in.pl[i].dst_len; \
     PL##i.src_stride = GFW_BK_pl##i##_src_stride; PL##i.dst_stride = GFW_BK_pl##i##_dst_stride; PL##i.w = GFW_BK_pl##i##_w; PL##i.h = GFW_BK_pl##i##_h; \
-    PL##i.bg[0] = GFW_BK_pl##i##_bg_0; PL##i.bg[1] = GFW_BK_pl##i##_bg_1; PL##i.bg[2] = GFW_BK_pl##i##_bg_2; PL##i.bg[3] = GFW_BK_pl##i##_bg_3; PL##i.limit = GFW_BK_pl##i##_limit; PL##i.fix = GFW_BK_pl##i##_fix;
+    PL##i.bg[0] = GFW_BK_pl##i##_bg_0; PL##i.bg[1] = GFW_BK_pl##i##_bg_1; PL##i.bg[2] = GFW_BK_pl##i##_bg_2; PL##i.bg[3] = GFW_BK_pl##i##_bg_3; PL##i.limit = GFW_BK_pl##i##_limit; PL##i.fix = GFW_BK_pl##i##_fix; \
+    PL##i.org_x = GFW_BK_pl##i##_org_x; PL##i.org_y = GFW_BK_pl##i##_org_y; PL##i.ox32 = GFW_BK_pl##i##_ox32; PL##i.oy32 = GFW_BK_pl##i##_oy32;
     GFW_PLANE_INIT(0) GFW_PLANE_INIT(1) GFW_PLANE_INIT(2) GFW_PLANE_INIT(3)
 #undef GFW_PLANE_INIT
 #else
@@ -1791,7 +1798,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                             }
                             const float lu = map_c<INF_COORDS>(pu[i], MP.mul_lx, MP.den_x, MP.rcp_x), lv = map_c<INF_COORDS>(pv[i], MP.mul_ly, MP.den_y, MP.rcp_y);   // :511-514
                             if (j == 0 && i == 0) { u0 = pu[0]; v0 = pv[0]; okm0 = okp[0]; lu0 = lu; lv0 = lv; }
-                            bx[i] = raw_bin<I>(lu); by[i] = raw_bin<I>(lv);
+                            bx[i] = bin_x<I>(lu, PL0); by[i] = bin_y<I>(lv, PL0);
                             const bool live = WHOLE || (lx < AF(out_w) && ly < AF(out_h));
                             if constexpr (I == 2) interior = interior & okp[i] & gfw_lanes(live) & gfw_lanes((unsigned)(bx[i] >> 5) < (unsigned)(PL0.w - 1)) & gfw_lanes((unsigned)(by[i] >> 5) < (unsigned)(PL0.h - 1));
                             else interior = interior & okp[i] & gfw_lanes(live) & lut_interior<T, I>(bx[i], by[i], PL0.w, PL0.h);
@@ -1801,7 +1808,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                             if (AF(nplanes) == 3 && !GFW_ABL(4)) {
                                 const float ccu = chroma_from_luma<INF_COORDS>(lu0, u0, MP.mul_cx, MP.mul_lx, MP.den_x, MP.rcp_x);
                                 const float ccv = chroma_from_luma<INF_COORDS>(lv0, v0, MP.mul_cy, MP.mul_ly, MP.den_y, MP.rcp_y);
-                                const Bins2 bc = make_bins2(ccu, ccv);
+                                const Bins2 bc = bins2_of(bin_x<2>(ccu, PL1), bin_y<2>(ccv, PL1));
                                 const GfwVote both = interior & okm0 & gfw_lanes((unsigned)bc.sx < (unsigned)(PL1.w - 1)) & gfw_lanes((unsigned)bc.sy < (unsigned)(PL1.h - 1));
                                 if (__builtin_expect(gfw_all_lanes(both), 1)) {
                                     uint32_t val[DW];
@@ -1939,7 +1946,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     bool chroma_done = false;
                     if constexpr (FASTROW && I == 2 && !is_f32<T>::value) if (fastrow && (INTERLEAVED_UV || AF(nplanes) == 3)) {
                         // the chroma site the same way: one question to the wave, then the branch-free interior taps of both chroma samples
-                        const Bins2 bc = make_bins2(cu, cv);
+                        const Bins2 bc = bins2_of(bin_x<2>(cu, PL1), bin_y<2>(cv, PL1));
                         if (__builtin_expect(gfw_all_lanes(okm0 & gfw_lanes((unsigned)bc.sx < (unsigned)(PL1.w - 1)) & gfw_lanes((unsigned)bc.sy < (unsigned)(PL1.h - 1))), 1)) {
                             if constexpr (INTERLEAVED_UV) {
                                 const int off0 = row_off(bc.sy, PL1.src_stride) + bc.sx * (int)(2 * sizeof(T));
@@ -1975,7 +1982,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     }
                     if constexpr (FASTROW && I == 2 && is_f32<T>::value && N0 == 1 && !INTERLEAVED_UV) if (fastrow && AF(nplanes) >= 2) {
                         // planar float frames (the EXR route: G, B, R, A planes of one geometry — round 5): one vote, then every further plane's interior taps with one set of bins
-                        const Bins2 bc = make_bins2(cu, cv);
+                        const Bins2 bc = bins2_of(bin_x<2>(cu, PL1), bin_y<2>(cv, PL1));
                         if (__builtin_expect(gfw_all_lanes(okm0 & gfw_lanes((unsigned)bc.sx < (unsigned)(PL1.w - 1)) & gfw_lanes((unsigned)bc.sy < (unsigned)(PL1.h - 1))), 1)) {
                             const uint32_t va = inside_value1<T>(PL1.src, PL1.src_stride, bc, PL1.bg, PL1.limit);
                             const uint32_t vb = AF(nplanes) > 2 ? inside_value1<T>(PL2.src, PL1.src_stride, bc, PL2.bg, PL2.limit) : 0u;
@@ -1992,7 +1999,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
                     }
                     if constexpr (FASTROW && I != 2 && !is_f32<T>::value && !INTERLEAVED_UV) if (fastrow && AF(nplanes) == 3) {
                         // bicubic / Lanczos4 chroma of planar frames: one vote, then both planes' interior taps with one set of bins
-                        const int cbx = raw_bin<I>(cu), cby = raw_bin<I>(cv);
+                        const int cbx = bin_x<I>(cu, PL1), cby = bin_y<I>(cv, PL1);
                         if (__builtin_expect(gfw_all_lanes(okm0 & lut_interior<T, I>(cbx, cby, PL1.w, PL1.h)), 1)) {
                             const uint32_t vu = inside_value1_lut<T, I>(PL1.src, PL1.src_stride, cbx, cby, &bg_c[0], lim_u, s_lut);
                             const uint32_t vv = inside_value1_lut<T, I>(PL2.src, PL1.src_stride, cbx, cby, &bg_v, lim_v, s_lut);

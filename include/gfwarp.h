@@ -304,18 +304,12 @@ enum {
                                         (1..GFW_CLIP_FRAMES_MAX; default 1: a frame leaves when it is complete).  Larger values trade latency for the
                                         throughput of gfw_undistort_clip (the occupancy tail of one frame filled by the next).  Ignored by a
                                         synchronous owner (GFW_OPT_FRAME_SYNC). */
-    GFW_OPT_FRAME_SYNC         = 10, /* 0 (default).  1: on a SYNCHRONOUS context (GFW_OPT_SYNCHRONOUS = 1, the reference's contract: opencl.rs:413) with
+    GFW_OPT_FRAME_SYNC         = 10  /* 0 (default).  1: on a SYNCHRONOUS context (GFW_OPT_SYNCHRONOUS = 1, the reference's contract: opencl.rs:413) with
                                         HIP_DEVICE buffers, "complete on return" is relaxed to "the FRAME is complete when its LAST plane's call returns":
                                         the calls of the frame's earlier planes validate, are held (GFW_OPT_COALESCE_PLANES) and return at once, the last
                                         plane's call launches the fused kernel and waits for it.  This is what the render loop needs — it consumes a
                                         frame's planes only after all of its process_pixels calls (rendering/mod.rs:494-545) — but it is NOT what a caller
                                         that reads plane 0 right after plane 0's call gets; hence opt-in, on every context of the frame. */
-    GFW_OPT_PIN_HOST           = 11  /* 1 (default): the ranges of HOST buffers (BufferSource::Cpu, gpu/mod.rs:34) are page-locked (hipHostRegister) when a
-                                        context first sees them and kept locked, least recently used out (64 ranges / 4 GiB per context), so that a frame's
-                                        copies run at the link's rate — a render loop hands the same frame pool round and round (FFmpeg's buffer pool,
-                                        rendering/mod.rs:522-525).  A range that cannot be locked keeps the pageable path; results are the same either way.
-                                        0: never lock the caller's memory (also: GFW_PIN_HOST=0 in the environment).  The caller must not free a range
-                                        while a frame that uses it is in flight — the rule any asynchronous copy has. */
 };
 int   gfw_set_option(gfw_ctx *ctx, int option, int64_t value);
 /* Enqueues whatever gfw_undistort_image calls GFW_OPT_COALESCE_PLANES / _FRAMES are holding for a frame or launch this context belongs to

@@ -58,14 +58,15 @@ def bake_header(frame, rb=4, checksum=0):
         if i < n:
             p, pl = pls[i]["params"], pls[i]
             vals = {"src_stride": p.stride, "dst_stride": pl["out_size"][2], "w": pl["size"][0], "h": pl["size"][1],
-                    "fix": (1 if p.plane_index == 0 else 2) if p.flags & 1 else 0}
+                    "fix": (1 if p.plane_index == 0 else 2) if p.flags & 1 else 0, "ox32": 0, "oy32": 0}
             bg = [float(np.float32(p.background[c]) * np.float32(p.max_pixel_value)) for c in range(4)]
             lim = p.pixel_value_limit
         else:
-            vals, bg, lim = {"src_stride": 0, "dst_stride": 0, "w": 0, "h": 0, "fix": 0}, [0.0] * 4, 0.0
+            vals, bg, lim = {"src_stride": 0, "dst_stride": 0, "w": 0, "h": 0, "fix": 0, "ox32": 0, "oy32": 0}, [0.0] * 4, 0.0
         out += ["#define GFW_BK_pl%d_%s (%d)" % (i, k, v) for k, v in vals.items()]
         for c in range(4):
             fl["pl%d_bg_%d" % (i, c)] = bg[c]
         fl["pl%d_limit" % i] = lim
+        fl["pl%d_org_x" % i] = fl["pl%d_org_y" % i] = 0.0          # (the interpreter's frames have no buffer rects; the GPU tier tests them)
     out += ["#define GFW_BK_%s %s" % (k, _f(v)) for k, v in fl.items()]
     return "\n".join(out) + "\n"

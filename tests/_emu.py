@@ -93,7 +93,10 @@ def build(defs, header, top="gfw_frame.hip", n_asm=13, driver="emu_driver.inc", 
         r = subprocess.run([CXX] + flags + [cpp, "-o", tmp, "-lm"], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("emulator build failed:\n" + r.stderr[-4000:])
-        os.replace(cpp, os.path.join(OUT, "emu_%s.cpp" % key))
+        if os.environ.get("GFW_EMU_KEEP_CPP") == "1":
+            import shutil
+            shutil.copyfile(cpp, os.path.join(OUT, "emu_%s.cpp" % key))
+        os.remove(cpp)                                    # (the generated translation unit — half a megabyte of text per configuration — is not kept: GFW_EMU_KEEP_CPP=1 for debugging)
         os.replace(tmp, so)
     return so
 

@@ -9,6 +9,9 @@
 //
 //   test_multi_device [threads = 4] [frames = 36]          (built by __graft_entry__.build_test_helpers with hipcc: it allocates device memory itself)
 #include <hip/hip_runtime.h>
+#include <unistd.h>
+#include <csignal>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -21,8 +24,15 @@
 
 using namespace gyroflow;
 
-#define CHECK(cond) do { if (!(cond)) { std::printf("FAILED %s:%d: %s (%s)\n", __FILE__, __LINE__, #cond, gfw_last_error()); std::exit(1); } } while (0)
-#define HIPOK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("FAILED %s:%d: %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
+// (a failing check on one thread leaves at once, through _exit: exit() would run the process's exit handlers — the library joins its build threads there — beside
+//  threads that are still inside the HIP runtime, and a failure would show as a hang with nothing printed)
+#define CHECK(cond) do { if (!(cond)) { std::fprintf(stderr, "FAILED %s:%d: %s (%s)\n", __FILE__, __LINE__, #cond, gfw_last_error()); std::fflush(stderr); _exit(1); } } while (0)
+#define HIPOK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "FAILED %s:%d: %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); std::fflush(stderr); _exit(1); } } while (0)
+
+// progress goes to stderr, unbuffered, so that a run that stops shows WHERE (a 4-thread run once hung beside three other GPU processes and said nothing: r06_c)
+#define MARK(...) do { std::fprintf(stderr, __VA_ARGS__); std::fflush(stderr); } while (0)
+static std::atomic<int> g_stage{0};
+static void on_alarm(int) { char b[96]; const int n = std::snprintf(b, sizeof(b), "\nFAILED: watchdog, no progress for 120 s (stage %d)\n", g_stage.load()); (void)!write(2, b, (size_t)n); _exit(4); }
 
 static const int W = 640, H = 360, CW = W / 2;                    // 4:2:2: chroma planes half as wide, as tall
 static const size_t YS = 1536, CS = 768;                          // row pitches (padded)
@@ -69,6 +79,7 @@ static std::vector<uint8_t> pattern(int w, int h, size_t stride, uint64_t seed) 
 static void render(int device, int first, int step, int n_frames, const std::vector<uint8_t> src[3], std::vector<unsigned long long> *sums, std::string *backends) {
     CHECK(gfw_set_device(device) == GFW_OK);
     HIPOK(hipSetDevice(device));
+    MARK("[render first %d step %d on device %d: start]\n", first, step, device);
     const int pw[3] = {W, CW, CW};
     const size_t ps[3] = {YS, CS, CS};
     uint8_t *d_src[3], *d_dst[3];
@@ -111,20 +122,26 @@ static void render(int device, int first, int step, int n_frames, const std::vec
         CHECK(gfw_undistort_frame(ctx, 3, planes, params, types, base.matrices[0].data(), H, nullptr, 0) == GFW_OK);
         if (backends && backends->find(gfw_last_backend(ctx)) == std::string::npos) { *backends += gfw_last_backend(ctx); *backends += ' '; }
     }
+    MARK("[render first %d: %d frames enqueued]\n", first, mine);
     if (ctx) {
         CHECK(gfw_synchronize(ctx) == GFW_OK);
+        MARK("[render first %d: synchronised]\n", first);
         std::vector<unsigned long long> h((size_t)mine);
         HIPOK(hipMemcpy(h.data(), d_sums, sizeof(unsigned long long) * (size_t)mine, hipMemcpyDeviceToHost));
         slot = 0;
         for (int k = first; k < n_frames; k += step, ++slot) (*sums)[k] = h[slot];
         gfw_destroy(ctx);
+        MARK("[render first %d: context destroyed]\n", first);
     }
     for (int i = 0; i < 3; ++i) { HIPOK(hipFree(d_src[i])); HIPOK(hipFree(d_dst[i])); }
     HIPOK(hipFree(d_sums));
+    MARK("[render first %d: done]\n", first);
+    g_stage.fetch_add(1); alarm(120);
 }
 
 int main(int argc, char **argv) {
     const int T = argc > 1 ? std::atoi(argv[1]) : 4, N = argc > 2 ? std::atoi(argv[2]) : 36;
+    std::signal(SIGALRM, on_alarm); alarm(120);
     const int ndev = gfw_list_devices(nullptr, 0);
     if (ndev <= 0) { std::printf("no HIP device: %s\n", gfw_last_error()); return 3; }
     std::vector<uint8_t> src[3] = {pattern(W, H, YS, 1), pattern(CW, H, CS, 2), pattern(CW, H, CS, 3)};
@@ -142,5 +159,7 @@ int main(int argc, char **argv) {
     for (int t = 0; t < T; ++t) std::printf("  thread %d on device %d: %s\n", t, t % ndev, backends[(size_t)t].c_str());
     if (bad || zero) { for (int k = 0; k < N; ++k) if (ref[(size_t)k] != got[(size_t)k]) std::printf("  frame %d: %016llx vs %016llx\n", k, ref[(size_t)k], got[(size_t)k]); return 1; }
     std::printf("multi-device ok\n");
+    std::fflush(stdout);
+    MARK("[main: leaving]\n");
     return 0;
 }

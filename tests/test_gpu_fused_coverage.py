@@ -154,3 +154,70 @@ def test_packed_half_float_takes_the_fused_kernel(jit, interp, fov):
     assert warp.last_backend().startswith("yuv_fused"), warp.last_backend()
     for i, (a, b) in enumerate(zip(ref, got)):
         assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "RGBAf16, plane %d" % i)
+
+
+# ---- buffer rects (mod.rs:209-224, 322-323; gpu/mod.rs:17-24) through the fused kernel — round 6 --------------------------------------------------------------
+def embed_in_surface(fr, in_org, out_org, pad=(24, 10)):
+    """Every plane of `fr` becomes a WINDOW of a larger surface, the way a host hands a plugin a region of its frame buffer: the source pixels sit at `in_org` of a
+    buffer `pad` pixels wider / taller than the plane and beyond (source_rect = (x, y, plane_w, plane_h)), the output goes to `out_org` of a larger 0x5A-filled buffer
+    (output_rect likewise); chroma planes take the origins divided by their subsampling.  Bytes outside the output rect must keep their 0x5A."""
+    import numpy as np
+    lw, lh, loh = fr.planes[0]["size"][0], fr.planes[0]["size"][1], fr.planes[0]["out_size"][1]
+    for pl in fr.planes:
+        pw, ph, stride = pl["size"]
+        ow, oh, ostride = pl["out_size"]
+        bpp = pl["params"].bytes_per_pixel
+        sub = max(1, lw // pw)
+        ix, iy = in_org[0] // sub, in_org[1] // max(1, lh // ph)
+        ox, oy = out_org[0] // sub, out_org[1] // max(1, loh // oh)
+        bw, bh = pw + ix + pad[0], ph + iy + pad[1]
+        bstride = S.align(bw * bpp, 64)
+        big = np.random.default_rng(pl["seed"]).integers(0, 256, size=bstride * bh, dtype=np.uint8)       # what lies around the window is NOT background: it must never be sampled
+        src2d = pl["src"].reshape(ph, stride)[:, :pw * bpp]
+        big.reshape(bh, bstride)[iy:iy + ph, ix * bpp:(ix + pw) * bpp] = src2d
+        obw, obh = ow + ox + pad[0], oh + oy + pad[1]
+        obstride = S.align(obw * bpp, 64)
+        p = pl["params"].copy()
+        p.stride, p.output_stride = bstride, obstride
+        p.source_rect[0], p.source_rect[1], p.source_rect[2], p.source_rect[3] = ix, iy, pw, ph
+        p.output_rect[0], p.output_rect[1], p.output_rect[2], p.output_rect[3] = ox, oy, ow, oh
+        p.flags |= abi.FLAG_HAS_SOURCE_RECT | abi.FLAG_HAS_OUTPUT_RECT
+        pl.update(src=big, size=(bw, bh, bstride), dst=np.full(obstride * obh, 0x5A, dtype=np.uint8), out_size=(obw, obh, obstride), params=p)
+    return fr
+
+
+@pytest.mark.parametrize("fmt", ["YUV422P16LE", "NV12", "P010", "YUV420P", "RGBA", "RGBA64", "RGBAF32", "GBRAPF32LE"])
+@pytest.mark.parametrize("interp", [2, 4, 8])
+@pytest.mark.parametrize("jit", [0, 2])
+def test_windows_of_larger_surfaces_take_the_fused_kernel(fmt, interp, jit):
+    """Source and output rects — a plane that is a window of a larger buffer — ran through the per-plane kernel until round 6 (373 us per C2 frame: 2 % of the
+    roofline).  The fused kernel now works on the rects as planes (pointers rebased by the host) and reproduces the one thing that does not rebase: the source
+    coordinate's `+ source_rect origin` before the 1/32-pixel binning (cpu_undistort.rs:510-515; a coordinate near 2000 + an origin of 36 rounds differently from the
+    coordinate alone).  A fov > 1 frame samples across the window's edges: what surrounds the window in the buffer is noise, what the kernel must use is background.
+    (Origins that leave every plane's first pixel dword-aligned: the bicubic / Lanczos4 taps of 8- and 16-bit planes are fetched as aligned dwords from the plane's
+    start, and a window that breaks that — a chroma origin of 18 bytes — goes the per-plane way, as an odd sub-buffer always has.)"""
+    import numpy as np
+    fr = embed_in_surface(S.SyntheticFrame(fmt, 384, 208, seed=0x6EC7 + interp, fov=1.35, interpolation=interp, background_rgba=(0.2, 0.6, 0.4, 1.0)), (40, 14), (20, 6))
+    ref = O.run_frame(fr)
+    got = warp.run_frame(fr, jit=jit)
+    assert warp.last_backend().startswith("yuv_fused") and warp.last_backend().endswith("_jit") == (jit == 2), warp.last_backend()
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "window of a surface, plane %d" % i)
+        assert np.count_nonzero(a == 0x5A) > 0
+    base = warp.run_frame(fr, fused=False)
+    assert warp.last_backend() == "plane_generic"
+    for i, (a, b) in enumerate(zip(ref, base)):
+        assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "per-plane window, plane %d" % i)
+
+
+@pytest.mark.parametrize("origin", [(0, 0), (2, 0), (0, 2), (1022, 600)])
+def test_window_origins_including_large_ones(origin):
+    """The origin enters a float addition: large origins change which 1/32-pixel bin a coordinate falls into (the whole point of adding it as the reference does);
+    zero components take the path without the addition."""
+    fr = embed_in_surface(S.SyntheticFrame("YUV422P16LE", 320, 192, seed=0x0719, fov=0.95), origin, (origin[0] // 2 * 2, origin[1]), pad=(6, 4))
+    ref = O.run_frame(fr)
+    for jit in (0, 2):
+        got = warp.run_frame(fr, jit=jit)
+        assert warp.last_backend().startswith("yuv_fused"), warp.last_backend()
+        for i, (a, b) in enumerate(zip(ref, got)):
+            assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "origin %s, plane %d" % (origin, i))

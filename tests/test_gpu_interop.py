@@ -70,6 +70,7 @@ def test_warp_reads_a_surface_exported_by_another_process(fmt):
             rc = lib.gfw_import_external_fd(fd, size, 0, C.byref(ptr), C.byref(handle))
             assert rc == 0 and ptr.value, lib.gfw_last_error().decode()
             d_dst = fr.device_outputs(dev)
+            torch.cuda.synchronize(dev)                      # (torch fills the destinations on ITS stream; the context's stream is non-blocking: without this the 0x5A fill can land after the warp — seen under pytest -n 4, r06_b)
             bufs = [warp.device_buffers(ptr.value + offs[p], pl["src"].nbytes, pl["size"], d_dst[p].data_ptr(), d_dst[p].numel(), pl["out_size"]) for p, pl in enumerate(fr.planes)]
             be = warp.Backend(fr.planes[0]["params"], fr.planes[0]["pixel_type"], fr.model, fr.digital, bufs[0])
             try:

@@ -27,6 +27,7 @@ SCRIPT = textwrap.dedent("""
                               interpolation=fr.planes[0]["params"].interpolation, readout_ms=0.0 if CQ is not None else 16.0, constant_quat=CQ) if False else fr
         d_src, d_dst = fr.device_planes(dev), fr.device_outputs(dev)
         d_mat = torch.from_numpy(warp.pack_matrices(fr.matrices)).to(dev)
+        torch.cuda.synchronize(dev)                          # (torch produced the planes on ITS stream; the context's stream is non-blocking)
         bufs = [warp.device_buffers(d_src[p].data_ptr(), d_src[p].numel(), pl["size"], d_dst[p].data_ptr(), d_dst[p].numel(), pl["out_size"]) for p, pl in enumerate(fr.planes)]
         be = warp.Backend(fr.planes[0]["params"], fr.planes[0]["pixel_type"], fr.model, fr.digital, bufs[0])
         be.set_option(abi.OPT_SYNCHRONOUS, 0); be.set_option(abi.OPT_MATRICES_ON_DEVICE, 2); be.set_option(abi.OPT_JIT, 2)

@@ -2,9 +2,9 @@
 """Static issue-cost model of a gfx950 kernel's ISA (hipcc -S output), per basic block.
 
 Cycle classes per wave64 VALU instruction, from profiles/r01_microbench_valu_rates.txt (MI355X, SIMD-32):
-  full (2 cycles):   v_mul/add/sub_f32, v_fma/fmac/fmaak/fmamk with <= 2 VGPR source reads and no SGPR source,
+  full (2 cycles):   v_mul/add/sub_f32, v_fma/fmac/fmaak/fmamk on distinct VGPR sources and no SGPR source (measured 2.3-2.4 at 8 waves per SIMD, round 6),
                      v_and/or/xor_b32, v_add/sub_u32, v_mov_b32 — inline constants and literals are free
-  half (4 cycles):   everything else (v_cvt, v_min/max, v_cmp, v_cndmask, shifts, v_bfi, v_mad_*, SDWA forms, 3-VGPR fma,
+  half (4 cycles):   everything else (v_cvt, v_min/max, v_cmp, v_cndmask, shifts, v_bfi, v_mad_*, SDWA forms, an fma that reads one VGPR twice,
                      v_pk_* (two elements), any VALU with an SGPR source operand)
   trans (8 cycles):  v_rcp/rsq/sqrt/exp/log/sin/cos
 usage: isa_cost.py file.s [kernel-substring]      prints per-block instruction and cycle counts in program order
@@ -38,7 +38,9 @@ def classify(op, args):
             has_s = any(re.match(r'^(s\d+|s\[|vcc|exec|ttmp|m0)', a.strip('|-')) for a in srcs)
             if has_s:
                 return 'valu', 4
-            if len(vregs) >= 3:
+            # (round 6, profiles/r06_microbench_cycles.txt: a v_fma_f32 on three DISTINCT VGPRs issues at the full rate, 2.37 cycles at 8 waves; one that names the
+            #  same VGPR twice does not, 3.74 — a register-bank effect, not the three-operand encoding)
+            if nv > len(vregs):
                 return 'valu', 4
             return 'valu', 2
         return 'valu', 4

@@ -81,7 +81,6 @@ template <int PAT> __global__ __launch_bounds__(256) void k(Rec *rec, float *out
     if ((threadIdx.x & 63) == 0) rec[gid >> 6] = Rec{t0, t1, hw, xcc};
 }
 
-static double g_wall_mhz = 0.0;
 template <int PAT> void run(const char *name, int instr_per_chain_iter, Rec *d_rec, float *d_out) {
     printf("%-58s", name);
     for (int W : {1, 2, 4, 8}) {
@@ -109,10 +108,6 @@ template <int PAT> void run(const char *name, int instr_per_chain_iter, Rec *d_r
         std::sort(per_simd.begin(), per_simd.end()); std::sort(own.begin(), own.end());
         if (per_simd.empty()) { printf("  W=%d: (no SIMD held exactly %d waves; %zu SIMDs seen)", W, W, simd.size()); continue; }
         printf("  W=%d: %5.2f (own %5.2f, %3zu SIMDs)", W, per_simd[per_simd.size() / 2], own[own.size() / 2], per_simd.size());
-        if (W == 8 && PAT == 0) {       // the clock: the s_memtime span of the whole launch against its wall time
-            unsigned long long a = ~0ull, b = 0; for (const Rec &r : h) { a = std::min(a, r.t0); b = std::max(b, r.t1); }
-            g_wall_mhz = (double)(b - a) / (ms * 1e-3) / 1e6;
-        }
     }
     printf("\n");
 }
@@ -156,6 +151,5 @@ int main() {
     run<15>("v_mov_b32, v_mov_b32 dpp quad_perm", 2, d_rec, d_out);
     run<23>("v_readlane_b32, v_add_u32 s,v", 2, d_rec, d_out);
     run<17>("v_mul_f32, ds_read_b32 + v_add_f32 (3 counted)", 3, d_rec, d_out);
-    printf("shader clock during the W=8 mul/add launch: %.0f MHz (s_memtime span / hipEvent wall)\n", g_wall_mhz);
     return 0;
 }
