@@ -95,6 +95,7 @@ struct gfw_ctx {
     float p1_eps_last = 0.0f;                      // certificate half-width of the last frame set up (reported in gfw_get_audit's word 6)
     float p1_k[4] = {0, 0, 0, 0}; float p1_rho_max = 0.0f; double p1_etab = 0.0; double p1_smax = 1.0; bool p1_valid = false;
     double p1_slope = 0.0, p1_kappa = 0.0;         // max |ds/drho| over the table's range; roundoff amplification of the exact path's theta_d/r (section 2c)
+    struct P1Radial *p1_radial = nullptr;          // the same for the radial models of round 6 (GoPro: gfw_api_certificate.inc); table in d_p1_table as well
     double p1_u1 = 0.0, p1_u2 = 0.0, p1_t32 = 0.0; // max sqrt(rho) |s'|, rho |s'|, rho^1.5 |s''| over the table's range: the curvature of the first pass's value across a lattice cell (gfw_frame.hip)
     DevBuf d_pts_in, d_pts_out, d_pts_rot, d_pts_shift, d_pts_mesh;   // gfw_undistort_points staging
     DevBuf d_tracks;                              // quaternion tracks
@@ -155,6 +156,7 @@ struct gfw_ctx {
 extern "C" int gfw_flush(gfw_ctx *c);
 int flush_if_pending(gfw_ctx *c);
 static void gfw_forget_context(gfw_ctx *c);
+static void p1_radial_free(gfw_ctx *c);
 static void gfw_register_context(gfw_ctx *c);
 
 static void prof_begin(gfw_ctx *c) {
@@ -307,6 +309,7 @@ void gfw_destroy(gfw_ctx *c) {
     for (auto &b : c->stage_src) b.release();
     for (auto &b : c->stage_dst) b.release();
     c->d_mesh.release(); c->d_ck_part.release(); c->d_p1_table.release(); c->d_audit.release(); c->d_tracks.release(); c->d_offsets.release(); for (auto &ss : c->sslots) { ss.d.release(); if (ss.h) (void)hipHostFree(ss.h); if (ss.done) (void)hipEventDestroy(ss.done); } c->d_prefix.release(); c->d_timings.release(); c->d_batch[0].release(); c->d_batch[1].release();
+    p1_radial_free(c);
     if (c->h_timings) (void)hipHostFree(c->h_timings);
     for (auto &e : c->timing_copied) if (e) (void)hipEventDestroy(e);
     for (auto &b : c->bslots) { b.buf.release(); if (b.built) (void)hipEventDestroy(b.built); if (b.consumed) (void)hipEventDestroy(b.consumed); }
@@ -788,6 +791,13 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
         }
         int jgrid = 0;
         hipFunction_t jf = jit_for(c, Y, bps, params[0].interpolation, n0, dw, dh, interleaved, fast1, &jgrid);
+        if (!jf && fast1 && Y.p1_rform) {
+            // a table over r is read by specialised builds only: until one is loaded (or for good, without hiprtc and without a cached kernel) the frame takes the
+            // ahead-of-time generic-model kernel and its exact first pass — whose tiles are one lane-row tall
+            fast1 = false; Y.p1_table = nullptr; Y.audit = nullptr;
+            const int rb = gfw_yuv_rows_per_lane(false, 0);
+            Y.tiles_y = (Y.ch + 4 * rb - 1) / (4 * rb);
+        }
         if (jf && Y.checksum) { const int krc = ck_table(c, jgrid, Y, batch); if (krc != GFW_OK) return krc; sum_taken = true; }
         bool all_device = c->matrices_on_device != 0;
         for (int i = 0; i < nplanes; ++i) all_device = all_device && planes[i].input.kind != GFW_BUF_HOST && planes[i].output.kind != GFW_BUF_HOST;
@@ -1056,6 +1066,17 @@ extern "C" long gfw_debug_jit_compile(const char *arch, const char *defines, con
     return n;
 }
 
+// The host side of a radial model's first-pass certificate without a device (tests/test_emu_pass1_audit.py feeds the interpreted kernel with it): the table of
+// GFW_P1_TABLE_N + 1 float pairs over r in [0, r_max] and {r_max, Tmax, T1, T2, e_table, nu2, d_min} (gfw_api_certificate.inc: p1_prepare_radial_gopro).
+// Returns 1 when a certificate exists for these coefficients and this range, 0 when the host declines, a negative GFW_ERR_* on bad arguments.
+extern "C" int gfw_debug_p1_radial(const gfw_kernel_params *params, int distortion_model, double r_max, float *table, double *out7) {
+    if (!params || !out7 || distortion_model != GFW_MODEL_GOPRO) { set_error("gfw_debug_p1_radial: model %d has no radial certificate", distortion_model); return GFW_ERR_INVALID_ARGUMENT; }
+    P1Radial R; std::vector<float2> tab;
+    if (!p1_prepare_radial_gopro(*params, r_max, R, table ? &tab : nullptr)) return 0;
+    if (table) memcpy(table, tab.data(), tab.size() * sizeof(float2));
+    out7[0] = R.r_max; out7[1] = R.Tmax; out7[2] = R.T1; out7[3] = R.T2; out7[4] = R.etab; out7[5] = R.nu2; out7[6] = R.dmin;
+    return 1;
+}
 extern "C" int gfw_debug_source_id(char *out, size_t cap) {
     if (!out || cap == 0) return GFW_ERR_INVALID_ARGUMENT;
     const std::string id = gfw_jit_source_id();

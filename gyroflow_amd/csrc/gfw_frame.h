@@ -55,7 +55,8 @@ struct GfwYuvArgs {
     GfwMapConst map_lx, map_ly, map_cx, map_cy;
     // certified first pass (gfw_frame.hip): table of (s_i, s_{i+1}-s_i) over rho in [0, rho_max], certificate half-width
     const float2 *p1_table;
-    float p1_rho_max, p1_rho_scale;   // scale = N / rho_max
+    float p1_rho_max, p1_rho_scale;   // scale = N / rho_max (rho form), N / r_max (r form: p1_rform)
+    float p1_kmax; int32_t p1_rform;  // the table's last key: rho_max, or r_max = sqrt(rho_max) when the table runs over r (radial models other than the fisheye; gfw_frame.hip p1_key)
     float p1_eps, p1_ew, p1_em;       // E = p1_eps + p1_ew * omega + p1_em * mu: bound on |approx - exact| of the projected row/column coordinate, pixels;
                                       // omega, mu = the cancellation measures of the frame's mid-row matrix, evaluated by the kernel
     float p1_f, p1_c;                 // f[1], c[1] (f[0], c[0] for horizontal rolling shutter)

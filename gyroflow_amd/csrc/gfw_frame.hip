@@ -1161,7 +1161,7 @@ __device__ __forceinline__ void feather_store(float ux, float uy, const Feather 
 // else — a percent or two of the pixels — goes through the exact projection: queued in LDS per wave and resolved
 // densely (one exact pass per few rows of the wave instead of one per pixel row).
 struct Mid { float m0, m1, m2, m3, m4, m5, m6, m7, m8; };
-struct P1 { float rho_max, rho_scale, eps, f, c, lim, wmin, rho_lim, gap; };     // rho_lim, gap (= 1/2 - E): the lattice form's
+struct P1 { float rho_max, rho_scale, eps, f, c, lim, wmin, rho_lim, gap, kmax; };     // rho_lim, gap (= 1/2 - E): the lattice form's; kmax: the table's last key (rho_max, or r_max in the r form)
 
 template <int MODEL>
 __device__ __forceinline__ int default_row(float ox, float oy, const GfwYuvArgs &A) {
@@ -1175,6 +1175,21 @@ __device__ __forceinline__ int pass1_exact(float ox, float oy, const Mid &M, con
     const GfwPt pt = rd<MODEL>(ox, oy, float4{M.m0, M.m1, M.m2, M.m3}, float4{M.m4, M.m5, M.m6, M.m7}, M.m8, matrices + (size_t)(AF(matrix_count) / 2) * GFW_MAT_STRIDE + 8, L, A);
     if (pt.ok) { const int lim = AF(hrs) ? AF(width) : AF(height); sy = max(min(round_i32(AF(hrs) ? pt.x : pt.y), lim), 0); }
     return sy;
+}
+// The table's key.  The fisheye's scale theta_d(atan r) / r is a smooth function of rho = r^2 (theta_d is odd in theta) and is tabulated over rho: no square root.
+// The radial models served since round 6 (GoPro's inverted polynomial, gopro.rs:25-72: even powers of the radius parameter) are smooth in r but have a sqrt(rho)
+// kink at the optical centre as functions of rho: their tables run over r, and the first pass takes the hardware's square root (1 ulp: inside E).  GFW_P1_RFORM is
+// a literal of a specialised build — the only builds that certify those models.
+#ifndef GFW_P1_RFORM
+#define GFW_P1_RFORM 0
+#endif
+// The key, clamped to the table's last one (a NaN becomes kmax: the hardware minimum).  In the r form the clamp is the COMPILER's v_min_f32, not min_limit's
+// inline asm: gfx950 needs a wait state between a transcendental's result and a VALU instruction that reads it, the compiler's hazard recogniser inserts it for its
+// own instructions and cannot see inside an asm statement — `v_sqrt_f32` followed at once by the asm's `v_min_f32` read a stale register (audit on the MI355X:
+// gaps of 39 px, a third of the certificates wrong, varying with the optimisation level; the interpreter, which has no pipeline, was clean: profiles/r06_gopro_first_pass.txt)
+__device__ __forceinline__ float p1_key_clamped(float rho, float kmax) {
+    if (GFW_P1_RFORM) return __builtin_fminf(gfw_hw_sqrt(rho), kmax);
+    return min_limit(rho, kmax);
 }
 // approximate + certificate; returns false when the exact path must decide.
 // (ax, ay, aw) = ox*m0+m2, ox*m3+m5, ox*m6+m8 are per-lane constants of the pixel column.
@@ -1194,7 +1209,7 @@ __device__ __forceinline__ bool pass1_fast(float ax, float ay, float aw, float o
     }
     // table position, clamped so that a rejected lane still indexes the table: rho is a sum of squares (>= +0, or NaN, which the
     // hardware minimum turns into rho_max); the interval index is the truncated position and v_fract_f32 its exact remainder
-    const float tpos = min_limit(rho, Q.rho_max) * Q.rho_scale;
+    const float tpos = p1_key_clamped(rho, Q.kmax) * Q.rho_scale;
     const uint32_t ti = gfw_f2u_trunc(tpos);
     if (aud && !(ti <= (uint32_t)GFW_P1_TABLE_N)) atomicAdd(&aud[5], 1ull);
     const float2 e = *reinterpret_cast<const float2 *>(reinterpret_cast<const uint8_t *>(tab) + ti * 8u);
@@ -1220,7 +1235,7 @@ __device__ __forceinline__ float pass1_node(float ox, float oy, const Mid &M, co
     const float a = X * rw, b = Y * rw;
     const float rho = __builtin_fmaf(a, a, b * b);
     const bool good = (W > Q.wmin) & (rho < Q.rho_lim);            // (a NaN fails both)
-    const float tpos = min_limit(rho, Q.rho_max) * Q.rho_scale;
+    const float tpos = p1_key_clamped(rho, Q.kmax) * Q.rho_scale;
     const uint32_t ti = gfw_f2u_trunc(tpos);
     const float2 e = *reinterpret_cast<const float2 *>(reinterpret_cast<const uint8_t *>(tab) + ti * 8u);
     const float s = __builtin_fmaf(__builtin_amdgcn_fractf(tpos), e.y, e.x);
@@ -1377,7 +1392,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     float bg_c[2] = {PL1.bg[0], PL1.bg[1]};
     const float lim_u = PL1.limit, bg_v = PL2.bg[0], lim_v = PL2.limit;
     Mid M{0, 0, 0, 0, 0, 0, 0, 0, 0};
-    P1 Q{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    P1 Q{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto load_mid = [&]() {                          // first-pass matrix of the current frame: wave-uniform -> scalar loads
         const float *mid = matrices + (size_t)(AF(matrix_count) >> 1) * GFW_MAT_STRIDE;
         M.m0 = mid[0]; M.m1 = mid[1]; M.m2 = mid[2]; M.m3 = mid[3]; M.m4 = mid[4];
@@ -1460,7 +1475,7 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     if (two_pass) {
         load_mid();
         if (FAST1) {
-            Q.rho_max = A.p1_rho_max; Q.rho_scale = A.p1_rho_scale;
+            Q.rho_max = A.p1_rho_max; Q.rho_scale = A.p1_rho_scale; Q.kmax = A.p1_kmax;
             Q.f = AF(p1_f); Q.c = AF(p1_c); Q.lim = (float)(AF(hrs) ? AF(width) : AF(height));
             p1_bound(0);
         }
@@ -2055,7 +2070,10 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
 }  // namespace
 // The one instantiation a run-time build contains: template arguments and the bake header come from gfw_jit.hip.
 extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFW_JIT_WAVES, 8))) void gfw_jit_kernel(const GfwClipArgs C) {
-    gfw_yuv_body<GFW_JIT_MODEL, GFW_JIT_T, GFW_JIT_N0, GFW_FRAME_TAPS, GFW_JIT_DW, GFW_JIT_DH, (GFW_JIT_IL != 0), GFW_JIT_RB, (GFW_JIT_FAST1 != 0), false>(C.Y, &C);
+#ifndef GFW_JIT_AUDIT
+#define GFW_JIT_AUDIT 0          // 1: the audit instantiation (GFW_OPT_KERNEL_VARIANT 3 / 4 on a clip whose certified first pass exists only in specialised builds)
+#endif
+    gfw_yuv_body<GFW_JIT_MODEL, GFW_JIT_T, GFW_JIT_N0, GFW_FRAME_TAPS, GFW_JIT_DW, GFW_JIT_DH, (GFW_JIT_IL != 0), GFW_JIT_RB, (GFW_JIT_FAST1 != 0), (GFW_JIT_AUDIT != 0)>(C.Y, &C);
 }
 #else
 // Register budget: the specialised-fisheye instantiations are held to GFW_WAVES_PER_EU waves per SIMD; the generic-model ones (every

@@ -60,6 +60,14 @@ struct Rtc {
         version = reinterpret_cast<decltype(version)>(dlsym(lib, "hiprtcVersion"));
         ok = create && compile && log_size && log && code_size && code && destroy;
         if (ok && version) (void)version(&ver_major, &ver_minor);
+        // hiprtc loads its compiler (libamd_comgr: LLVM inside) and its built-in headers LAZILY, at the first compile — on a worker thread, AFTER the exit hook below has
+        // been registered, so their exit handlers would run BEFORE the hook: a process that leaves main() while its first build is still compiling then tears LLVM
+        // down under the worker and the hook waits for a thread that never returns (seen once in thirty runs of tests/cpp/test_multi_device beside other GPU
+        // processes, where the build outlived a 36-frame clip: profiles/r06_exit_during_build.txt).  Loaded here, their handlers are older than the hook.
+        if (ok) {
+            for (const char *dep : {"libamd_comgr.so.3", "libamd_comgr.so.2", "libamd_comgr.so"}) if (dlopen(dep, RTLD_NOW | RTLD_GLOBAL)) break;
+            for (const char *dep : {"libhiprtc-builtins.so.7", "libhiprtc-builtins.so"}) if (dlopen(dep, RTLD_NOW | RTLD_GLOBAL)) break;
+        }
     }
 };
 void join_all_workers();

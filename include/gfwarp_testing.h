@@ -38,6 +38,11 @@ int   gfw_debug_jit_key(int nplanes, const gfw_buffers *planes, const gfw_kernel
  * quotes them only for the library that matches.  Returns the string's length, or a negative GFW_ERR_*. */
 int   gfw_debug_source_id(char *out, size_t cap);
 
+/* The host side of the certified first pass of a radial lens model other than the fisheye (round 6: GFW_MODEL_GOPRO), without a device: `table` receives the
+ * 8193 float pairs (T(r_i), T(r_i+1) - T(r_i)) over r in [0, r_max] (or NULL), out7 = {r_max, max T, max |T'|, bound on |T''|, table error, noise of the exact
+ * path's Newton result, min POLY'}.  1: certificate derived; 0: the host declines for these coefficients / this range (the clip keeps the exact first pass). */
+int   gfw_debug_p1_radial(const gfw_kernel_params *params, int distortion_model, double r_max, float *table, double *out7);
+
 #ifdef __cplusplus
 }
 #endif

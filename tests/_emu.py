@@ -232,6 +232,47 @@ SAMPLE_KIND = {"Luma8": (1, 1), "Luma16": (2, 1), "RGB8": (1, 3), "RGBA8": (1, 4
                "RGBAf": (4, 4), "R32f": (4, 1), "RGBAf16": (3, 4)}          # plane 0's sample kind (bytes; 3 = two-byte float) and channel count (build_yuv_args); UV planes first: per-plane kernel
 
 
+def p1_table_radial(fr):
+    """The certified first pass of a gopro clip as the library sets it up (gfw_api_certificate.inc: p1_setup_radial): the table over r comes from the LIBRARY's own
+    host code (gfw_debug_p1_radial — the derivation is long and this is its only statement; what the interpreter adds is the audit of every certificate it issues),
+    the coefficients of E are restated here.  -> (table, rho_max, rho_scale, (e0, ew, em, E), lat) like p1_table, or None."""
+    p0 = fr.planes[0]["params"]
+    mc = p0.matrix_count
+    if mc <= 1:
+        return None
+    hrs = bool(p0.flags & abi.FLAG_HORIZONTAL_RS)
+    m = np.asarray(fr.matrices, dtype=np.float64)[mc >> 1]
+    rho_max = 0.0
+    for y in (0.0, p0.output_height * 0.5, float(p0.output_height)):
+        for x in (0.0, p0.output_width * 0.5, float(p0.output_width)):
+            ox, oy = x + p0.translation2d[0], y + p0.translation2d[1]
+            X, Y, W = ox * m[0] + oy * m[1] + m[2], ox * m[3] + oy * m[4] + m[5], ox * m[6] + oy * m[7] + m[8]
+            rho_max = 1e9 if not W > 0.05 else max(rho_max, (X * X + Y * Y) / (W * W))
+    rho_max = min(rho_max * 1.25 + 0.01, 64.0)
+    r_need = min(math.sqrt(rho_max) * 1.08, 8.0)
+    lib = abi.load_library()
+    lib.gfw_debug_p1_radial.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    tab, out = np.zeros((8193, 2), np.float32), np.zeros(7, np.float64)
+    if lib.gfw_debug_p1_radial(C.byref(p0), fr.model, r_need, tab.ctypes.data, out.ctypes.data) != 1:
+        return None
+    rmax, Tmax, T1, T2, etab, nu2, _ = out
+    f, cc = abs(float(p0.f[0] if hrs else p0.f[1])), abs(float(p0.c[0] if hrs else p0.c[1]))
+    u24, vmag = 1.05 / 16777216.0, f * rmax * Tmax + abs(cc)
+    G = f * (Tmax + 2.0 * rmax * T1)
+    e0 = u24 * (G * 10.0 * rmax + 6.0 * f * rmax * rmax * T1 + 11.0 * vmag) + 2.0 * f * rmax * etab + 1.05 * f * nu2 + 1.0 / 16384.0
+    ew, em = u24 * G * rmax, u24 * G
+    x0, y0 = p0.translation2d[0], p0.translation2d[1]
+    ax, ay = max(abs(x0), abs(x0 + p0.output_width)), max(abs(y0), abs(y0 + p0.output_height))
+    px, py, pw = ax * abs(m[0]) + ay * abs(m[1]), ax * abs(m[3]) + ay * abs(m[4]), ax * abs(m[6]) + ay * abs(m[7])
+    wden = max(m[8] - pw, max(1.0 / 1024.0, (pw + abs(m[8])) / 8.0))
+    eps = e0 + ew * 3.0 * pw / wden + em * 3.0 * max(px, py) / wden
+    if not eps < 0.2:
+        return None
+    lat = np.array([Tmax * (1 + 1e-6), 0.5 * T1 * (1 + 1e-6), 0.5 * rmax * T1 * (1 + 1e-6), 0.25 * (rmax * T2 + T1) * (1 + 1e-6), 4.0 * u24 * vmag + 1.0 / 131072.0, 1.0], np.float32)
+    # (the driver derives the table's last key from rho_max in the r form: sqrtf)
+    return tab, np.float32(rmax * rmax * (1.0 - 1e-6)), np.float32(8192.0 / rmax), (np.float32(e0), np.float32(ew), np.float32(em), eps), lat
+
+
 def launch_shape(fr):
     """Template arguments of the frame's instantiation, as gfw_api.hip's build_yuv_args + jit_for choose them (fisheye, no extras)."""
     pls = fr.planes
@@ -367,11 +408,16 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=F
     jit_model = 1 if lean else (-2 if extras & (16 | 32) else -1)
     stretched = any(st > 0.001 and st != 1.0 for st in (p0.input_horizontal_stretch, p0.input_vertical_stretch))      # p1_setup: exact first pass
     p1 = p1_table(p0, fr0.matrices, p0.matrix_count) if (fisheye and extras == 0 and not stretched) else None
+    rform = fr0.model == abi.MODELS["gopro"] and extras == 0 and not stretched
+    if rform:
+        p1 = p1_table_radial(fr0)           # (round 6: a table over r, specialised builds only in the product; the interpreter runs either form of the body)
     fast1 = p1 is not None
     rb = 4 if fast1 else 1
     defs = {"GFW_FRAME_KIND": bps, "GFW_FRAME_TAPS": p0.interpolation, "GFW_JIT_WAVES": jit_waves(n0, p0.matrix_count, jit_model, extras, p0.interpolation, bps, dh), "GFW_JIT_MODEL": jit_model,
             "GFW_JIT_T": {1: "uint8_t", 2: "uint16_t", 3: "_Float16", 4: "float"}[bps], "GFW_JIT_N0": n0, "GFW_JIT_DW": dw, "GFW_JIT_DH": dh,
             "GFW_JIT_IL": 1 if il else 0, "GFW_JIT_RB": rb, "GFW_JIT_FAST1": 1 if fast1 else 0}
+    if rform and fast1:
+        defs["GFW_P1_RFORM"] = 1
     assert not checksums or (baked and not audit)
     header = _bake.bake_header(fr0, rb=rb, checksum=1 if checksums else 0)
     header, n1 = re.subn(r"#define GFW_BK_extras \(0\)", "#define GFW_BK_extras (%d)" % extras, header)

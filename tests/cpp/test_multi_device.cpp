@@ -140,6 +140,19 @@ static void render(int device, int first, int step, int n_frames, const std::vec
 }
 
 int main(int argc, char **argv) {
+    if (argc > 1 && std::string(argv[1]) == "exit") {
+        // leave main() while the context's FIRST background build is still compiling (GFW_OPT_JIT = 1 starts it at the third frame; four frames of 640 x 360 are
+        // over in a millisecond): the library's exit hook must join the build with the compiler's own exit handlers still to come (gfw_jit.hip, Rtc)
+        std::signal(SIGALRM, on_alarm); alarm(60);
+        if (gfw_list_devices(nullptr, 0) <= 0) { std::printf("no HIP device: %s\n", gfw_last_error()); return 3; }
+        std::vector<uint8_t> src1[3] = {pattern(W, H, YS, 1), pattern(CW, H, CS, 2), pattern(CW, H, CS, 3)};
+        std::vector<unsigned long long> sums(4, 0);
+        std::string be;
+        render(0, 0, 1, 4, src1, &sums, &be);
+        std::printf("exit-during-build: leaving main (backends so far: %s)\n", be.c_str());
+        std::fflush(stdout);
+        return 0;
+    }
     const int T = argc > 1 ? std::atoi(argv[1]) : 4, N = argc > 2 ? std::atoi(argv[2]) : 36;
     std::signal(SIGALRM, on_alarm); alarm(120);
     const int ndev = gfw_list_devices(nullptr, 0);

@@ -24,3 +24,14 @@ def test_threads_with_their_own_device_and_context_reproduce_the_one_thread_chec
     # both kinds of kernel served frames of the one-thread run: ahead of time first, the run-time specialised one once its background build landed
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("multi-device:")][0]
     assert "yuv_fused" in line, line
+
+
+def test_a_process_may_leave_main_while_its_first_build_is_compiling():
+    """GFW_OPT_JIT = 1 (the default) compiles a clip's kernel on a worker thread; a short render can be over, its contexts destroyed and main() left while that build is
+    still inside hiprtc.  The library's exit hook joins it — and must be OLDER than the compiler's own exit handlers, which hiprtc would otherwise register lazily at
+    the first compile (one run in thirty of the multi-device test hung at exit beside other GPU processes before round 6 loaded the compiler up front: gfw_jit.hip)."""
+    if not os.path.exists(EXE):
+        pytest.skip("tests/cpp/test_multi_device not built (__graft_entry__.build)")
+    for rep in range(6):
+        r = subprocess.run([EXE, "exit"], capture_output=True, text=True, timeout=180, cwd=ROOT, env=dict(os.environ, GFW_JIT_CACHE=""))
+        assert r.returncode == 0 and "exit-during-build: leaving main" in r.stdout, "repetition %d: rc %s\n" % (rep, r.returncode) + r.stdout[-2000:] + r.stderr[-2000:]
