@@ -52,7 +52,7 @@ N_RESIDENT = 64                  # distinct source frames + per-row matrix table
 CLIP_FRAMES = 16                 # most frames gfw_undistort_clip puts into one launch (GFW_CLIP_FRAMES_MAX)
 N_DST = 8                        # destination frame sets written round-robin (the frames of one clip launch are in flight together: one set each)
 N_CHECK = 3                      # frames of the timed region compared with the oracle afterwards
-TRAFFIC_FILE = os.path.join("profiles", "r05_c2_traffic.json")       # rocprofv3 PMC passes of the C2 workload; names the kernel source it was taken on (abi.kernel_source_id)
+TRAFFIC_FILE = os.path.join("profiles", "r06_c2_traffic.json")       # rocprofv3 PMC passes of the C2 workload; names the kernel source it was taken on (abi.kernel_source_id)
 
 
 # coefficient sets of the other physical lens models (the ones tests/test_gpu_lens_models.py runs), for --lens-model
@@ -308,7 +308,7 @@ def worker(args):
     if args.lca != 1.0:
         ov = dict(ov or {}, lens_correction_amount=args.lca)
     NR = 4 if args.host_buffers else max(1, args.resident)
-    if auto_clip and NR > args.clip and NR % args.clip:
+    if args.clip > 1 and NR > args.clip and NR % args.clip and args.resident == N_RESIDENT and not args.host_buffers:
         NR -= NR % args.clip                            # the source sets cycle in whole clip calls (each frame of a call writes its own destination set)
     device_built = args.build_matrices or args.c5
     # frame j of this rank: seed and timestamp of its own (seed = 0x9F10 + frame index); the C5 clip's

@@ -143,3 +143,87 @@ def test_adversarial_clips_never_get_a_wrong_certificate(case):
     if a["certified"]:
         assert a["gap_px"] < a["eps_px"], a
     assert all(np.array_equal(x, y) for x, y in zip(O.run_frame(fr), outs[0]))
+
+
+# ---- round 6: the certified first pass of a radial model other than the fisheye (GoPro's inverted polynomial, gopro.rs:25-72) ------------------------------------
+def random_gopro_clip(seed):
+    rng = np.random.default_rng(90000 + seed)
+    w, h = int(rng.integers(60, 200)) * 2, int(rng.integers(40, 120)) * 2
+    lens = S.gopro_style_lens(w, h)
+    lens["model"] = "gopro"
+    lens["f"] = (float(rng.uniform(0.4, 0.9)) * w,) * 2
+    lens["k"] = [0.0, float(rng.uniform(0.9, 1.1)), float(rng.uniform(-0.03, 0.03)), float(rng.uniform(-0.2, 0.02)), float(rng.uniform(-0.04, 0.04)),
+                 float(rng.uniform(-0.02, 0.02)), float(rng.uniform(-0.008, 0.008))] + [0.0] * 5
+    if seed % 3:
+        lens["r_limit"] = float(rng.uniform(1.0, 3.0))
+    return S.SyntheticFrame(["YUV422P16LE", "NV12", "YUV420P"][seed % 3], w, h, seed=int(rng.integers(1, 1 << 20)), lens=lens, fov=float(rng.uniform(0.6, 1.8)),
+                            readout_ms=float(rng.uniform(-25.0, 25.0)), horizontal_rs=bool(rng.random() < 0.25))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_every_certificate_of_a_random_gopro_clip(seed):
+    """The table over r and the bounds behind E come from the library's own host code (gfw_debug_p1_radial: the derivation has one statement); what this adds is the
+    audit — the interpreted kernel re-derives the exact row of every pixel it certified, the measured |table - exact| must stay inside E — and the oracle."""
+    fr = random_gopro_clip(seed)
+    if _emu.p1_table_radial(fr) is None:
+        pytest.skip("the host declines a certificate for this lens / range (Newton not provably contracting, POLY' too small, E too wide)")
+    outs, a = _emu.run_frames([fr], audit=True)
+    assert a["wrong"] == 0 and a["queue_overflow"] == 0 and a["out_of_range"] == 0, a
+    assert a["certified"] > 0 and a["gap_px"] < a["eps_px"], a
+    assert all(np.array_equal(x, y) for x, y in zip(O.run_frame(fr), outs[0]))
+
+
+def test_the_radial_certificate_declines_what_it_cannot_prove():
+    import ctypes as C
+    from gyroflow_amd import abi
+    lib = abi.load_library()
+    lib.gfw_debug_p1_radial.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    out = np.zeros(7)
+
+    def ask(k, r_max, model=abi.MODELS["gopro"]):
+        p = abi.KernelParams()
+        for i, v in enumerate(k):
+            p.k[i] = v
+        return lib.gfw_debug_p1_radial(C.byref(p), model, r_max, None, out.ctypes.data)
+    good = [0.0, 1.0, 0.01, -0.12, 0.02, 0.01, -0.004]
+    assert ask(good, 1.5) == 1 and out[6] > 0.5 and 0.9 < out[1] < 1.1                       # d_min, Tmax of a real lens
+    assert ask([0.01] + good[1:], 1.5) == 0                                                 # k0 != 0: the scale has a pole at the optical centre
+    assert ask([0.0, 1.0, 0.0, -0.5, 0.0, 0.0, 0.0], 1.5) == 0                               # POLY' = 1 - 1.5 p^2 vanishes inside the range: the map folds
+    assert ask(good, 9.0) == 0                                                              # beyond the range the certificate is written for
+    assert ask(good, 1.5, model=abi.MODELS["opencv_fisheye"]) < 0                           # not a radial-table model
+
+
+def test_the_radial_table_and_its_bounds_against_an_independent_statement():
+    """T(r) = k1 q(atan r) / r with q = POLY^-1: the table's entries against a bisection in f64 written here, and the bounds the certificate uses (max T, max |T'|)
+    against a dense sampling of the same statement — the bounds must hold, and not be useless."""
+    import ctypes as C
+    from gyroflow_amd import abi
+    lib = abi.load_library()
+    lib.gfw_debug_p1_radial.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    k = [0.0, 1.03, -0.02, -0.15, 0.03, 0.012, -0.005]
+    p = abi.KernelParams()
+    for i, v in enumerate(k):
+        p.k[i] = v
+    kf = [float(p.k[i]) for i in range(7)]                                                  # the coefficients as the kernel sees them (f32)
+    tab, out = np.zeros((8193, 2), np.float32), np.zeros(7)
+    r_max = 1.7
+    assert lib.gfw_debug_p1_radial(C.byref(p), abi.MODELS["gopro"], r_max, tab.ctypes.data, out.ctypes.data) == 1
+
+    def q(theta):
+        lo, hi = 0.0, 4.0
+        for _ in range(200):
+            mid = 0.5 * (lo + hi)
+            if sum(c * mid ** i for i, c in enumerate(kf)) < theta:
+                lo = mid
+            else:
+                hi = mid
+        return 0.5 * (lo + hi)
+
+    def T(r):
+        return 1.0 if r == 0.0 else kf[1] * q(np.arctan(r)) / r
+    for i in (0, 1, 17, 4096, 8000, 8192):
+        assert abs(float(tab[i, 0]) - T(r_max * i / 8192.0)) < 2e-7, i
+    rs = np.linspace(0.0, r_max, 4001)
+    ts = np.array([T(r) for r in rs])
+    slope = np.abs(np.diff(ts) / np.diff(rs)).max()
+    assert ts.max() <= out[1] and slope <= out[2] <= 3.0 * slope + 0.05, (ts.max(), out[1], slope, out[2])

@@ -1,6 +1,6 @@
 #!/bin/bash
-# tools/profile_pmc.sh <tag> — rocprofv3 kernel-trace stats + PMC passes of the SHIPPED library under bench.py's default workload (C2, clip calls of 8 frames through the
-# run-time specialised kernel: one dispatch of gfw_jit_kernel = 8 frames).  Counters in their own runs (no trace domains with --pmc).
+# tools/profile_pmc.sh <tag> — rocprofv3 kernel-trace stats + PMC passes of the SHIPPED library under bench.py's default workload (C2, clip calls of 10 frames through the
+# run-time specialised kernel: one dispatch of gfw_jit_kernel = 10 frames).  Counters in their own runs (no trace domains with --pmc).
 set -u
 cd $GRAFT_REPO_ROOT
 TAG=${1:-r04}
@@ -8,7 +8,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 export RANK=0 LOCAL_RANK=0 WORLD_SIZE=1   # bench.py as a worker itself (no launcher process between rocprofv3 and the kernels)
-CMD="python bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-parity ${BENCH_EXTRA:-}"
+CMD="python bench.py --steps 80 --warmup 10 --clip 10 --no-cpu-baseline --no-parity ${BENCH_EXTRA:-}"      # every dispatch of gfw_jit_kernel carries 10 frames (warm-up, pre-heat and timed region alike): the driver line's launch
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o trace -- $CMD > $OUT/bench_trace.log 2>&1
 pmc() { n=$1; shift; timeout 120 rocprofv3 -f csv --pmc "$@" -d $OUT/pmc$n -o pmc$n -- $CMD > $OUT/bench_pmc$n.log 2>&1; }
 pmc 1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE
