@@ -741,6 +741,8 @@ def worker(args):
                 refs[k] = O.run_frame(view)
                 if not all(np.array_equal(refs[k][p], got[d][p]) for p in range(nplanes)):
                     bad.append(k)
+                    diff = [np.flatnonzero(refs[k][p] != got[d][p]) for p in range(nplanes)]
+                    print("bench: step %d differs from the oracle: %s bytes per plane, first at %s" % (k, [int(x.size) for x in diff], [int(x[0]) if x.size else None for x in diff]), file=sys.stderr)
                 if args.c5 and sums_in_kernel:
                     # the checksum of the bytes WRITTEN (the pixels: stride padding and the gaps between planes stay out), each at its place in its 64-bit word
                     want = 0

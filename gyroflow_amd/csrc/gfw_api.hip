@@ -1070,9 +1070,9 @@ extern "C" long gfw_debug_jit_compile(const char *arch, const char *defines, con
 // GFW_P1_TABLE_N + 1 float pairs over r in [0, r_max] and {r_max, Tmax, T1, T2, e_table, nu2, d_min} (gfw_api_certificate.inc: p1_prepare_radial_gopro).
 // Returns 1 when a certificate exists for these coefficients and this range, 0 when the host declines, a negative GFW_ERR_* on bad arguments.
 extern "C" int gfw_debug_p1_radial(const gfw_kernel_params *params, int distortion_model, double r_max, float *table, double *out7) {
-    if (!params || !out7 || distortion_model != GFW_MODEL_GOPRO) { set_error("gfw_debug_p1_radial: model %d has no radial certificate", distortion_model); return GFW_ERR_INVALID_ARGUMENT; }
+    if (!params || !out7 || !p1_model_radial(distortion_model)) { set_error("gfw_debug_p1_radial: model %d has no radial certificate", distortion_model); return GFW_ERR_INVALID_ARGUMENT; }
     P1Radial R; std::vector<float2> tab;
-    if (!p1_prepare_radial_gopro(*params, r_max, R, table ? &tab : nullptr)) return 0;
+    if (!p1_prepare_radial(distortion_model, *params, r_max, R, table ? &tab : nullptr)) return 0;
     if (table) memcpy(table, tab.data(), tab.size() * sizeof(float2));
     out7[0] = R.r_max; out7[1] = R.Tmax; out7[2] = R.T1; out7[3] = R.T2; out7[4] = R.etab; out7[5] = R.nu2; out7[6] = R.dmin;
     return 1;

@@ -1268,7 +1268,11 @@ __device__ __forceinline__ void gfw_yuv_body(const GfwYuvArgs &A_in, const GfwCl
     const unsigned long long tl_start = wall_clock64();           // the wave's first instruction
 #endif
 #if GFW_BAKE
-    const int n_frames = clip ? clip->n_frames : 1;
+    // (`clip` is the kernel's own by-value argument in a baked build, never null — and must not be TESTED: a pointer comparison is a use the optimiser cannot forward
+    // to the argument segment, so in builds where the test survives to that point (the twelve-coefficient polynomial's certified pass did it) the whole 2.2 KB block
+    // is copied to scratch by every lane — 0.4 ms per launch — at private offset 0, which the hardware-level compare takes for null: n_frames came out as 1 and the
+    // launch's other frames were never written.  profiles/r06_radial_closed_form.txt)
+    const int n_frames = clip->n_frames;
 #else
     constexpr int n_frames = 1;
     (void)clip;

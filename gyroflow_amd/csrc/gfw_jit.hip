@@ -289,7 +289,15 @@ hipFunction_t gfw_jit_get(int device, const std::string &arch, const std::vector
             e->join();                                   // the worker has published its result: returns at once
             hipError_t err = hipModuleLoadData(&e->mod, e->code.data());
             if (err == hipSuccess) err = hipModuleGetFunction(&e->fn, e->mod, "gfw_jit_kernel");
-            if (err != hipSuccess) { e->log += std::string("\nmodule load: ") + hipGetErrorString(err); e->state.store(ST_FAILED); }
+            // A specialised build whose lanes keep a kilobyte or more in scratch has its argument block there (2.2 KB, copied by every lane: 0.4 ms per launch
+            // — the ahead-of-time kernels are several times faster): not used.  Nothing the shipped source compiles to does this; round 6 met it once, through a
+            // pointer test in the kernel body that kept the optimiser from reading the argument segment directly (profiles/r06_radial_closed_form.txt).
+            int scratch = 0;
+            if (err == hipSuccess && hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, e->fn) == hipSuccess && scratch >= 1024) {
+                char b[160]; snprintf(b, sizeof(b), "\nspecialised kernel refused: %d bytes of scratch per lane (its argument block lives there); the ahead-of-time kernel serves the clip", scratch);
+                e->log += b; (void)hipModuleUnload(e->mod); e->mod = nullptr; e->fn = nullptr; e->state.store(ST_FAILED);
+            }
+            else if (err != hipSuccess) { e->log += std::string("\nmodule load: ") + hipGetErrorString(err); e->state.store(ST_FAILED); }
             else { e->code.clear(); e->code.shrink_to_fit(); e->state.store(ST_LOADED); }
         }
         st = e->state.load();

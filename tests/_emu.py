@@ -232,8 +232,11 @@ SAMPLE_KIND = {"Luma8": (1, 1), "Luma16": (2, 1), "RGB8": (1, 3), "RGBA8": (1, 4
                "RGBAf": (4, 4), "R32f": (4, 1), "RGBAf16": (3, 4)}          # plane 0's sample kind (bytes; 3 = two-byte float) and channel count (build_yuv_args); UV planes first: per-plane kernel
 
 
+RADIAL_TABLE_MODELS = {abi.MODELS[m] for m in ("gopro", "sony", "generic_polynomial", "poly3", "poly5", "ptlens")}      # gfw_api_certificate.inc: p1_model_radial
+
+
 def p1_table_radial(fr):
-    """The certified first pass of a gopro clip as the library sets it up (gfw_api_certificate.inc: p1_setup_radial): the table over r comes from the LIBRARY's own
+    """The certified first pass of a clip under a radial lens model other than the fisheye (GoPro, Sony, generic polynomial, poly3 / poly5 / ptlens) as the library sets it up (gfw_api_certificate.inc: p1_setup_radial): the table over r comes from the LIBRARY's own
     host code (gfw_debug_p1_radial — the derivation is long and this is its only statement; what the interpreter adds is the audit of every certificate it issues),
     the coefficients of E are restated here.  -> (table, rho_max, rho_scale, (e0, ew, em, E), lat) like p1_table, or None."""
     p0 = fr.planes[0]["params"]
@@ -408,7 +411,7 @@ def run_frames(frames, mesh=None, baked=True, grid=8, votes=0, hw_ulp=0, audit=F
     jit_model = 1 if lean else (-2 if extras & (16 | 32) else -1)
     stretched = any(st > 0.001 and st != 1.0 for st in (p0.input_horizontal_stretch, p0.input_vertical_stretch))      # p1_setup: exact first pass
     p1 = p1_table(p0, fr0.matrices, p0.matrix_count) if (fisheye and extras == 0 and not stretched) else None
-    rform = fr0.model == abi.MODELS["gopro"] and extras == 0 and not stretched
+    rform = fr0.model in RADIAL_TABLE_MODELS and extras == 0 and not stretched
     if rform:
         p1 = p1_table_radial(fr0)           # (round 6: a table over r, specialised builds only in the product; the interpreter runs either form of the body)
     fast1 = p1 is not None

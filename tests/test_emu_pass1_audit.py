@@ -3,6 +3,8 @@ the exact rolling-shutter row of every pixel whose approximate row it accepted a
 tap, store, matrix row and table entry against the declared buffer lengths — over seeded random fisheye clips (lens coefficients, focal length, principal point,
 field of view 0.5-3, readout up to +-30 ms, both shutter directions, odd sizes).  The CPU twin of tests/test_gpu_pass1_sweep.py (same assertions: no wrong
 certificate, gap below half the certificate's half-width E, nothing out of range, the queue never overflows)."""
+import math
+
 import numpy as np
 import pytest
 
@@ -171,6 +173,88 @@ def test_every_certificate_of_a_random_gopro_clip(seed):
     assert a["wrong"] == 0 and a["queue_overflow"] == 0 and a["out_of_range"] == 0, a
     assert a["certified"] > 0 and a["gap_px"] < a["eps_px"], a
     assert all(np.array_equal(x, y) for x, y in zip(O.run_frame(fr), outs[0]))
+
+
+CLOSED_FORM_K = {          # coefficient ranges around what the lens databases hold for these models (lensfun's poly3 / poly5 / ptlens; Sony's and the generic theta polynomial)
+    "sony": lambda rng: [rng.uniform(0.9, 1.1), rng.uniform(-0.05, 0.05), rng.uniform(-0.15, 0.05), rng.uniform(-0.04, 0.04), rng.uniform(-0.01, 0.01), rng.uniform(-0.004, 0.004)],
+    "generic_polynomial": lambda rng: [rng.uniform(0.9, 1.1), rng.uniform(-0.05, 0.05), rng.uniform(-0.15, 0.05), rng.uniform(-0.04, 0.04), rng.uniform(-0.01, 0.01), rng.uniform(-0.004, 0.004)]
+                                       + [rng.uniform(-0.001, 0.001) for _ in range(6)],
+    "poly3": lambda rng: [rng.uniform(-0.12, 0.12)],
+    "poly5": lambda rng: [rng.uniform(-0.12, 0.12), rng.uniform(-0.04, 0.04)],
+    "ptlens": lambda rng: [rng.uniform(-0.03, 0.03), rng.uniform(-0.06, 0.06), rng.uniform(-0.04, 0.04)],
+}
+
+
+def random_closed_form_clip(model, seed):
+    rng = np.random.default_rng(91000 + 100 * sorted(CLOSED_FORM_K).index(model) + seed)
+    w, h = int(rng.integers(60, 200)) * 2, int(rng.integers(40, 120)) * 2
+    lens = S.gopro_style_lens(w, h)
+    lens["model"] = model
+    lens["f"] = (float(rng.uniform(0.4, 0.9)) * w,) * 2
+    k = [float(v) for v in CLOSED_FORM_K[model](rng)]
+    lens["k"] = k + [0.0] * (12 - len(k))
+    if seed % 3:
+        lens["r_limit"] = float(rng.uniform(1.0, 3.0))
+    return S.SyntheticFrame(["YUV422P16LE", "NV12", "YUV420P"][seed % 3], w, h, seed=int(rng.integers(1, 1 << 20)), lens=lens, fov=float(rng.uniform(0.6, 1.8)),
+                            readout_ms=float(rng.uniform(-25.0, 25.0)), horizontal_rs=bool(rng.random() < 0.25))
+
+
+@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("model", sorted(CLOSED_FORM_K))
+def test_every_certificate_of_a_random_closed_form_radial_clip(model, seed):
+    """Sony / generic polynomial (a polynomial in theta = atan r, sony.rs:69-88, generic_polynomial.rs) and lensfun's poly3 / poly5 / ptlens (polynomials in r): no
+    iteration in the exact path, so the certificate is the table's error plus the formula's roundings (gfw_api_certificate.inc: p1_prepare_radial_thetapoly / _rpoly).
+    The interpreted kernel re-derives the exact row of every pixel it certified; the frame equals the oracle."""
+    fr = random_closed_form_clip(model, seed)
+    assert _emu.p1_table_radial(fr) is not None, "a closed-form model over a sane range must be certifiable"
+    outs, a = _emu.run_frames([fr], audit=True)
+    assert a["wrong"] == 0 and a["queue_overflow"] == 0 and a["out_of_range"] == 0, a
+    assert a["certified"] > 0 and a["gap_px"] < a["eps_px"], a
+    assert all(np.array_equal(x, y) for x, y in zip(O.run_frame(fr), outs[0]))
+
+
+@pytest.mark.parametrize("model", sorted(CLOSED_FORM_K))
+def test_closed_form_tables_against_an_independent_statement(model):
+    """The table's entries against the model's formula written here in f64, max |T| and max |T'| against a dense sampling of it: the bounds hold and are not useless;
+    the all-zero Sony / generic lens (the reference passes the point through: sony.rs:71) has no table."""
+    import ctypes as C
+    from gyroflow_amd import abi
+    lib = abi.load_library()
+    lib.gfw_debug_p1_radial.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(0xC10 + len(model))
+    p = abi.KernelParams()
+    for i, v in enumerate(CLOSED_FORM_K[model](rng)):
+        p.k[i] = v
+    k = [float(p.k[i]) for i in range(12)]
+
+    def T(r):
+        if model in ("sony", "generic_polynomial"):
+            n = 6 if model == "sony" else 12
+            t = math.atan(r)
+            return k[0] if r == 0.0 else sum(k[i] * t ** (i + 1) for i in range(n)) / r
+        if model == "poly3":
+            return 1.0 + k[0] * r * r
+        if model == "poly5":
+            return 1.0 + k[0] * r ** 2 + k[1] * r ** 4
+        return 1.0 + k[2] * r + k[1] * r ** 2 + k[0] * r ** 3
+    r_max = 2.1
+    tab, out = np.zeros((8193, 2), np.float32), np.zeros(7)
+    assert lib.gfw_debug_p1_radial(C.byref(p), abi.MODELS[model], r_max, tab.ctypes.data, out.ctypes.data) == 1
+    for i in (0, 1, 17, 4096, 8000, 8192):
+        assert abs(float(tab[i, 0]) - T(r_max * i / 8192.0)) < 2e-7 * max(1.0, abs(T(r_max * i / 8192.0))), i
+        if i < 8192:
+            assert abs(float(tab[i, 1]) - (T(r_max * (i + 1) / 8192.0) - T(r_max * i / 8192.0))) < 1e-9, i
+    rs = np.linspace(0.0, r_max, 20001)
+    ts = np.array([T(r) for r in rs])
+    slope = np.abs(np.diff(ts) / np.diff(rs)).max()
+    curv = np.abs(np.diff(ts, 2)).max() / (rs[1] - rs[0]) ** 2
+    assert np.abs(ts).max() <= out[1] and slope <= out[2] <= 3.0 * slope + 0.05 and curv <= out[3] * (1 + 1e-3) + 1e-3, (np.abs(ts).max(), out[1], slope, out[2], curv, out[3])
+    assert out[4] < 1e-6 and out[5] < 1e-5, out                                              # table error and float noise: far below a 32nd of a pixel at any focal length
+    if model in ("sony", "generic_polynomial"):
+        z = abi.KernelParams()
+        z.k[5] = 0.25                                                                       # k0..k3 zero (sony) — the generic model tests all twelve
+        assert lib.gfw_debug_p1_radial(C.byref(z), abi.MODELS["sony"], r_max, None, out.ctypes.data) == 0
+        assert lib.gfw_debug_p1_radial(C.byref(abi.KernelParams()), abi.MODELS[model], r_max, None, out.ctypes.data) == 0
 
 
 def test_the_radial_certificate_declines_what_it_cannot_prove():

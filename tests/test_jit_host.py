@@ -152,3 +152,30 @@ def test_the_checksum_build_takes_its_sums_without_a_private_segment(tmp_path):
     assert k[".private_segment_fixed_size"] == 0 and k[".vgpr_count"] <= 72, (k[".vgpr_count"], k[".private_segment_fixed_size"])
     assert KR.workgroups_per_cu(k) >= 7, KR.workgroups_per_cu(k)
     assert k[".group_segment_fixed_size"] - kp[".group_segment_fixed_size"] in range(2048, 2048 + 128), (k[".group_segment_fixed_size"], kp[".group_segment_fixed_size"])
+
+
+@pytest.mark.parametrize("model", ["gopro", "sony", "generic_polynomial"])
+def test_the_certified_pass_of_a_radial_model_specialises_without_a_private_segment(tmp_path, model):
+    """Round 6: the twelve-coefficient polynomial's certified build came out with 2.3 KB of scratch per lane — the kernel's whole argument block, copied there by every
+    lane because the body TESTED its pointer (`clip ? clip->n_frames : 1`; a comparison is a use the optimiser cannot forward to the argument segment) — ran 0.43 ms
+    per launch and, the copy sitting at private offset 0 where the compare reads "null", wrote only the first frame of a clip launch (profiles/r06_radial_closed_form.txt).
+    Whatever a served radial model's clip compiles to reads its arguments where they are."""
+    import build_jit_cache as B
+    from gyroflow_amd import synthetic as S
+    import bench
+    lib = abi.load_library()
+    lens = dict(S.gopro_style_lens(3840, 2160))
+    k = bench.LENS_MODEL_K[model]
+    lens["model"], lens["k"] = model, k + [0.0] * (12 - len(k))
+    fr = S.SyntheticFrame("YUV422P16LE", 3840, 2160, seed=0x9F10, timestamp_ms=1000.0, lens=lens, readout_ms=16.0, pixels=False)
+    defs, header, _ = B.key_of(lib, fr)
+    assert b"GFW_JIT_FAST1=1" in defs and b"#define GFW_P1_RFORM (1)" in header, defs
+    out = str(tmp_path / "radial.co")
+    log = C.create_string_buffer(1 << 16)
+    n = lib.gfw_debug_jit_compile(b"gfx950", defs, header, out.encode(), log, len(log))
+    if n == -2:
+        pytest.skip("libhiprtc.so not available")
+    assert n > 0, log.value.decode(errors="replace")[-3000:]
+    kr = [x for x in KR.report(out) if x[".name"] == "gfw_jit_kernel"][0]
+    # (the GoPro solver's ten Newton steps spill three dwords at eight waves — the argument block is 2224 bytes)
+    assert kr[".private_segment_fixed_size"] <= 64 and kr[".vgpr_count"] <= 64, (kr[".vgpr_count"], kr[".private_segment_fixed_size"])
