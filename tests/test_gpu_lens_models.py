@@ -187,3 +187,25 @@ def test_ibis_terms_with_device_resident_matrices(mode):
             be.close()
         for i, (a, b) in enumerate(zip(ref, outs)):
             assert_plane_equal(a, b, fr.planes[i]["pixel_type"], "ibis mode %d variant %d plane %d" % (mode, variant, i))
+
+
+@pytest.mark.parametrize("model", sorted(PHYSICAL))
+@pytest.mark.parametrize("fmt,lca", [("YUV422P16LE", 1.0), ("NV12", 1.0), ("YUV420P", 0.45)])
+def test_every_frame_of_a_clip_launch_for_every_lens_model(model, fmt, lca):
+    """gfw_undistort_clip, four frames in one launch of the clip's specialised build, device-resident tables: every frame lands in its own planes and equals the
+    oracle's — for every lens model (round 6: one model's build took a clip launch for a single frame, tests/test_gpu_pass1_radial.py tells the story; the frame-by-
+    frame tests above could not see it)."""
+    import test_gpu_jit as J
+    w, h = 384, 216
+    lens = S.gopro_style_lens(w, h)
+    lens["model"] = model
+    lens["k"] = PHYSICAL[model] + [0.0] * (12 - len(PHYSICAL[model]))
+    if model == "gopro":
+        lens["r_limit"] = 2.5
+    frames = [S.SyntheticFrame(fmt, w, h, seed=0x9F10 + j, timestamp_ms=1000.0 + 33.3 * j, lens=dict(lens), fov=1.2, readout_ms=16.0, pixels=False,
+                               base_overrides={"lens_correction_amount": lca}) for j in range(4)]
+    backend, status, (ms, launches, covered), outs, srcs = J.device_clip(frames, 2, True)
+    assert backend.endswith("_jit") and status[0] == 2 and launches == 1 and covered == 4, (backend, status, launches, covered)
+    for j, fr in enumerate(frames):
+        for p, (a, b) in enumerate(zip(O.run_frame(J._View(fr, srcs[j])), outs[j])):
+            assert_plane_equal(a, b, fr.planes[p]["pixel_type"], "%s clip launch (%s), frame %d plane %d" % (model, backend, j, p))

@@ -154,12 +154,13 @@ def test_the_checksum_build_takes_its_sums_without_a_private_segment(tmp_path):
     assert k[".group_segment_fixed_size"] - kp[".group_segment_fixed_size"] in range(2048, 2048 + 128), (k[".group_segment_fixed_size"], kp[".group_segment_fixed_size"])
 
 
-@pytest.mark.parametrize("model", ["gopro", "sony", "generic_polynomial"])
-def test_the_certified_pass_of_a_radial_model_specialises_without_a_private_segment(tmp_path, model):
+@pytest.mark.parametrize("model", ["gopro", "sony", "generic_polynomial", "opencv_standard", "poly3", "poly5", "ptlens", "insta360"])
+def test_every_lens_models_clip_specialises_without_a_private_segment(tmp_path, model):
     """Round 6: the twelve-coefficient polynomial's certified build came out with 2.3 KB of scratch per lane — the kernel's whole argument block, copied there by every
     lane because the body TESTED its pointer (`clip ? clip->n_frames : 1`; a comparison is a use the optimiser cannot forward to the argument segment) — ran 0.43 ms
     per launch and, the copy sitting at private offset 0 where the compare reads "null", wrote only the first frame of a clip launch (profiles/r06_radial_closed_form.txt).
-    Whatever a served radial model's clip compiles to reads its arguments where they are."""
+    Whatever a lens model's clip compiles to reads its arguments where they are (54 builds — 9 models x 3 formats x bilinear / Lanczos4 — swept by hand: at most
+    20 bytes, a few spilled dwords of the GoPro solver; this keeps the C2 geometry of each model under test)."""
     import build_jit_cache as B
     from gyroflow_amd import synthetic as S
     import bench
@@ -169,7 +170,8 @@ def test_the_certified_pass_of_a_radial_model_specialises_without_a_private_segm
     lens["model"], lens["k"] = model, k + [0.0] * (12 - len(k))
     fr = S.SyntheticFrame("YUV422P16LE", 3840, 2160, seed=0x9F10, timestamp_ms=1000.0, lens=lens, readout_ms=16.0, pixels=False)
     defs, header, _ = B.key_of(lib, fr)
-    assert b"GFW_JIT_FAST1=1" in defs and b"#define GFW_P1_RFORM (1)" in header, defs
+    served = model in ("gopro", "sony", "generic_polynomial")                            # the certified first pass over r (gfw_api_certificate.inc: p1_model_radial_served)
+    assert (b"GFW_JIT_FAST1=1" in defs and b"#define GFW_P1_RFORM (1)" in header) == served, defs
     out = str(tmp_path / "radial.co")
     log = C.create_string_buffer(1 << 16)
     n = lib.gfw_debug_jit_compile(b"gfx950", defs, header, out.encode(), log, len(log))
