@@ -335,6 +335,9 @@ def worker(args):
     dst_total = S.align(offs[-1], 256)
     d_dstbuf = [torch.full((dst_total,), 0x5A, dtype=torch.uint8, device=dev) for _ in range(N_DST)]
     d_dst = [[d_dstbuf[d][offs[p]:offs[p] + sizes[p]] for p in range(nplanes)] for d in range(N_DST)]
+    if os.environ.get("GFW_BENCH_ADDR") and not args.host_buffers:      # diagnosis: where the resident sets landed (profiles/r06_c3_bimodal.txt)
+        print("addr src0", [hex(t.data_ptr()) for t in d_src[0]], "src1", [hex(t.data_ptr()) for t in d_src[min(1, NR - 1)]],
+              "dst", [hex(t.data_ptr()) for t in d_dstbuf[:3]], file=sys.stderr, flush=True)
     bufsets = []                                      # bufsets[j * N_DST + d]: source set j -> destination set d
     for j in range(NR):
         fr = frames[j]

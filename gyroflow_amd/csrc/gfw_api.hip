@@ -586,6 +586,8 @@ struct ClipBatch {
     GfwClipArgs CA;
     hipFunction_t fn = nullptr;
     int grid = 0, n = 0;
+    int n_call = 0;                              // frames of the gfw_undistort_clip call being dealt into launches (0: frames held from per-plane calls)
+    int limit = GFW_CLIP_MAX;                    // frames this launch takes: clip_launch_limit() of the frame that opened it
     const gfw_buffers *first = nullptr;          // planes of the frame that opened the pending launch (fully validated by run_planes)
     const char *backend = "";
     unsigned long long *sums[GFW_CLIP_MAX] = {};   // gfw_set_frame_checksums: where each frame's checksum goes (the launch's kernel takes it: CA.Y.checksum)
@@ -594,6 +596,23 @@ struct ClipBatch {
 // (peek: the ring index advances — sum_commit — only once the frame has been enqueued; a call that fails consumes no slot, so "frame k submitted" keeps meaning what gfwarp.h says)
 static unsigned long long *next_sum(gfw_ctx *c) { return (c->sums && c->sum_n) ? c->sums + (c->sum_k % c->sum_n) : nullptr; }
 static void sum_commit(gfw_ctx *c, unsigned long long *sum) { if (sum) c->sum_k++; }
+// How many frames one launch of the specialised kernel takes.  The frames of a launch are worked through in order by every XCD with no barrier between them, and the
+// bytes they touch are in flight together: 8K frames (265 MB read + written each) measured 184 us per frame in launches of 2, 4 or 8 and 200-202 us in launches of
+// 16 (4.2 GB per launch); 4K frames (66 MB) 42.3-43.2 us anywhere from 8 to 16 (profiles/r06_c3_frames_per_launch.txt).  So a launch is capped at
+// GFW_CLIP_LAUNCH_BYTES of source + destination (1.1 GB: sixteen 4K 16-bit 4:2:2 frames, four 8K ones; never below 2 frames), and the frames of one
+// gfw_undistort_clip call are dealt evenly over the launches that needs (16 frames under a cap of 4: 4 + 4 + 4 + 4, not a runt at the end).
+static size_t clip_launch_bytes() {
+    static const size_t v = [] { const char *e = getenv("GFW_CLIP_LAUNCH_MB"); const long mb = e ? atol(e) : 0; return mb > 0 ? (size_t)mb << 20 : (size_t)1100 << 20; }();
+    return v;
+}
+static int clip_launch_limit(const GfwYuvArgs &Y, int nplanes, int n_call) {
+    size_t bytes = 0;
+    for (int i = 0; i < nplanes && i < 4; ++i) bytes += ((size_t)(Y.pl[i].src_stride < 0 ? -Y.pl[i].src_stride : Y.pl[i].src_stride) + (size_t)(Y.pl[i].dst_stride < 0 ? -Y.pl[i].dst_stride : Y.pl[i].dst_stride)) * (size_t)Y.pl[i].h;
+    int cap = bytes ? (int)(clip_launch_bytes() / bytes) : GFW_CLIP_MAX;
+    cap = cap < 2 ? 2 : (cap > GFW_CLIP_MAX ? GFW_CLIP_MAX : cap);
+    if (n_call > cap) { const int launches = (n_call + cap - 1) / cap; cap = (n_call + launches - 1) / launches; }
+    return cap;
+}
 // the launch's table of partial sums: one word per frame, workgroup and wave (gfw_frame.hip ck_flush)
 static int clip_flush(gfw_ctx *c, ClipBatch *b);
 static int ck_table(gfw_ctx *c, int grid, GfwYuvArgs &Y, ClipBatch *pending) {
@@ -808,14 +827,15 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
                                  !clip_same_params(batch->CA.Y, Y) || clip_overlaps(batch, planes, nplanes))) {
                 const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc;
             }
-            if (batch->n == 0) { batch->CA.Y = Y; batch->fn = jf; batch->grid = jgrid; batch->first = planes; batch->backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit"; }
+            if (batch->n == 0) { batch->CA.Y = Y; batch->fn = jf; batch->grid = jgrid; batch->first = planes; batch->backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit";
+                                 batch->limit = clip_launch_limit(Y, nplanes, batch->n_call); }
             batch->sums[batch->n] = sum;
             sum_commit(c, sum);                       // the frame is part of the pending launch from here on
             GfwFrameDyn &F = batch->CA.fr[batch->n++];
             for (int i = 0; i < 4; ++i) { F.src[i] = Y.pl[i].src; F.dst[i] = Y.pl[i].dst; }
             F.matrices = Y.matrices;
             c->last_backend = fast1 ? "yuv_fused_p1_jit" : "yuv_fused_jit";
-            if (batch->n == GFW_CLIP_MAX) { const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc; }
+            if (batch->n >= batch->limit) { const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc; }
             if (sum && !sum_taken) {                  // (a frame of a launch whose kernel does not take sums: behind the launch it has just joined)
                 const int frc = clip_flush(c, batch); if (frc != GFW_OK) return frc;
                 const int src_ = checksum_written(c, nplanes, planes, params, sum); if (src_ != GFW_OK) return src_;
@@ -980,12 +1000,13 @@ int gfw_undistort_clip(gfw_ctx *c, int n_frames, int nplanes, const gfw_buffers 
     // the frame loop of a render (rendering/mod.rs:487-547 calls process_pixels once per frame), here on the library side: frames that
     // share the specialised kernel leave in launches of up to GFW_CLIP_MAX frames, everything else exactly as gfw_undistort_frame
     ClipBatch batch;
+    batch.n_call = n_frames;
     for (int f = 0; f < n_frames; ++f) {
         // A frame shaped exactly like the one that opened the pending launch (same descriptions but for the pointers; the parameters are
         // shared by construction) needs none of the per-frame validation again: its pointers join the launch.  ~10 us -> < 1 us of host time.
         bool words = true;                            // (the checksum build places an element by its offset: every plane on a 64-bit word, as run_planes checked for the launch's first frame)
         if (c->sums && batch.n > 0) for (int i = 0; i < nplanes && i < 4; ++i) words = words && (((uintptr_t)planes[(size_t)f * nplanes + i].output.data + (uintptr_t)(batch.CA.fr[0].dst[i] - (uint8_t *)batch.first[i].output.data)) & 7) == 0;
-        if (batch.n > 0 && batch.n < GFW_CLIP_MAX && (!c->sums || (batch.CA.Y.checksum && words)) && c->matrices_on_device == 2 && matrices[f] && clip_same_shape(batch.first, planes + (size_t)f * nplanes, nplanes) &&
+        if (batch.n > 0 && batch.n < batch.limit && (!c->sums || (batch.CA.Y.checksum && words)) && c->matrices_on_device == 2 && matrices[f] && clip_same_shape(batch.first, planes + (size_t)f * nplanes, nplanes) &&
             !clip_ring_table(c, matrices[f]) && !clip_overlaps(&batch, planes + (size_t)f * nplanes, nplanes)) {
             batch.sums[batch.n] = next_sum(c);
             sum_commit(c, batch.sums[batch.n]);
@@ -998,7 +1019,7 @@ int gfw_undistort_clip(gfw_ctx *c, int n_frames, int nplanes, const gfw_buffers 
             }
             F.matrices = matrices[f];
             c->last_backend = batch.backend;
-            if (batch.n == GFW_CLIP_MAX) { const int frc = clip_flush(c, &batch); if (frc != GFW_OK) return frc; }
+            if (batch.n >= batch.limit) { const int frc = clip_flush(c, &batch); if (frc != GFW_OK) return frc; }
             continue;
         }
         const int rc = run_planes(c, nplanes, planes + (size_t)f * nplanes, params, pixel_types, matrices[f], matrix_count, nullptr, 0, &batch);
