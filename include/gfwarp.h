@@ -254,7 +254,10 @@ int gfw_undistort_frame(gfw_ctx *ctx, int nplanes,
  * kernel (GFW_OPT_JIT) leave in launches of up to GFW_CLIP_FRAMES_MAX frames, so that the occupancy tail of one frame is
  * filled by the next and the cost differences between image regions average out over the GPU's partitions.  The frames of
  * one launch are in flight together; a frame whose buffers overlap a pending frame's (it writes or reads a destination
- * already in the launch, or writes one of its sources) starts a new launch, so the results are those of the ordered calls. */
+ * already in the launch, or writes one of its sources) starts a new launch, so the results are those of the ordered calls.
+ * A launch also takes at most 1.1 GB of source + destination (sixteen 4K 16-bit 4:2:2 frames, four 8K ones; at least two
+ * frames; environment GFW_CLIP_LAUNCH_MB overrides): past that the frames in flight together cost more than the tail they
+ * fill (8K: 9 %), and the call's frames are dealt evenly over the launches it needs (16 under a cap of 4: 4 + 4 + 4 + 4). */
 #define GFW_CLIP_FRAMES_MAX 16
 int gfw_undistort_clip(gfw_ctx *ctx, int n_frames, int nplanes,
                        const gfw_buffers *planes,

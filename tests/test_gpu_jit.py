@@ -197,6 +197,40 @@ def test_clip_entry_point_matches_frame_by_frame_and_the_oracle(fmt, n):
             assert_plane_equal(a, c, fr.planes[p]["pixel_type"], "frame by frame, frame %d plane %d" % (j, p))
 
 
+_CAP_SCRIPT = r"""
+import sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np
+from gyroflow_amd import synthetic as S
+import _oracle as O
+import test_gpu_jit as J
+frames = [S.SyntheticFrame("YUV422P16LE", 320, 192, seed=0x9F10 + j, timestamp_ms=1000.0 + 33.3 * j, pixels=False) for j in range(7)]
+backend, status, (ms, launches, covered), outs, srcs = J.device_clip(frames, 2, True)
+bad = 0
+for j, fr in enumerate(frames):
+    for a, b in zip(O.run_frame(J._View(fr, srcs[j])), outs[j]):
+        bad += int(np.count_nonzero(np.asarray(a) != np.asarray(b)))
+print("RESULT " + json.dumps({"backend": backend, "launches": int(launches), "covered": int(covered), "bad": bad}))
+"""
+
+
+def test_a_clip_call_is_dealt_evenly_over_launches_of_capped_size(tmp_path):
+    """gfw_api.hip clip_launch_limit: a launch of the specialised kernel takes at most GFW_CLIP_LAUNCH_MB of source + destination (1.1 GB by default: 8K frames
+    in launches of sixteen measured 9 % slower than in launches of four, profiles/r06_c3_frames_per_launch.txt) and the call's frames are dealt evenly over the
+    launches that needs.  With the cap at 1 MB a 320 x 192 4:2:2 16-bit frame (491 KB) goes two to a launch: a 7-frame call leaves as 2 + 2 + 2 + 1, every frame
+    bit-exact.  (The cap is read once per process: its own interpreter.)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "cap.py"
+    script.write_text(_CAP_SCRIPT % {"root": root, "tests": os.path.join(root, "tests")})
+    for mb, want in (("1", 4), ("0", 1)):                 # 0: the default cap — one launch of seven
+        r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, GFW_CLIP_LAUNCH_MB=mb), capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        assert r.returncode == 0 and line, (r.stdout[-2000:], r.stderr[-2000:])
+        res = json.loads(line[-1][7:])
+        assert res["backend"].endswith("_jit") and res["launches"] == want and res["covered"] == 7 and res["bad"] == 0, (mb, res)
+
+
 @pytest.mark.parametrize("fmt,kw", [
     ("YUV422P16LE", dict(fov=1.4, base_overrides={"background_mode": 3, "background_margin": 0.1, "background_margin_feather": 0.1})),
     ("YUVA444P10LE", dict(fov=1.3, interpolation=4, base_overrides={"background_mode": 3, "background_margin": 0.13, "background_margin_feather": 0.24})),
