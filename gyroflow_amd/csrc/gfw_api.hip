@@ -580,125 +580,7 @@ static bool int_products_exact(int n_max, int n) {
 
 #include "gfw_api_certificate.inc"
 #include "gfw_api_eligibility.inc"
-// Frames of one gfw_undistort_clip call waiting to go out in one launch of the specialised kernel.
-static_assert(GFW_CLIP_MAX == GFW_CLIP_FRAMES_MAX, "gfw_frame.h and gfwarp.h disagree on the frames of a clip launch");
-struct ClipBatch {
-    GfwClipArgs CA;
-    hipFunction_t fn = nullptr;
-    int grid = 0, n = 0;
-    int n_call = 0;                              // frames of the gfw_undistort_clip call being dealt into launches (0: frames held from per-plane calls)
-    int limit = GFW_CLIP_MAX;                    // frames this launch takes: clip_launch_limit() of the frame that opened it
-    const gfw_buffers *first = nullptr;          // planes of the frame that opened the pending launch (fully validated by run_planes)
-    const char *backend = "";
-    unsigned long long *sums[GFW_CLIP_MAX] = {};   // gfw_set_frame_checksums: where each frame's checksum goes (the launch's kernel takes it: CA.Y.checksum)
-};
-// gfw_set_frame_checksums: the word of the next frame submitted on the context (nullptr: off)
-// (peek: the ring index advances — sum_commit — only once the frame has been enqueued; a call that fails consumes no slot, so "frame k submitted" keeps meaning what gfwarp.h says)
-static unsigned long long *next_sum(gfw_ctx *c) { return (c->sums && c->sum_n) ? c->sums + (c->sum_k % c->sum_n) : nullptr; }
-static void sum_commit(gfw_ctx *c, unsigned long long *sum) { if (sum) c->sum_k++; }
-// How many frames one launch of the specialised kernel takes.  The frames of a launch are worked through in order by every XCD with no barrier between them, and the
-// bytes they touch are in flight together: 8K frames (265 MB read + written each) measured 184 us per frame in launches of 2, 4 or 8 and 200-202 us in launches of
-// 16 (4.2 GB per launch); 4K frames (66 MB) 42.3-43.2 us anywhere from 8 to 16 (profiles/r06_c3_frames_per_launch.txt).  So a launch is capped at
-// GFW_CLIP_LAUNCH_BYTES of source + destination (1.1 GB: sixteen 4K 16-bit 4:2:2 frames, four 8K ones; never below 2 frames), and the frames of one
-// gfw_undistort_clip call are dealt evenly over the launches that needs (16 frames under a cap of 4: 4 + 4 + 4 + 4, not a runt at the end).
-static size_t clip_launch_bytes() {
-    static const size_t v = [] { const char *e = getenv("GFW_CLIP_LAUNCH_MB"); const long mb = e ? atol(e) : 0; return mb > 0 ? (size_t)mb << 20 : (size_t)1100 << 20; }();
-    return v;
-}
-static int clip_launch_limit(const GfwYuvArgs &Y, int nplanes, int n_call) {
-    size_t bytes = 0;
-    for (int i = 0; i < nplanes && i < 4; ++i) bytes += ((size_t)(Y.pl[i].src_stride < 0 ? -Y.pl[i].src_stride : Y.pl[i].src_stride) + (size_t)(Y.pl[i].dst_stride < 0 ? -Y.pl[i].dst_stride : Y.pl[i].dst_stride)) * (size_t)Y.pl[i].h;
-    int cap = bytes ? (int)(clip_launch_bytes() / bytes) : GFW_CLIP_MAX;
-    cap = cap < 2 ? 2 : (cap > GFW_CLIP_MAX ? GFW_CLIP_MAX : cap);
-    if (n_call > cap) { const int launches = (n_call + cap - 1) / cap; cap = (n_call + launches - 1) / launches; }
-    return cap;
-}
-// the launch's table of partial sums: one word per frame, workgroup and wave (gfw_frame.hip ck_flush)
-static int clip_flush(gfw_ctx *c, ClipBatch *b);
-static int ck_table(gfw_ctx *c, int grid, GfwYuvArgs &Y, ClipBatch *pending) {
-    const size_t need = (size_t)GFW_CLIP_MAX * (size_t)(grid > 4096 ? grid : 4096) * 4 * sizeof(unsigned long long);      // (2 MB: every grid the launcher picks on 256 CUs)
-    if (need > c->d_ck_part.cap && pending && pending->n > 0) { const int frc = clip_flush(c, pending); if (frc != GFW_OK) return frc; }     // (a pending launch names the table that is about to move)
-    HIP_TRY(c->d_ck_part.ensure(need), GFW_ERR_HIP);
-    Y.ck_part = (unsigned long long *)c->d_ck_part.ptr;
-    return GFW_OK;
-}
-static int ck_finish(gfw_ctx *c, const GfwClipArgs &CA, int grid, unsigned long long *const *sums) {
-    GfwCkSums S;
-    for (int i = 0; i < 16; ++i) S.sum[i] = i < CA.n_frames ? sums[i] : nullptr;
-    HIP_TRY(gfw_launch_ck_finish(CA.Y.ck_part, grid * 4, CA.n_frames, S, c->stream), GFW_ERR_HIP);
-    return GFW_OK;
-}
-static bool clip_same_shape(const gfw_buffers *a, const gfw_buffers *b, int nplanes) {
-    for (int i = 0; i < nplanes; ++i) {
-        const gfw_buffer_desc *x[2] = {&a[i].input, &a[i].output}, *y[2] = {&b[i].input, &b[i].output};
-        for (int k = 0; k < 2; ++k) {
-            if (x[k]->width != y[k]->width || x[k]->height != y[k]->height || x[k]->stride != y[k]->stride || x[k]->kind != y[k]->kind ||
-                x[k]->len != y[k]->len || x[k]->has_rect != y[k]->has_rect || x[k]->has_rotation != y[k]->has_rotation ||
-                memcmp(x[k]->rect, y[k]->rect, sizeof(x[k]->rect)) || x[k]->rotation != y[k]->rotation || !y[k]->data) return false;
-        }
-    }
-    return true;
-}
-static bool clip_ring_table(gfw_ctx *c, const float *m) {          // a table of gfw_build_matrices' cross-stream ring (ordered by events)
-    for (int i = 0; i < gfw_ctx::kBuiltSlots; ++i) if (c->bslots[i].buf.ptr == (const void *)m && c->bslots[i].built) return true;
-    return false;
-}
-// The frames of one launch are in flight together, the calls they stand for are ordered: a frame whose planes overlap a pending frame's
-// destination (it would read or overwrite that frame's output) or whose destination overlaps a pending frame's source must go out behind them.
-// A launch shares ONE argument block among its frames: everything but the per-frame pointers.  The specialised kernel reads a handful of fields from that
-// block at run time — plane-0's KernelParams (fov, lens_correction_amount, the refraction coefficient, background margin / feather, the digital lens's
-// parameters) and the host-evaluated uniforms (cos / sin of input_rotation, the rotated frame size) — and the jit key blanks them (they may move from
-// frame to frame: dynamic zoom, keyframed lens correction).  Frames that arrive through per-plane calls bring their OWN parameters: a frame may join a pending
-// launch only when these blocks are byte-identical to the launch's, else the pending frames go out first (gfw_undistort_clip shares one array by contract).
-static bool clip_same_params(const GfwYuvArgs &a, const GfwYuvArgs &b) {
-    if (memcmp(&a.kp, &b.kp, sizeof(a.kp)) != 0) return false;
-    GfwCommon ca = a.common, cb = b.common;
-    ca.matrices = cb.matrices = nullptr;              // the per-frame table: carried by GfwFrameDyn
-    if (memcmp(&ca, &cb, sizeof(ca)) != 0) return false;
-    for (int i = 0; i < 4; ++i) if (a.pl[i].src_len != b.pl[i].src_len || a.pl[i].dst_len != b.pl[i].dst_len) return false;
-    return true;
-}
-static bool clip_overlaps(const ClipBatch *b, const gfw_buffers *planes, int nplanes) {
-    auto hit = [](const uint8_t *p, size_t pl, const uint8_t *q, size_t ql) { return p && q && p < q + ql && q < p + pl; };
-    for (int k = 0; k < b->n; ++k) {
-        const GfwFrameDyn &F = b->CA.fr[k];
-        for (int i = 0; i < nplanes; ++i) {
-            const uint8_t *ns = (const uint8_t *)planes[i].input.data, *nd = (const uint8_t *)planes[i].output.data;
-            const size_t nsl = planes[i].input.len, ndl = planes[i].output.len;
-            for (int j = 0; j < nplanes && j < 4; ++j) {
-                const size_t sl = b->first[j].input.len, dl = b->first[j].output.len;
-                if (hit(nd, ndl, F.dst[j], dl) || hit(nd, ndl, F.src[j], sl) || hit(ns, nsl, F.dst[j], dl)) return true;
-            }
-        }
-    }
-    return false;
-}
-// diagnosis (GFW_JIT_DEFS=GFW_TIMELINE=1 builds): the per-wave clocks of the 40th launch of a specialised kernel go to $GFW_TIMELINE_FILE (tools/analyze_timeline.py)
-static void timeline_dump(gfw_ctx *c, hipFunction_t fn) {
-    static const char *tl_file = getenv("GFW_TIMELINE_FILE");
-    static int n_launch = 0;
-    if (tl_file && ++n_launch == 40) {
-        std::vector<unsigned long long> host(8192 * 8);
-        (void)hipStreamSynchronize(c->stream);
-        if (gfw_jit_read_symbol(fn, "gfw_tl", host.data(), host.size() * 8))
-            if (FILE *f = fopen(tl_file, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
-        if (gfw_jit_read_symbol(fn, "gfw_tl_blocks", host.data(), host.size() * 8))       // GFW_TIMELINE = 2 builds: the clocks of the branch-free row's blocks
-            if (FILE *f = fopen((std::string(tl_file) + ".blocks").c_str(), "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
-    }
-}
-static int clip_flush(gfw_ctx *c, ClipBatch *b) {
-    if (!b || b->n == 0) return GFW_OK;
-    b->CA.n_frames = b->n; b->CA.pad_ = 0;
-    prof_begin(c);
-    const hipError_t e = gfw_jit_launch(b->fn, b->CA, b->grid, c->stream);
-    int crc = GFW_OK;
-    if (e == hipSuccess && b->CA.Y.checksum) crc = ck_finish(c, b->CA, b->grid, b->sums);
-    prof_end(c, b->n);
-    timeline_dump(c, b->fn);
-    b->n = 0;
-    if (e != hipSuccess) { set_error("clip launch failed: %s", hipGetErrorString(e)); return GFW_ERR_HIP; }
-    return crc;
-}
+#include "gfw_api_clip.inc"
 
 #include "gfw_api_bake.inc"
 // gfw_set_frame_checksums behind a kernel that does not take the sum itself: a pass over what the frame's kernels wrote — the pixels of each plane's output rect
@@ -1034,370 +916,5 @@ int gfw_undistort_clip(gfw_ctx *c, int n_frames, int nplanes, const gfw_buffers 
 
 }  // extern "C"
 
-// ------------------------------------------------------------------------------------------------ test hooks
-extern "C" {
-int gfw_debug_math(int op, const float *a, const float *b, float *out, size_t n) {
-    if (!a || !out || n == 0) { set_error("null/empty arrays"); return GFW_ERR_INVALID_ARGUMENT; }
-    if (device_count() == 0) { set_error("no HIP device visible"); return GFW_ERR_NO_DEVICE; }
-    HIP_TRY(hipSetDevice(g_current_device), GFW_ERR_HIP);
-    DevBuf da, db, dout;                                   // released on every path
-    struct Release { DevBuf &x, &y, &z; ~Release() { x.release(); y.release(); z.release(); } } release{da, db, dout};
-    HIP_TRY(da.ensure(n * sizeof(float)), GFW_ERR_HIP);
-    HIP_TRY(dout.ensure(n * sizeof(float)), GFW_ERR_HIP);
-    if (b) HIP_TRY(db.ensure(n * sizeof(float)), GFW_ERR_HIP);
-    HIP_TRY(hipMemcpy(da.ptr, a, n * sizeof(float), hipMemcpyHostToDevice), GFW_ERR_HIP);
-    if (b) HIP_TRY(hipMemcpy(db.ptr, b, n * sizeof(float), hipMemcpyHostToDevice), GFW_ERR_HIP);
-    HIP_TRY(gfw_launch_debug_math(op, (const float *)da.ptr, (const float *)db.ptr, (float *)dout.ptr, n, nullptr), GFW_ERR_HIP);
-    HIP_TRY(hipMemcpy(out, dout.ptr, n * sizeof(float), hipMemcpyDeviceToHost), GFW_ERR_HIP);
-    return GFW_OK;
-}
-long long gfw_debug_selftest(int test, unsigned long long n, unsigned long long seed) {
-    if (device_count() == 0) { set_error("no HIP device visible"); return GFW_ERR_NO_DEVICE; }
-    HIP_TRY(hipSetDevice(g_current_device), GFW_ERR_HIP);
-    if (test == 2 && n == 0) n = 1ull << 31;
-    DevBuf dbad, none1, none2;
-    struct Release { DevBuf &x, &y, &z; ~Release() { x.release(); y.release(); z.release(); } } release{dbad, none1, none2};
-    unsigned long long bad = 0;
-    HIP_TRY(dbad.ensure(sizeof(bad)), GFW_ERR_HIP);
-    HIP_TRY(hipMemset(dbad.ptr, 0, sizeof(bad)), GFW_ERR_HIP);
-    HIP_TRY(gfw_launch_debug_selftest(test, n, seed, (unsigned long long *)dbad.ptr, nullptr), GFW_ERR_HIP);
-    HIP_TRY(hipMemcpy(&bad, dbad.ptr, sizeof(bad), hipMemcpyDeviceToHost), GFW_ERR_HIP);
-    return (long long)bad;
-}
-}
-
-// Verification helper of the frame-sharded clip run ("8 B checksum per frame"): adds the sum of the
-// buffer's u64 words (mod 2^64) to *d_out, in order on the context's stream.  `bytes` must be a multiple of 8 and the
-// buffer 16-byte aligned; d_out is a device pointer the caller zeroed.
-// Host-side build check of the run-time specialisation path (no device involved): compiles the embedded kernel source for `arch`
-// with the given ';'-separated -D definitions and bake header; returns the code object's size (optionally written to `out_path`).
-extern "C" long gfw_debug_jit_compile(const char *arch, const char *defines, const char *bake_header_text, const char *out_path, char *log, size_t cap) {
-    if (!arch || !defines || !bake_header_text) return GFW_ERR_INVALID_ARGUMENT;
-    std::vector<std::string> defs;
-    std::string cur;
-    for (const char *p = defines; ; ++p) {
-        if (*p == ';' || *p == 0) { if (!cur.empty()) defs.push_back(cur); cur.clear(); if (!*p) break; }
-        else cur += *p;
-    }
-    std::string lg;
-    std::vector<char> code;
-    const long n = gfw_jit_compile_only(arch, defs, bake_header_text, lg, &code);
-    if (log && cap) snprintf(log, cap, "%s", lg.c_str());
-    if (n > 0 && out_path && *out_path && !gfw_jit_write_code_object(out_path, code)) return GFW_ERR_UNKNOWN;
-    return n;
-}
-
-// The host side of a radial model's first-pass certificate without a device (tests/test_emu_pass1_audit.py feeds the interpreted kernel with it): the table of
-// GFW_P1_TABLE_N + 1 float pairs over r in [0, r_max] and {r_max, Tmax, T1, T2, e_table, nu2, d_min} (gfw_api_certificate.inc: p1_prepare_radial_gopro).
-// Returns 1 when a certificate exists for these coefficients and this range, 0 when the host declines, a negative GFW_ERR_* on bad arguments.
-extern "C" int gfw_debug_p1_radial(const gfw_kernel_params *params, int distortion_model, double r_max, float *table, double *out7) {
-    if (!params || !out7 || !p1_model_radial(distortion_model)) { set_error("gfw_debug_p1_radial: model %d has no radial certificate", distortion_model); return GFW_ERR_INVALID_ARGUMENT; }
-    P1Radial R; std::vector<float2> tab;
-    if (!p1_prepare_radial(distortion_model, *params, r_max, R, table ? &tab : nullptr)) return 0;
-    if (table) memcpy(table, tab.data(), tab.size() * sizeof(float2));
-    out7[0] = R.r_max; out7[1] = R.Tmax; out7[2] = R.T1; out7[3] = R.T2; out7[4] = R.etab; out7[5] = R.nu2; out7[6] = R.dmin;
-    return 1;
-}
-extern "C" int gfw_debug_source_id(char *out, size_t cap) {
-    if (!out || cap == 0) return GFW_ERR_INVALID_ARGUMENT;
-    const std::string id = gfw_jit_source_id();
-    snprintf(out, cap, "%s", id.c_str());
-    return (int)id.size();
-}
-
-// Build-time helper of the shipped kernel cache (tools/build_jit_cache.py; no device involved): what the library WOULD specialise a frame of these planes to —
-// the ';'-separated definition list, the bake header and the cache file name of the kernel (gfw_jit.hip) — exactly as run_planes / jit_for derive them on a
-// device, with `matrices_on_device` as the context option would be set (2: device-resident tables, the first pass's table range from the intrinsics).
-extern "C" int gfw_debug_jit_key(int nplanes, const gfw_buffers *planes, const gfw_kernel_params *params, const int *pixel_types, int distortion_model, int digital_lens,
-                                 const float *h_matrices, int matrix_count, int matrices_on_device, const char *arch,
-                                 char *defs_out, size_t defs_cap, char *header_out, size_t header_cap, char *name_out, size_t name_cap) {
-    if (!planes || !params || !pixel_types || !arch || nplanes < 1 || nplanes > 4) { set_error("bad arguments"); return GFW_ERR_INVALID_ARGUMENT; }
-    for (int i = 0; i < nplanes; ++i) {
-        if (pixel_types[i] < 0 || pixel_types[i] >= GFW_PIX_COUNT) { set_error("plane %d: unknown pixel type", i); return GFW_ERR_INVALID_ARGUMENT; }
-        const int rc = validate_plane(&planes[i], &params[i], pixel_types[i]);
-        if (rc != GFW_OK) return rc;
-    }
-    gfw_ctx c;
-    c.dry = true; c.model = distortion_model; c.digital = digital_lens; c.matrices_on_device = matrices_on_device; c.arch = arch;
-    GfwPlane launches[4];
-    memset(launches, 0, sizeof(launches));
-    for (int i = 0; i < nplanes; ++i) { launches[i].src = (const uint8_t *)planes[i].input.data; launches[i].dst = (uint8_t *)planes[i].output.data; }
-    GfwYuvArgs Y;
-    int bps = 0, n0 = 1, dw = 1, dh = 1; bool interleaved = false, fast1 = false;
-    if (!build_yuv_args(&c, nplanes, planes, params, pixel_types, launches, matrices_on_device ? nullptr : h_matrices, matrix_count, 0, Y, bps, n0, dw, dh, interleaved, fast1)) {
-        set_error("not a frame the fused kernel serves"); return GFW_ERR_UNSUPPORTED_BUFFER; }
-    fill_common(&c, &params[0], nullptr, nullptr, 0, Y.common);
-    const int jit_model = jit_model_of(Y);
-    const std::vector<std::string> defs = jit_defs(Y, bps, params[0].interpolation, n0, dw, dh, interleaved, fast1, jit_model, jit_waves(n0, Y.matrix_count, jit_model, Y.extras, params[0].interpolation, bps, dh));
-    std::string d;
-    for (const std::string &x : defs) { if (!d.empty()) d += ";"; d += x; }
-    const std::string header = bake_header(Y, fast1), name = gfw_jit_cache_name(arch, defs, header);
-    if (d.size() + 1 > defs_cap || header.size() + 1 > header_cap || name.size() + 1 > name_cap) { set_error("output buffers too small"); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
-    memcpy(defs_out, d.c_str(), d.size() + 1); memcpy(header_out, header.c_str(), header.size() + 1); memcpy(name_out, name.c_str(), name.size() + 1);
-    return GFW_OK;
-}
-
-extern "C" int gfw_checksum64(gfw_ctx *c, const void *d_buf, size_t bytes, unsigned long long *d_out) {
-    if (!c || !d_buf || !d_out || (bytes & 7) || ((uintptr_t)d_buf & 15)) { set_error("bad checksum arguments"); return GFW_ERR_INVALID_ARGUMENT; }
-    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }
-
-    HIP_TRY(gfw_launch_checksum64(d_buf, bytes, d_out, c->stream), GFW_ERR_HIP);
-    return GFW_OK;
-}
-
-extern "C" int gfw_set_frame_checksums(gfw_ctx *c, unsigned long long *d_sums, size_t count) {
-    if (!c) { set_error("null context"); return GFW_ERR_INVALID_ARGUMENT; }
-    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }          // frames being held were submitted under the previous setting
-    c->sums = (d_sums && count) ? d_sums : nullptr; c->sum_n = c->sums ? count : 0; c->sum_k = 0;
-    return GFW_OK;
-}
-
-extern "C" int gfw_pack_matrices(const float *rows14, int count, float *rows16) {
-    if (!rows14 || !rows16 || count < 0) { set_error("null arrays"); return GFW_ERR_INVALID_ARGUMENT; }
-    for (int r = 0; r < count; ++r) {
-        const float *m = rows14 + (size_t)r * 14;
-        float *o = rows16 + (size_t)r * GFW_MAT_STRIDE;
-        memcpy(o, m, 14 * sizeof(float));
-        if (m[9] != 0.0f || m[10] != 0.0f || m[11] != 0.0f || m[12] != 0.0f || m[13] != 0.0f) { o[14] = cosf(-m[11]); o[15] = sinf(-m[11]); }
-        else { o[14] = 1.0f; o[15] = 0.0f; }
-    }
-    return GFW_OK;
-}
-
-extern "C" {
-int gfw_set_quaternion_tracks(gfw_ctx *c, const int64_t *org_ts, const double *org_q, int org_n,
-                              const int64_t *sm_ts, const double *sm_q, int sm_n) {
-    if (!c || org_n < 0 || sm_n < 0 || (org_n && (!org_ts || !org_q)) || (sm_n && (!sm_ts || !sm_q))) { set_error("bad track arguments"); return GFW_ERR_INVALID_ARGUMENT; }
-    for (int i = 1; i < org_n; ++i) if (org_ts[i] <= org_ts[i - 1]) { set_error("original track timestamps must ascend"); return GFW_ERR_INVALID_ARGUMENT; }
-    for (int i = 1; i < sm_n; ++i) if (sm_ts[i] <= sm_ts[i - 1]) { set_error("smoothed track timestamps must ascend"); return GFW_ERR_INVALID_ARGUMENT; }
-    HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
-    const size_t b0 = (size_t)org_n * 8, b1 = (size_t)org_n * 32, b2 = (size_t)sm_n * 8, b3 = (size_t)sm_n * 32;
-    HIP_TRY(c->d_tracks.ensure(b0 + b1 + b2 + b3 + 64), GFW_ERR_HIP);
-    HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
-    char *base = (char *)c->d_tracks.ptr;
-    if (org_n) { HIP_TRY(hipMemcpy(base, org_ts, b0, hipMemcpyHostToDevice), GFW_ERR_HIP); HIP_TRY(hipMemcpy(base + b0, org_q, b1, hipMemcpyHostToDevice), GFW_ERR_HIP); }
-    if (sm_n) { HIP_TRY(hipMemcpy(base + b0 + b1, sm_ts, b2, hipMemcpyHostToDevice), GFW_ERR_HIP); HIP_TRY(hipMemcpy(base + b0 + b1 + b2, sm_q, b3, hipMemcpyHostToDevice), GFW_ERR_HIP); }
-    c->tracks.org_ts = (const int64_t *)base; c->tracks.org_q = (const double *)(base + b0); c->tracks.org_n = org_n;
-    c->tracks.sm_ts = (const int64_t *)(base + b0 + b1); c->tracks.sm_q = (const double *)(base + b0 + b1 + b2); c->tracks.sm_n = sm_n;
-    return GFW_OK;
-}
-int gfw_set_sync_offsets(gfw_ctx *c, double duration_ms, const int64_t *ts_us, const double *offsets_ms, int count) {
-    if (!c || count < 0 || (count && (!ts_us || !offsets_ms)) || !(duration_ms == duration_ms)) { set_error("bad sync-offset arguments"); return GFW_ERR_INVALID_ARGUMENT; }
-    for (int i = 1; i < count; ++i) if (ts_us[i] <= ts_us[i - 1]) { set_error("sync-offset timestamps must ascend"); return GFW_ERR_INVALID_ARGUMENT; }
-    HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
-    HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
-    if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream), GFW_ERR_HIP);
-    c->tracks.duration_ms = duration_ms; c->tracks.off_n = count; c->tracks.off_ts = nullptr; c->tracks.off_ms = nullptr;
-    if (count) {
-        HIP_TRY(c->d_offsets.ensure((size_t)count * 16), GFW_ERR_HIP);
-        char *base = (char *)c->d_offsets.ptr;
-        HIP_TRY(hipMemcpy(base, ts_us, (size_t)count * 8, hipMemcpyHostToDevice), GFW_ERR_HIP);
-        HIP_TRY(hipMemcpy(base + (size_t)count * 8, offsets_ms, (size_t)count * 8, hipMemcpyHostToDevice), GFW_ERR_HIP);
-        c->tracks.off_ts = (const int64_t *)base; c->tracks.off_ms = (const double *)(base + (size_t)count * 8);
-    }
-    return GFW_OK;
-}
-// Copies `count` frame descriptors into the next slot of the pinned/device rings on `stream`; returns the device pointer.
-static int stage_timings(gfw_ctx *c, const gfw_frame_timing *t, int count, hipStream_t stream, const gfw_frame_timing **d_out) {
-    if (!c->h_timings) {
-        HIP_TRY(hipHostMalloc((void **)&c->h_timings, sizeof(gfw_frame_timing) * gfw_ctx::kTimingSlots * gfw_ctx::kMaxBatch), GFW_ERR_HIP);
-        HIP_TRY(c->d_timings.ensure(sizeof(gfw_frame_timing) * gfw_ctx::kTimingSlots * gfw_ctx::kMaxBatch), GFW_ERR_HIP);
-        for (auto &e : c->timing_copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming), GFW_ERR_HIP);
-    }
-    const int slot = c->timing_next;
-    c->timing_next = (slot + 1) % gfw_ctx::kTimingSlots;
-    HIP_TRY(hipEventSynchronize(c->timing_copied[slot]), GFW_ERR_HIP);         // the copy that last read this pinned slot is done
-    gfw_frame_timing *h = c->h_timings + (size_t)slot * gfw_ctx::kMaxBatch;
-    gfw_frame_timing *d = (gfw_frame_timing *)c->d_timings.ptr + (size_t)slot * gfw_ctx::kMaxBatch;
-    memcpy(h, t, sizeof(gfw_frame_timing) * count);
-    HIP_TRY(hipMemcpyAsync(d, h, sizeof(gfw_frame_timing) * count, hipMemcpyHostToDevice, stream), GFW_ERR_HIP);
-    HIP_TRY(hipEventRecord(c->timing_copied[slot], stream), GFW_ERR_HIP);
-    *d_out = d;
-    return GFW_OK;
-}
-static bool timing_ok(const gfw_frame_timing *t) { return t->rows >= 1 && t->readout_dim >= 1 && t->suppress_rotation >= 0 && t->suppress_rotation <= 2; }
-
-int gfw_build_matrices(gfw_ctx *c, const gfw_frame_timing *t, float *rows16_out, float **out_ptr) {
-    return gfw_build_matrices_stab(c, t, nullptr, rows16_out, out_ptr);
-}
-int gfw_build_matrices_stab(gfw_ctx *c, const gfw_frame_timing *t, const gfw_frame_stab *stab, float *rows16_out, float **out_ptr) {
-    if (!c || !t) { set_error("null context/timing"); return GFW_ERR_INVALID_ARGUMENT; }
-    if (!timing_ok(t)) { set_error("rows %d, readout_dim %d, suppress_rotation %d", t->rows, t->readout_dim, t->suppress_rotation); return GFW_ERR_INVALID_ARGUMENT; }
-    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }
-    HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
-    GfwStab S, *Sp = nullptr;
-    gfw_ctx::StabSlot *stab_slot = nullptr; size_t stab_bytes = 0;
-    if (stab) {
-        if (stab->ibis_count < 0 || stab->ois_count < 0 || (stab->ibis_count && !stab->ibis) || (stab->ois_count && !stab->ois) ||
-            !(stab->crop_area[2] != 0.0) || !(stab->crop_area[3] != 0.0) || !(stab->pixel_pitch[0] != 0.0) || !(stab->pixel_pitch[1] != 0.0)) {
-            set_error("bad stabiliser data (counts %d/%d, crop %g x %g, pitch %g x %g)", stab->ibis_count, stab->ois_count, stab->crop_area[2], stab->crop_area[3], stab->pixel_pitch[0], stab->pixel_pitch[1]);
-            return GFW_ERR_INVALID_ARGUMENT; }
-        for (int i = 1; i < stab->ibis_count; ++i) if (!(stab->ibis[i * 4] >= stab->ibis[(i - 1) * 4])) { set_error("IBIS spline positions must ascend"); return GFW_ERR_INVALID_ARGUMENT; }
-        for (int i = 1; i < stab->ois_count; ++i) if (!(stab->ois[i * 4] >= stab->ois[(i - 1) * 4])) { set_error("OIS spline positions must ascend"); return GFW_ERR_INVALID_ARGUMENT; }
-        const size_t nb0 = (size_t)stab->ibis_count * 32, nb1 = (size_t)stab->ois_count * 32;
-        // next pair of the ring; the build that last read it (four builds ago) has normally long finished
-        gfw_ctx::StabSlot &ss = c->sslots[c->sslot_next];
-        c->sslot_next = (c->sslot_next + 1) % gfw_ctx::kStabSlots;
-        if (!ss.done) HIP_TRY(hipEventCreateWithFlags(&ss.done, hipEventDisableTiming), GFW_ERR_HIP);
-        if (ss.used) HIP_TRY(hipEventSynchronize(ss.done), GFW_ERR_HIP);
-        HIP_TRY(ss.d.ensure(nb0 + nb1 + 64), GFW_ERR_HIP);
-        if (ss.hcap < nb0 + nb1 + 64) {
-            if (ss.h) (void)hipHostFree(ss.h);
-            ss.h = nullptr; ss.hcap = 0;
-            HIP_TRY(hipHostMalloc(&ss.h, nb0 + nb1 + 64), GFW_ERR_HIP);
-            ss.hcap = nb0 + nb1 + 64;
-        }
-        stab_slot = &ss;
-        char *base = (char *)ss.d.ptr;
-        if (nb0) memcpy(ss.h, stab->ibis, nb0);
-        if (nb1) memcpy((char *)ss.h + nb0, stab->ois, nb1);
-        stab_bytes = nb0 + nb1;
-        const double inv = t->framebuffer_inverted ? -1.0 : 1.0;
-        S.offset = stab->offset; S.sensor_h = stab->sensor_size[1]; S.crop_y = stab->crop_area[1]; S.crop_h = stab->crop_area[3];
-        S.scale_x = stab->width / stab->crop_area[2] / stab->pixel_pitch[0];                       // frame_transform.rs:234-241
-        S.scale_y = stab->height / stab->crop_area[3] / stab->pixel_pitch[1] * inv;
-        S.height = stab->height;
-        S.ibis = (const double *)base; S.ois = (const double *)(base + nb0); S.ibis_n = stab->ibis_count; S.ois_n = stab->ois_count;
-        Sp = &S;
-    }
-    const size_t table_floats = (size_t)t->rows * GFW_MAT_STRIDE;
-    const gfw_frame_timing *d_t = nullptr;
-    if (rows16_out) {                                        // caller-owned table: built in order on the context's stream
-        HIP_TRY(c->d_prefix.ensure(4 * sizeof(double)), GFW_ERR_HIP);
-        { const int rc = stage_timings(c, t, 1, c->stream, &d_t); if (rc != GFW_OK) return rc; }
-        if (stab_slot && stab_bytes) HIP_TRY(hipMemcpyAsync(stab_slot->d.ptr, stab_slot->h, stab_bytes, hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
-        HIP_TRY(gfw_launch_build_matrices(c->tracks, d_t, 1, t->rows, (double *)c->d_prefix.ptr, rows16_out, table_floats, c->stream, Sp), GFW_ERR_HIP);
-        if (stab_slot) { HIP_TRY(hipEventRecord(stab_slot->done, c->stream), GFW_ERR_HIP); stab_slot->used = true; }
-        if (out_ptr) *out_ptr = rows16_out;
-        if (c->synchronous) HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
-        return GFW_OK;
-    }
-    // context-owned table: next slot of the ring, built on the auxiliary stream (overlaps the warp in flight)
-    gfw_ctx::BuiltSlot &b = c->bslots[c->bslot_next];
-    c->bslot_next = (c->bslot_next + 1) % gfw_ctx::kBuiltSlots;
-    const size_t table_bytes = table_floats * sizeof(float);
-    HIP_TRY(b.buf.ensure(table_bytes + 4 * sizeof(double)), GFW_ERR_HIP);
-    if (!b.built) { HIP_TRY(hipEventCreateWithFlags(&b.built, hipEventDisableTiming), GFW_ERR_HIP); HIP_TRY(hipEventCreateWithFlags(&b.consumed, hipEventDisableTiming), GFW_ERR_HIP); }
-    if (b.used) HIP_TRY(hipStreamWaitEvent(c->copy_stream, b.consumed, 0), GFW_ERR_HIP);   // the warp that read this slot is done
-    { const int rc = stage_timings(c, t, 1, c->copy_stream, &d_t); if (rc != GFW_OK) return rc; }
-    if (stab_slot && stab_bytes) HIP_TRY(hipMemcpyAsync(stab_slot->d.ptr, stab_slot->h, stab_bytes, hipMemcpyHostToDevice, c->copy_stream), GFW_ERR_HIP);
-    HIP_TRY(gfw_launch_build_matrices(c->tracks, d_t, 1, t->rows, (double *)((char *)b.buf.ptr + table_bytes), (float *)b.buf.ptr, table_floats, c->copy_stream, Sp), GFW_ERR_HIP);
-    HIP_TRY(hipEventRecord(b.built, c->copy_stream), GFW_ERR_HIP);
-    if (stab_slot) { HIP_TRY(hipEventRecord(stab_slot->done, c->copy_stream), GFW_ERR_HIP); stab_slot->used = true; }
-    if (out_ptr) *out_ptr = (float *)b.buf.ptr;
-    if (c->synchronous) HIP_TRY(hipStreamSynchronize(c->copy_stream), GFW_ERR_HIP);
-    return GFW_OK;
-}
-// The tables of `count` upcoming frames in one launch, in order on the context's stream: no cross-stream events, and the
-// builder's latency (a few slerps in f64 per row) is paid once per batch instead of once per frame.
-int gfw_build_matrices_batch(gfw_ctx *c, const gfw_frame_timing *t, int count, float **out_ptrs) {
-    if (!c || !t || !out_ptrs || count < 1 || count > gfw_ctx::kMaxBatch) { set_error("bad batch arguments (1 <= count <= %d)", gfw_ctx::kMaxBatch); return GFW_ERR_INVALID_ARGUMENT; }
-    int max_rows = 0;
-    for (int i = 0; i < count; ++i) {
-        if (!timing_ok(&t[i])) { set_error("frame %d: rows %d, readout_dim %d, suppress_rotation %d", i, t[i].rows, t[i].readout_dim, t[i].suppress_rotation); return GFW_ERR_INVALID_ARGUMENT; }
-        if (t[i].rows > max_rows) max_rows = t[i].rows;
-    }
-    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }
-    HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
-    // two batches alternate: the stream is in order, so the batch being overwritten was consumed by launches enqueued before this one (held frames have just left)
-    DevBuf &buf = c->d_batch[c->batch_next];
-    c->batch_next ^= 1;
-    const size_t table_floats = (size_t)max_rows * GFW_MAT_STRIDE;
-    const size_t tables_bytes = table_floats * sizeof(float) * count;
-    HIP_TRY(buf.ensure(tables_bytes + 4 * sizeof(double) * count), GFW_ERR_HIP);
-    const gfw_frame_timing *d_t = nullptr;
-    { const int rc = stage_timings(c, t, count, c->stream, &d_t); if (rc != GFW_OK) return rc; }
-    HIP_TRY(gfw_launch_build_matrices(c->tracks, d_t, count, max_rows, (double *)((char *)buf.ptr + tables_bytes), (float *)buf.ptr, table_floats, c->stream), GFW_ERR_HIP);
-    for (int i = 0; i < count; ++i) out_ptrs[i] = (float *)buf.ptr + table_floats * i;
-    if (c->synchronous) HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
-    return GFW_OK;
-}
-}
-
-// Inverse point map (`undistort_points`, cpu_undistort.rs:652-858; the STMap "dist"
-// pass stmap.rs:123-127 runs it per pixel).  See include/gfwarp.h for the argument contract.
-extern "C" int gfw_undistort_points(gfw_ctx *c, const gfw_kernel_params *p, const float *points, size_t n, int grid_width,
-                                    const float *rotations, int rotation_count, const float *shifts, int index_mode,
-                                    const double *mesh, size_t mesh_len, float *out, int out_on_device) {
-    if (!c || !p || !rotations || !out || rotation_count < 1 || index_mode < 0 || index_mode > 3) { set_error("bad undistort_points arguments"); return GFW_ERR_INVALID_ARGUMENT; }
-    if (!points && grid_width < 1) { set_error("grid_width must be >= 1 when points is NULL"); return GFW_ERR_INVALID_ARGUMENT; }
-    if (mesh_len > GFW_MESH_MAX) { set_error("mesh too large"); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
-    { const int mrc = validate_mesh(mesh, mesh_len); if (mrc != GFW_OK) return mrc; }
-    if (n == 0) return GFW_OK;                                               // :637 `if distorted.is_empty() { return Vec::new(); }`
-    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }
-    HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
-    GfwPointsArgs A;
-    memset(&A, 0, sizeof(A));
-    A.n = n; A.grid_w = grid_width; A.rotation_count = rotation_count; A.index_mode = index_mode;
-    const size_t pts_bytes = n * 2 * sizeof(float);
-    if (points) {
-        HIP_TRY(c->d_pts_in.ensure(pts_bytes), GFW_ERR_HIP);
-        HIP_TRY(hipMemcpyAsync(c->d_pts_in.ptr, points, pts_bytes, hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
-        A.points = (const float *)c->d_pts_in.ptr;
-    }
-    HIP_TRY(c->d_pts_rot.ensure((size_t)rotation_count * 9 * sizeof(float)), GFW_ERR_HIP);
-    HIP_TRY(hipMemcpyAsync(c->d_pts_rot.ptr, rotations, (size_t)rotation_count * 9 * sizeof(float), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
-    A.rotations = (const float *)c->d_pts_rot.ptr;
-    std::vector<float> packed;
-    if (shifts) {
-        // cos/sin of the roll angle by the host libm, exactly what the reference evaluates per point (:756-757)
-        packed.resize((size_t)rotation_count * 6);
-        for (int i = 0; i < rotation_count; ++i) {
-            const float *s = shifts + (size_t)i * 5;
-            float *d = packed.data() + (size_t)i * 6;
-            d[0] = s[0]; d[1] = s[1]; d[2] = cosf(s[2]); d[3] = sinf(s[2]); d[4] = s[3]; d[5] = s[4];
-        }
-        HIP_TRY(c->d_pts_shift.ensure(packed.size() * sizeof(float)), GFW_ERR_HIP);
-        HIP_TRY(hipMemcpyAsync(c->d_pts_shift.ptr, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
-        A.shifts = (const float *)c->d_pts_shift.ptr;
-    }
-    if (mesh && mesh_len) {
-        HIP_TRY(c->d_pts_mesh.ensure(mesh_len * sizeof(double)), GFW_ERR_HIP);
-        HIP_TRY(hipMemcpyAsync(c->d_pts_mesh.ptr, mesh, mesh_len * sizeof(double), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
-        A.mesh = (const double *)c->d_pts_mesh.ptr; A.mesh_len = (int)mesh_len;
-    }
-    float *d_out = out;
-    if (!out_on_device) { HIP_TRY(c->d_pts_out.ensure(pts_bytes), GFW_ERR_HIP); d_out = (float *)c->d_pts_out.ptr; }
-    A.out = d_out;
-    GfwCommon C;
-    fill_common(c, p, nullptr, nullptr, 0, C);
-    HIP_TRY(gfw_launch_points(*p, C, A, c->stream), GFW_ERR_HIP);
-    c->last_backend = "points";
-    if (!out_on_device) HIP_TRY(hipMemcpyAsync(out, d_out, pts_bytes, hipMemcpyDeviceToHost, c->stream), GFW_ERR_HIP);
-    // host staging vectors (packed shifts) and pageable copies: always complete before returning
-    HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
-    return GFW_OK;
-}
-
-// STMap "undist" coordinate map (src/core/stmap.rs:87-109, :127-137): coords is width*height*2 f32, host or device
-// memory (coords_on_device); pixels whose projection is None keep their previous content, as parallel_exr leaves 0.
-extern "C" int gfw_stmap_undistort(gfw_ctx *c, const gfw_kernel_params *p, const float *matrices, int matrix_count,
-                                   const float *mesh, size_t mesh_len, int width, int height, float *coords, int coords_on_device) {
-    if (!c || !p || !coords || width < 1 || height < 1) { set_error("bad stmap arguments"); return GFW_ERR_INVALID_ARGUMENT; }
-    if (p->matrix_count != matrix_count || matrix_count < 1) { set_error("matrix_count %d != %d", p->matrix_count, matrix_count); return GFW_ERR_INVALID_ARGUMENT; }
-    if (mesh_len > GFW_MESH_MAX) { set_error("mesh too large"); return GFW_ERR_BUFFER_SIZE_MISMATCH; }
-    { const int mrc = validate_mesh(mesh, mesh_len); if (mrc != GFW_OK) return mrc; }
-    { const int frc_ = flush_if_pending(c); if (frc_ != GFW_OK) return frc_; }
-    HIP_TRY(hipSetDevice(c->device), GFW_ERR_HIP);
-    const float *d_mat = nullptr;
-    int rc = upload_matrices(c, matrices, matrix_count, &d_mat);
-    if (rc != GFW_OK) return rc;
-    const float *d_mesh = nullptr;
-    if (mesh && mesh_len) { HIP_TRY(hipMemcpyAsync(c->d_mesh.ptr, mesh, mesh_len * sizeof(float), hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP); d_mesh = (const float *)c->d_mesh.ptr; }
-    GfwCommon C;
-    fill_common(c, p, d_mat, d_mesh, (int)mesh_len, C);
-    const size_t bytes = (size_t)width * height * 2 * sizeof(float);
-    float *d_coords = coords;
-    if (!coords_on_device) {
-        if (c->stage_dst.empty()) c->stage_dst.resize(1);
-        HIP_TRY(c->stage_dst[0].ensure(bytes), GFW_ERR_HIP);
-        d_coords = (float *)c->stage_dst[0].ptr;
-        HIP_TRY(hipMemcpyAsync(d_coords, coords, bytes, hipMemcpyHostToDevice, c->stream), GFW_ERR_HIP);
-    }
-    HIP_TRY(gfw_launch_stmap(*p, C, width, height, d_coords, c->stream), GFW_ERR_HIP);
-    c->last_backend = "stmap";
-    { const int mrc = matrices_consumed(c); if (mrc != GFW_OK) return mrc; }
-    if (!coords_on_device) HIP_TRY(hipMemcpyAsync(coords, d_coords, bytes, hipMemcpyDeviceToHost, c->stream), GFW_ERR_HIP);
-    if (c->synchronous || !coords_on_device) HIP_TRY(hipStreamSynchronize(c->stream), GFW_ERR_HIP);
-    return GFW_OK;
-}
+#include "gfw_api_testhooks.inc"
+#include "gfw_api_adjacent.inc"

@@ -806,6 +806,11 @@ __device__ __forceinline__ void gfw_sample(float uvx, float uvy, const float *ja
             for (int in_x = b0; in_x <= b1; ++in_x) {
                 const float in_fx = (float)in_x - uvx;
                 const float dr = in_fx * in_fx * A + in_fx * in_fy2 + in_fy3;
+                // (round 6) a tap outside the filter's support leaves before its root is taken: a correctly rounded root is below 2 exactly when its operand is
+                // below 4 (sqrt(4 - 2^-22) = 2 - 2^-24 - 2^-50..., under the midpoint of the last two floats below 2), and a NaN fails both forms of the test — so
+                // this is `kk == 0 -> continue` of the reference for those taps, decided 25 instructions earlier.  Neighbouring lanes sit at neighbouring
+                // offsets of the same tap, so the corners of the bounding box (55-60 % of it for a near-identity jacobian) are dead for whole waves.
+                if (!(dr < 4.0f)) continue;
                 float xx = gfw_fabsf(sqrtf(dr));
                 const float x2 = xx * xx;
                 float kk = 0.0f;
