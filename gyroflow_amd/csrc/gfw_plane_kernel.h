@@ -31,7 +31,10 @@ __device__ __forceinline__ void gfw_tile_coords(int tiles_x, int tiles_y, int &t
     ty = t / tiles_x; tx = t - ty * tiles_x;
 }
 
-template <int PIX, int I, int MODEL>
+// DUAL (EWA only, round 6): the launch also warps a second plane that shares every kernel parameter but the background — U and V of a planar frame: their
+// coordinates, jacobians and tap weights are the same numbers, so they are worked out once and only the sums are kept twice (cpu_undistort.rs:331-369 per plane:
+// the same operations on the same operands in the same order for each of the two).  The host decides (gfw_api.hip run_planes).
+template <int PIX, int I, int MODEL, bool DUAL = false>
 __global__ __launch_bounds__(256) void gfw_plane_kernel(const GfwPlane A, const GfwCommon C) {
     constexpr int N = GfwPix<PIX>::N;
     constexpr int BPP = GfwPix<PIX>::BPP;
@@ -55,10 +58,11 @@ __global__ __launch_bounds__(256) void gfw_plane_kernel(const GfwPlane A, const 
     if (!(opx >= 0.0f && opy >= 0.0f && gfw_f2i(opx) < P.output_width && gfw_f2i(opy) < P.output_height)) return;
 
     uint8_t *pix_out = A.dst + (int64_t)y * A.dst_stride + (int64_t)x * BPP;
-    float bg[N], pixel[N];
+    uint8_t *pix_out2 = DUAL ? A.dst2 + (int64_t)y * A.dst_stride + (int64_t)x * BPP : nullptr;
+    float bg[N], pixel[N], bg2[N], pixel2[N];
     #pragma unroll
-    for (int c = 0; c < N; ++c) { bg[c] = P.background[c] * P.max_pixel_value; pixel[c] = bg[c]; }     // :523
-    if ((P.flags & 4) == 4) { GfwPix<PIX>::store(pix_out, bg); return; }                              // :558-561
+    for (int c = 0; c < N; ++c) { bg[c] = P.background[c] * P.max_pixel_value; pixel[c] = bg[c]; bg2[c] = DUAL ? A.background2[c] * P.max_pixel_value : 0.0f; pixel2[c] = bg2[c]; }     // :523
+    if ((P.flags & 4) == 4) { GfwPix<PIX>::store(pix_out, bg); if constexpr (DUAL) GfwPix<PIX>::store(pix_out2, bg2); return; }                              // :558-561
     const bool fix_range = (P.flags & 1) == 1, is_y = P.plane_index == 0;
 
     GfwPt uv = gfw_undistort_coord_fullres<MODEL>((float)x, (float)y, P, C);
@@ -92,20 +96,22 @@ __global__ __launch_bounds__(256) void gfw_plane_kernel(const GfwPlane A, const 
             float ux = uv.x, uy = uv.y;
             gfw_to_source_rect(ux, uy, P, C);
             gfw_to_source_rect(p2x, p2y, P, C);
-            float c1[N], c2[N];
-            gfw_sample<PIX, I>(ux, uy, jac, P, A.src, bg, lut, c1);
-            gfw_sample<PIX, I>(p2x, p2y, jac, P, A.src, bg, lut, c2);
+            float c1[N], c2[N], d1[N], d2[N];
+            gfw_sample<PIX, I, DUAL>(ux, uy, jac, P, A.src, bg, lut, c1, A.src2, bg2, d1);
+            gfw_sample<PIX, I, DUAL>(p2x, p2y, jac, P, A.src, bg, lut, c2, A.src2, bg2, d2);
             #pragma unroll
-            for (int c = 0; c < N; ++c) pixel[c] = c1[c] * alpha + c2[c] * (1.0f - alpha);
-            if (fix_range) gfw_remap_colorrange<N>(pixel, is_y);
+            for (int c = 0; c < N; ++c) { pixel[c] = c1[c] * alpha + c2[c] * (1.0f - alpha); if constexpr (DUAL) pixel2[c] = d1[c] * alpha + d2[c] * (1.0f - alpha); }
+            if (fix_range) { gfw_remap_colorrange<N>(pixel, is_y); if constexpr (DUAL) gfw_remap_colorrange<N>(pixel2, is_y); }
             GfwPix<PIX>::store(pix_out, pixel);
+            if constexpr (DUAL) GfwPix<PIX>::store(pix_out2, pixel2);
             return;
         }
         gfw_to_source_rect(uv.x, uv.y, P, C);                                                          // :510-515
-        gfw_sample<PIX, I>(uv.x, uv.y, jac, P, A.src, bg, lut, pixel);
+        gfw_sample<PIX, I, DUAL>(uv.x, uv.y, jac, P, A.src, bg, lut, pixel, A.src2, bg2, pixel2);
     }
-    if (fix_range) gfw_remap_colorrange<N>(pixel, is_y);
+    if (fix_range) { gfw_remap_colorrange<N>(pixel, is_y); if constexpr (DUAL) gfw_remap_colorrange<N>(pixel2, is_y); }
     GfwPix<PIX>::store(pix_out, pixel);
+    if constexpr (DUAL) GfwPix<PIX>::store(pix_out2, pixel2);
 }
 
 
@@ -117,6 +123,16 @@ static hipError_t launch_plane_pi(const GfwPlane &A, const GfwCommon &C, hipStre
     const int grid = ((n + 7) >> 3) << 3;
     if (grid <= 0) return hipSuccess;
     dim3 block(64, 4);
+    if constexpr (I == 0 && GfwPix<PIX>::N == 1) {
+        if (A.src2) {                                      // EWA on a pair of single-channel planes (the host paired them: run_planes)
+            if (C.model == GFW_MODEL_OPENCV_FISHEYE && C.mesh_len == 0)
+                hipLaunchKernelGGL((gfw_plane_kernel<PIX, I, GFW_MODEL_OPENCV_FISHEYE, true>), dim3(grid), block, 0, s, A, C);
+            else
+                hipLaunchKernelGGL((gfw_plane_kernel<PIX, I, -1, true>), dim3(grid), block, 0, s, A, C);
+            return hipGetLastError();
+        }
+    }
+    if (A.src2) return hipErrorInvalidValue;               // (never paired by the host for anything else)
     if (C.model == GFW_MODEL_OPENCV_FISHEYE && C.mesh_len == 0)
         hipLaunchKernelGGL((gfw_plane_kernel<PIX, I, GFW_MODEL_OPENCV_FISHEYE>), dim3(grid), block, 0, s, A, C);
     else

@@ -25,6 +25,11 @@ struct GfwPlane {
     int32_t out_rows;        // ceil(dst_len / dst_stride)
     int32_t out_cols;        // dst_stride / bytes_per_pixel
     int32_t pix;             // GFW_PIX_*
+    // EWA on planar chroma (round 6): a second plane with the SAME kernel parameters but for its background — U and V of a planar frame — warped by the launch of the
+    // first: one set of coordinates, one jacobian, one set of tap weights, two sums (gfw_plane_kernel<.., DUAL>).  nullptr: an ordinary launch.
+    const uint8_t *src2;
+    uint8_t *dst2;
+    float background2[4];    // the second plane's KernelParams::background
 };
 
 struct GfwCommon {
@@ -753,14 +758,16 @@ template <> struct GfwPix<GFW_PIX_RGBAF16> {   // half 2.7.1 from_f32/to_f32 = I
 
 // ----------------------------------------------------------------------------
 // sample_input_at: cpu_undistort.rs:329-419.  I in {2,4,8}: LUT taps; I == 0: EWA.
-template <int PIX, int I>
+template <int PIX, int I, bool DUAL = false>
 __device__ __forceinline__ void gfw_sample(float uvx, float uvy, const float *jac, const gfw_kernel_params &P, const uint8_t *src,
-                                           const float *bg, const float *lut /* LDS or global COEFFS */, float *out) {
+                                           const float *bg, const float *lut /* LDS or global COEFFS */, float *out,
+                                           const uint8_t *src2 = nullptr, const float *bg2 = nullptr, float *out2 = nullptr) {
     constexpr int N = GfwPix<PIX>::N;
     constexpr int BPP = GfwPix<PIX>::BPP;
-    float sum[N];
+    static_assert(!DUAL || I == 0, "the second plane rides on the EWA sampler only");
+    float sum[N], sum2[N];       // DUAL: the second plane's sums — same taps, same weights, same order of additions as a launch of its own
     #pragma unroll
-    for (int c = 0; c < N; ++c) sum[c] = 0.0f;
+    for (int c = 0; c < N; ++c) { sum[c] = 0.0f; sum2[c] = 0.0f; }
     const int sr0 = P.source_rect[0], sr1 = P.source_rect[1];
     const int sr0e = P.source_rect[0] + P.source_rect[2], sr1e = P.source_rect[1] + P.source_rect[3];
     if constexpr (I == 0) {
@@ -817,16 +824,18 @@ __device__ __forceinline__ void gfw_sample(float uvx, float uvy, const float *ja
                 if (xx < 1.0f)      kk = P.ewa_coeffs_p[0] + P.ewa_coeffs_p[1] * xx + P.ewa_coeffs_p[2] * x2 + P.ewa_coeffs_p[3] * x2 * xx;
                 else if (xx < 2.0f) kk = P.ewa_coeffs_q[0] + P.ewa_coeffs_q[1] * xx + P.ewa_coeffs_q[2] * x2 + P.ewa_coeffs_q[3] * x2 * xx;
                 if (kk == 0.0f) continue;
-                float px[N];
-                if (yin && in_x >= sr0 && in_x < sr0e) GfwPix<PIX>::load(src + (int64_t)in_y * P.stride + (int64_t)in_x * BPP, px);
-                else { _Pragma("unroll") for (int c2 = 0; c2 < N; ++c2) px[c2] = bg[c2]; }
+                float px[N], qx[N];
+                if (yin && in_x >= sr0 && in_x < sr0e) {
+                    GfwPix<PIX>::load(src + (int64_t)in_y * P.stride + (int64_t)in_x * BPP, px);
+                    if constexpr (DUAL) GfwPix<PIX>::load(src2 + (int64_t)in_y * P.stride + (int64_t)in_x * BPP, qx);
+                } else { _Pragma("unroll") for (int c2 = 0; c2 < N; ++c2) { px[c2] = bg[c2]; if constexpr (DUAL) qx[c2] = bg2[c2]; } }
                 #pragma unroll
-                for (int c2 = 0; c2 < N; ++c2) sum[c2] = sum[c2] + kk * px[c2];
+                for (int c2 = 0; c2 < N; ++c2) { sum[c2] = sum[c2] + kk * px[c2]; if constexpr (DUAL) sum2[c2] = sum2[c2] + kk * qx[c2]; }
                 sum_div += kk;
             }
         }
         #pragma unroll
-        for (int c2 = 0; c2 < N; ++c2) sum[c2] = too_large ? bg[c2] : sum[c2] / sum_div;
+        for (int c2 = 0; c2 < N; ++c2) { sum[c2] = too_large ? bg[c2] : sum[c2] / sum_div; if constexpr (DUAL) sum2[c2] = too_large ? bg2[c2] : sum2[c2] / sum_div; }
     } else {
         constexpr int SHIFT = (I >> 2) + 1;
         constexpr float OFFSET = (I == 2) ? 0.0f : (I == 4 ? 1.0f : 3.0f);
@@ -872,7 +881,7 @@ __device__ __forceinline__ void gfw_sample(float uvx, float uvy, const float *ja
         }
     }
     #pragma unroll
-    for (int c = 0; c < N; ++c) out[c] = gfw_min(sum[c], P.pixel_value_limit);
+    for (int c = 0; c < N; ++c) { out[c] = gfw_min(sum[c], P.pixel_value_limit); if constexpr (DUAL) out2[c] = gfw_min(sum2[c], P.pixel_value_limit); }
 }
 
 // remap_colorrange: cpu_undistort.rs:254-260 (only the first N lanes exist)

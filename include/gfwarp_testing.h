@@ -43,6 +43,10 @@ int   gfw_debug_source_id(char *out, size_t cap);
  * path's Newton result, min POLY'}.  1: certificate derived; 0: the host declines for these coefficients / this range (the clip keeps the exact first pass). */
 int   gfw_debug_p1_radial(const gfw_kernel_params *params, int distortion_model, double r_max, float *table, double *out7);
 
+/* How many launches of the per-plane kernel on this context served TWO planes (round 6: EWA on the U and V planes of a planar frame — one set of coordinates and
+ * tap weights, two sums; the backend name stays "plane_generic").  -1 for a null context. */
+long long gfw_debug_paired_launches(gfw_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

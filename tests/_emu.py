@@ -537,6 +537,32 @@ def run_plane(fr, idx, mesh=None):
     return dst
 
 
+def run_plane_pair(fr, idx, mesh=None):
+    """Planes `idx` and `idx + 1` (U and V of a planar frame under EWA) through ONE host-interpreted launch of gfw_plane_kernel<.., DUAL> — the pairing
+    gfw_api.hip run_planes makes when the two planes share every kernel parameter but plane_index and the background -> the two outputs."""
+    pa, pb = fr.planes[idx], fr.planes[idx + 1]
+    p = pa["params"]
+    assert p.interpolation >= 10 and pa["pixel_type"] == pb["pixel_type"]
+    pix = abi.PIXEL_TYPES[pa["pixel_type"]][0]
+    mesh_len = 0 if mesh is None else len(mesh)
+    model = abi.MODELS["opencv_fisheye"] if (fr.model == abi.MODELS["opencv_fisheye"] and mesh_len == 0) else -1
+    lib = C.CDLL(build({"EMU_PIX": pix, "EMU_I": 0, "EMU_MODEL": model, "EMU_DUAL": 1}, "", top="gfw_plane_kernel.h", n_asm=2, driver="emu_plane_driver.inc", extra_flags=()))
+    lib.gfw_emu_launch_plane2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    com = common_for(fr, p, mesh)
+    keep = None
+    if mesh_len:
+        keep = np.ascontiguousarray(mesh, dtype=np.float32)
+        com.mesh, com.mesh_len = keep.ctypes.data, keep.size
+    packed = warp.pack_matrices(fr.matrices)
+    srcs = [np.concatenate([np.ascontiguousarray(pl["src"]), np.zeros(64, np.uint8)]) for pl in (pa, pb)]
+    dsts = [pl["dst"].copy() for pl in (pa, pb)]
+    bg2 = (C.c_float * 4)(*[float(v) for v in pb["params"].background])
+    rc = lib.gfw_emu_launch_plane2(C.cast(C.byref(p), C.c_void_p), srcs[0].ctypes.data, dsts[0].ctypes.data, dsts[0].size, pa["out_size"][2], packed.ctypes.data,
+                                   C.cast(C.byref(com), C.c_void_p), srcs[1].ctypes.data, dsts[1].ctypes.data, C.cast(bg2, C.c_void_p))
+    assert rc == 0, "gfw_emu_launch_plane2 -> %d" % rc
+    return dsts
+
+
 def run_frame_per_plane(fr, mesh=None):
     return [run_plane(fr, i, mesh) for i in range(len(fr.planes))]
 

@@ -165,6 +165,26 @@ def test_per_plane_ewa_against_the_oracle(interp):
     per_plane_same_as_oracle(S.SyntheticFrame("YUV422P16LE", 160, 96, seed=5, fov=1.3, interpolation=interp))
 
 
+@pytest.mark.parametrize("fmt,interp,kw", [
+    ("YUV422P16LE", 10, dict(fov=1.6, background_rgba=(0.9, 0.2, 0.4, 1.0))),
+    ("YUV420P", 12, dict(fov=1.4, background_rgba=(0.1, 0.8, 0.3, 1.0), base_overrides={"background_mode": 1})),
+    ("YUV444P16LE", 11, dict(fov=1.3, background_rgba=(0.3, 0.6, 0.9, 1.0), base_overrides={"background_mode": 3, "background_margin": 0.1, "background_margin_feather": 0.12})),
+    ("YUV420P", 13, dict(fov=1.2, flags=abi.FLAG_FIX_COLOR_RANGE, limited_range=True)),
+])
+def test_ewa_on_paired_chroma_planes_against_the_oracle(fmt, interp, kw):
+    """gfw_plane_kernel<.., DUAL> (round 6): U and V of a planar frame through ONE launch — one set of coordinates, jacobians and tap weights, two sums, each
+    plane's own background — must write what the oracle writes for each plane on its own (cpu_undistort.rs:331-369 per plane)."""
+    fr = S.SyntheticFrame(fmt, 160, 96, seed=15 + interp, interpolation=interp, **kw)
+    assert len(fr.planes) >= 3 and fr.planes[1]["pixel_type"] == fr.planes[2]["pixel_type"]
+    got = _emu.run_plane_pair(fr, 1)
+    for k, i in enumerate((1, 2)):
+        pl = fr.planes[i]
+        ref = pl["dst"].copy()
+        assert O.undistort_image(pl["src"], pl["size"], ref, pl["out_size"], pl["params"], pl["pixel_type"], fr.model, fr.digital, fr.matrices) == 1
+        assert np.array_equal(ref, got[k]), "plane %d: %d bytes differ" % (i, int(np.count_nonzero(ref != got[k])))
+    assert not np.array_equal(got[0], got[1])
+
+
 @pytest.mark.parametrize("fmt", ["RGB24", "RGB48BE", "AYUV64LE", "RGBAF16"])
 def test_per_plane_pixel_types_against_the_oracle(fmt):
     per_plane_same_as_oracle(S.SyntheticFrame(fmt, 200, 120, seed=6, fov=1.5, background_rgba=(0.2, 0.4, 0.6, 0.8)))
