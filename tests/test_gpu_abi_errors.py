@@ -84,6 +84,8 @@ def test_asynchronous_mode_with_many_frames_in_flight():
     dsts = [[torch.zeros(pl["dst"].nbytes, dtype=torch.uint8, device=dev) for pl in fr.planes] for fr in frames]
     bufs = [[warp.device_buffers(s.data_ptr(), s.numel(), pl["size"], d.data_ptr(), d.numel(), pl["out_size"])
              for s, d, pl in zip(ss, dd, fr.planes)] for ss, dd, fr in zip(srcs, dsts, frames)]
+    torch.cuda.synchronize(dev)          # the uploads and zero fills above run on torch's stream, the warps on the context's own: without this a fill can land
+                                         # AFTER the frame it was meant to precede (seen once beside three other GPU processes: a plane of zeros, gpurun_out/r06_z)
     be = warp.Backend(frames[0].planes[0]["params"], types[0], frames[0].model, 0, bufs[0][0])
     try:
         be.set_option(abi.OPT_SYNCHRONOUS, 0)

@@ -171,6 +171,7 @@ def test_ibis_terms_with_device_resident_matrices(mode):
     dev = torch.device("cuda", 0)
     host = fr.matrices if mode == 1 else warp.pack_matrices(fr.matrices)
     d_mat = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
+    torch.cuda.synchronize(dev)                              # (the table is uploaded on torch's stream, read on the context's)
     for variant in (0, 1):                                   # fused (generic-model instantiation) and per-plane kernels
         outs = [pl["dst"].copy() for pl in fr.planes]
         bufs = [warp.host_buffers(pl["src"], pl["size"], o, pl["out_size"]) for pl, o in zip(fr.planes, outs)]

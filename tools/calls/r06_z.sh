@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6, call y (and z, after the row prefetch): EWA on planar chroma — U and V in one launch (gfw_plane_kernel<.., DUAL>): its test, the suites that reach the per-plane kernel, the EWA benches
-O=gpurun_out/r06_y; mkdir -p $O; : > $O/summary.txt
+O=gpurun_out/r06_z; mkdir -p $O; : > $O/summary.txt
 export TMPDIR=/tmp
 timeout 1500 python3 -m pytest tests/test_gpu_ewa_pair.py tests/test_gpu_fuzz.py tests/test_gpu_parity.py tests/test_gpu_fused_coverage.py tests/test_gpu_coalesce.py tests/test_gpu_checksum.py tests/test_gpu_abi_errors.py -q -m gpu --tb=short -p no:cacheprovider -n 4 2>&1 | grep -v "amdgpu.ids" | tail -6 | tee -a $O/summary.txt
 rec() { local name="$1"; shift; timeout 600 python3 bench.py --gpus 1 "$@" > $O/bench_$name.json 2> $O/bench_$name.err
