@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 6, call ab: the GPU tier serially in ONE process, as the driver runs it (after kMaxEntries 256 -> 4096), then under -n 4; the driver's bench line
+O=gpurun_out/r06_ab; mkdir -p $O; : > $O/summary.txt
+export TMPDIR=/tmp
+timeout 1500 python3 -m pytest tests -q -m gpu -x --tb=long -p no:cacheprovider > $O/suite_serial.log 2>&1; tail -4 $O/suite_serial.log | tee -a $O/summary.txt
+timeout 900 python3 -m pytest tests -q -m gpu -n 4 -rf --tb=long -p no:cacheprovider > $O/suite_n4.log 2>&1; tail -3 $O/suite_n4.log | tee -a $O/summary.txt; grep -n "^FAILED\|^ERROR" $O/suite_n4.log | head
+timeout 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee -a $O/summary.txt
+timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err; tail -c 1800 $O/bench_driver.json | tee -a $O/summary.txt
