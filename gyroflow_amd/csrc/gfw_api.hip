@@ -754,8 +754,11 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
                 q.plane_index = params[i].plane_index;
                 memcpy(q.background, params[i].background, sizeof(q.background));
                 const GfwPlane &a = launches[i], &b = launches[i + 1];
+                // (the two launches it replaces run one after the other: the second plane may not read or overwrite what the first writes, nor the first the second's)
+                auto apart = [](const uint8_t *p, size_t pn, const uint8_t *r, size_t rn) { return p + pn <= r || r + rn <= p; };
+                const size_t il = planes[i].input.len, ol = (size_t)a.dst_len;
                 paired = memcmp(&q, &params[i], sizeof(q)) == 0 && a.dst_len == b.dst_len && a.dst_stride == b.dst_stride && a.out_rows == b.out_rows && a.out_cols == b.out_cols &&
-                         planes[i].input.len == planes[i + 1].input.len && a.src != b.src && a.dst != b.dst;
+                         planes[i].input.len == planes[i + 1].input.len && apart(a.dst, ol, b.dst, ol) && apart(a.dst, ol, b.src, il) && apart(b.dst, ol, a.src, il);
             }
             fill_common(c, &params[i], d_mat, d_mesh, (int)mesh_len, C);
             if (paired) {
