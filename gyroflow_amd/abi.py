@@ -166,6 +166,7 @@ def bind(lib):
     lib.gfw_last_error.restype = C.c_char_p
     lib.gfw_debug_source_id.argtypes = [C.c_char_p, sz]; lib.gfw_debug_source_id.restype = i32
     lib.gfw_debug_paired_launches.argtypes = [vp]; lib.gfw_debug_paired_launches.restype = C.c_longlong
+    lib.gfw_debug_frames_per_launch.argtypes = [C.c_ulonglong, C.c_ulonglong, i32]; lib.gfw_debug_frames_per_launch.restype = i32
     lib.gfw_pixel_type_info.argtypes = [i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_float)]
     lib.gfw_pixel_type_info.restype = i32
     return lib
@@ -174,7 +175,7 @@ def bind(lib):
 EXPORTS = ["gfw_abi_version", "gfw_list_devices", "gfw_set_device", "gfw_get_info", "gfw_is_buffer_supported",
            "gfw_create", "gfw_destroy", "gfw_undistort_image", "gfw_undistort_frame", "gfw_set_option",
            "gfw_get_stream", "gfw_set_stream", "gfw_synchronize", "gfw_flush", "gfw_import_external_fd", "gfw_release_external", "gfw_last_backend", "gfw_get_profile", "gfw_last_error", "gfw_debug_math", "gfw_debug_jit_key", "gfw_debug_selftest", "gfw_get_audit", "gfw_pack_matrices", "gfw_checksum64", "gfw_set_frame_checksums", "gfw_set_quaternion_tracks", "gfw_build_matrices", "gfw_build_matrices_stab", "gfw_set_sync_offsets", "gfw_build_matrices_batch", "gfw_stmap_undistort", "gfw_undistort_points",
-           "gfw_pixel_type_info", "gfw_undistort_clip", "gfw_jit_status", "gfw_get_profile_frames", "gfw_debug_jit_compile", "gfw_debug_source_id", "gfw_debug_p1_radial", "gfw_debug_paired_launches"]
+           "gfw_pixel_type_info", "gfw_undistort_clip", "gfw_jit_status", "gfw_get_profile_frames", "gfw_debug_jit_compile", "gfw_debug_source_id", "gfw_debug_p1_radial", "gfw_debug_paired_launches", "gfw_debug_frames_per_launch"]
 
 
 def load_library(path=None):

@@ -47,6 +47,11 @@ int   gfw_debug_p1_radial(const gfw_kernel_params *params, int distortion_model,
  * tap weights, two sums; the backend name stays "plane_generic").  -1 for a null context. */
 long long gfw_debug_paired_launches(gfw_ctx *ctx);
 
+/* How many frames one launch of a gfw_undistort_clip call takes (no device needed): frames of `bytes_per_frame` of source + destination under a budget of
+ * `budget_bytes` per launch (0: the library's, 1.1 GB or GFW_CLIP_LAUNCH_MB), `frames_in_call` frames dealt evenly over the launches that needs (0: frames held
+ * from per-plane calls — the cap alone).  Between 2 and GFW_CLIP_FRAMES_MAX. */
+int   gfw_debug_frames_per_launch(unsigned long long bytes_per_frame, unsigned long long budget_bytes, int frames_in_call);
+
 #ifdef __cplusplus
 }
 #endif

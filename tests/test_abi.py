@@ -108,3 +108,28 @@ def test_the_shipped_library_carries_no_timing_ablation():
     assert src.count("[GFW-TESTING-BEGIN]") == src.count("[GFW-TESTING-END]") >= 2
     shipped = gen_jit_source.amalgam()
     assert "GFW_ABLATE_FORCE" not in shipped and "#define GFW_ABL(bits) (0)" in shipped
+
+
+def test_frames_per_launch_of_a_clip_call():
+    """gfw_api_clip.inc clip_frames_per_launch (round 6): a launch is capped by the bytes it keeps in flight and a call's frames are dealt evenly — never fewer than
+    two, never more than GFW_CLIP_FRAMES_MAX, no runt at the end."""
+    lib = abi.load_library()
+    f = lib.gfw_debug_frames_per_launch
+    MB, budget = 1 << 20, 1100 << 20
+    c2, c3, c1 = 3840 * 2160 * 2 * 2 * 2, 7680 * 4320 * 2 * 2 * 2, 1920 * 1080 * 3
+    # the value is the launch's LIMIT: a call of no more frames than fit leaves in one launch, a longer one in launches of equal size
+    assert f(c2, budget, 16) == 16 and f(c2, budget, 10) == 16 and f(c2, budget, 20) == 10          # sixteen 4K 16-bit 4:2:2 frames are 1.06 GB; 20 -> 10 + 10
+    assert f(c3, budget, 16) == 4 and f(c3, budget, 10) == 4 and f(c3, budget, 0) == 4                # 8K: four to a launch; 10 -> 4 + 4 + 2 (ceil(10 / 3))
+    assert f(c1, budget, 16) == 16 and f(c1, budget, 40) == 14                                       # 40 small frames: 14 + 14 + 12
+    assert f(4000 * MB, budget, 16) == 2                                                             # never fewer than two
+    assert f(0, budget, 7) == 16 and f(c2, 600 * MB, 16) == 8 and f(c2, 600 * MB, 10) == 5           # 600 MB: nine fit, 16 -> 8 + 8, 10 -> 5 + 5
+    for n in range(1, 64):
+        for bytes_per_frame in (c1, c2, c3, 300 * MB):
+            k = f(bytes_per_frame, budget, n)
+            cap = f(bytes_per_frame, budget, 0)
+            assert 2 <= k <= cap <= 16
+            if n <= cap:
+                assert k == cap
+            else:
+                assert -(-n // k) == -(-n // cap), (n, bytes_per_frame, k, cap)                      # dealing evenly never costs a launch
+                assert k * (-(-n // k)) - n < -(-n // k), (n, k)                                     # ... and the last launch is short by less than one frame per launch
