@@ -102,7 +102,10 @@ struct Entry {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
     void join() { std::lock_guard<std::mutex> lk(join_mu); if (worker.joinable()) worker.join(); }
-    ~Entry() { join(); }
+    // At process exit only (join_all_workers): a build that has not come back within the hook's patience is left behind — the thread is detached and dies with the
+    // process — instead of being waited for without end (see join_all_workers).
+    void abandon() { std::lock_guard<std::mutex> lk(join_mu); if (worker.joinable()) worker.detach(); }
+    ~Entry() { if (state.load(std::memory_order_acquire) == ST_COMPILING) abandon(); else join(); }
 };
 
 std::mutex g_mu;
@@ -207,10 +210,23 @@ static void cache_store(const std::string &hash, const std::vector<char> &code) 
     (void)write_atomically(std::string(e) + "/" + hash + rtc_tag() + ".co", code);
 }
 
+// The exit hook.  It waits for the builds in flight — but not without end.  The hook is older than the exit handlers of everything the compiler constructs lazily
+// DURING a compile (LLVM's function-local statics and managed statics, first touched on the worker thread): those run before it, under the compile, and can leave
+// the worker blocked for good on something that no longer exists.  Preloading the compiler's libraries (rtc()) took the libraries' own handlers out of that race and
+// made the hang rare, not impossible: once in the round's last serial run of the GPU tier `tests/cpp/test_multi_device 4 36` printed "multi-device ok", left main()
+// with its background build still compiling and sat in exit() until the 120 s watchdog (gpurun_out/r06_ab, profiles/r06_exit_during_build.txt).  So: a build gets
+// GFW_EXIT_WAIT_MS (default 20 s; a build takes 0.3-1 s, a few seconds beside other processes) to come back; one that does not is detached and ends with the process.
 void join_all_workers() {
     std::vector<std::shared_ptr<Entry>> all;
     { std::lock_guard<std::mutex> lk(g_mu); for (auto &kv : g_cache) all.push_back(kv.second); }
-    for (auto &e : all) e->join();
+    const char *env = getenv("GFW_EXIT_WAIT_MS");
+    const long patience_ms = (env && atol(env) >= 0) ? atol(env) : 20000;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(patience_ms);
+    for (auto &e : all) {
+        while (e->state.load(std::memory_order_acquire) == ST_COMPILING && std::chrono::steady_clock::now() < deadline) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        if (e->state.load(std::memory_order_acquire) != ST_COMPILING) e->join();          // published its result: the thread is on its way out
+        else e->abandon();
+    }
 }
 
 void compile_entry(Entry *e, std::string source, std::vector<std::string> opts, std::string hash) {
