@@ -748,8 +748,10 @@ static int run_planes(gfw_ctx *c, int nplanes, const gfw_buffers *planes, const 
             // colour-range fix asks only whether a plane is luma) and the background — one KernelParams: the coordinates, jacobians and tap weights of their pixels
             // are the same numbers.  One launch works them out once and keeps two sets of sums (gfw_plane_kernel<.., DUAL>): 1.43 -> 1.11 ms per C2 frame.
             bool paired = false;
+            // (plane_index is read for one thing, the colour-range fix's luma / chroma scale: without the flag any two planes qualify — the four planes of a planar
+            // float frame leave as two launches —, with it two planes that are both chroma)
             if (i + 1 < nplanes && params[i].interpolation >= 10 && PIX_N[pixel_types[i]] == 1 && pixel_types[i] == pixel_types[i + 1] &&
-                params[i].plane_index != 0 && params[i + 1].plane_index != 0) {
+                ((params[i].plane_index != 0 && params[i + 1].plane_index != 0) || (((params[i].flags | params[i + 1].flags) & GFW_FLAG_FIX_COLOR_RANGE) == 0))) {
                 gfw_kernel_params q = params[i + 1];
                 q.plane_index = params[i].plane_index;
                 memcpy(q.background, params[i].background, sizeof(q.background));

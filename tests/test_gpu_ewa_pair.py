@@ -39,8 +39,8 @@ def run_counted(fr, mutate=None):
     ("YUV444P16LE", 11, dict(fov=1.3, background_rgba=(0.3, 0.6, 0.9, 1.0), base_overrides={"background_mode": 3, "background_margin": 0.1, "background_margin_feather": 0.12}), 1),
     ("YUV420P", 13, dict(fov=1.2, flags=abi.FLAG_FIX_COLOR_RANGE, limited_range=True), 1),
     ("YUV420P10LE", 10, dict(fov=0.9), 1),
-    ("GBRAPF32LE", 10, dict(fov=1.4, background_rgba=(0.7, 0.1, 0.5, 0.9)), 1),        # four float planes: 1 and 2 share a launch, 0 (plane_index 0) and 3 go alone
-    ("YUVA444P10LE", 12, dict(fov=1.3, background_rgba=(0.2, 0.9, 0.4, 0.6)), 1),      # Y, U + V, A
+    ("GBRAPF32LE", 10, dict(fov=1.4, background_rgba=(0.7, 0.1, 0.5, 0.9)), 2),        # four float planes of one geometry, no colour-range fix: 0 + 1 and 2 + 3
+    ("YUVA444P10LE", 12, dict(fov=1.3, background_rgba=(0.2, 0.9, 0.4, 0.6)), 2),      # 4:4:4 with alpha, no colour-range fix: Y + U, V + A
     ("NV12", 10, dict(fov=1.5, background_rgba=(0.9, 0.2, 0.4, 1.0)), 0),              # interleaved chroma is one two-channel plane already
     ("RGBA", 12, dict(fov=1.5), 0),
     ("YUV422P16LE", 4, dict(fov=1.5), 0),                                               # not EWA: the fused kernel's frame
