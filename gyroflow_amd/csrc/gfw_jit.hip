@@ -104,8 +104,12 @@ struct Entry {
     void join() { std::lock_guard<std::mutex> lk(join_mu); if (worker.joinable()) worker.join(); }
     // At process exit only (join_all_workers): a build that has not come back within the hook's patience is left behind — the thread is detached and dies with the
     // process — instead of being waited for without end (see join_all_workers).
-    void abandon() { std::lock_guard<std::mutex> lk(join_mu); if (worker.joinable()) worker.detach(); }
-    ~Entry() { if (state.load(std::memory_order_acquire) == ST_COMPILING) abandon(); else join(); }
+    // (try_lock: a context's thread may itself be waiting inside join() for this very build — GFW_OPT_JIT = 2 — when main() returns: the hook must not queue behind it)
+    void abandon() { std::unique_lock<std::mutex> lk(join_mu, std::try_to_lock); if (lk.owns_lock() && worker.joinable()) worker.detach(); }
+    ~Entry() {
+        if (state.load(std::memory_order_acquire) == ST_COMPILING) abandon(); else join();
+        if (worker.joinable()) (void)new std::thread(std::move(worker));       // could not be detached (see abandon): a joinable std::thread must never be destroyed
+    }
 };
 
 std::mutex g_mu;
