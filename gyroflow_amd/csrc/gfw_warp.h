@@ -805,12 +805,15 @@ __device__ __forceinline__ void gfw_sample(float uvx, float uvy, const float *ja
         // jacobian makes the CPU loop run for hours and would hang a GPU queue.  Footprints above GFW_EWA_MAX_TAPS source
         // pixels per output pixel are written as background instead.
         const bool too_large = ((int64_t)b1 - b0 + 1) * ((int64_t)b3 - b2 + 1) > (int64_t)GFW_EWA_MAX_TAPS;
-        for (int in_y = b2; in_y <= (too_large ? b2 - 1 : b3); ++in_y) {
+        // Both loops run over INCLUSIVE ranges whose ends may be INT_MAX (gfw_f2i saturates: coordinates at or beyond 2^31, an infinite jacobian entry) — `in_x <= b1`
+        // would never turn false there and `b2 - 1` would wrap at INT_MIN; the reference's `bounds.0..=bounds.1` visits each index once.  So: leave AT the last index
+        // (the counter is advanced only when another index follows; `continue` reaches the advance like any other path).
+        for (int in_y = b2, more_y = (!too_large && b2 <= b3) ? 1 : 0; more_y; more_y = in_y != b3, in_y += more_y) {
             const float in_fy = (float)in_y - uvy;
             const float in_fy2 = in_fy * B;
             const float in_fy3 = in_fy * in_fy * Cc;
             const bool yin = in_y >= sr1 && in_y < sr1e;
-            for (int in_x = b0; in_x <= b1; ++in_x) {
+            for (int in_x = b0, more_x = b0 <= b1 ? 1 : 0; more_x; more_x = in_x != b1, in_x += more_x) {
                 const float in_fx = (float)in_x - uvx;
                 const float dr = in_fx * in_fx * A + in_fx * in_fy2 + in_fy3;
                 // (round 6) a tap outside the filter's support leaves before its root is taken: a correctly rounded root is below 2 exactly when its operand is
